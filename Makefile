@@ -1,0 +1,36 @@
+# Build of the MI355X loop-detection core (gfx950 only) and of the CPU oracle (test infrastructure).
+#   make            -> cerebro_amd/lib/libcerebro_hip.so  + oracle/_build/liboracle.so
+#   make lib / make oracle / make clean
+HIPCC      ?= /opt/rocm/bin/hipcc
+ARCH       ?= gfx950
+# -ffp-contract=off: the PnP kernels must round exactly like the oracle (no FMA contraction);
+# the scan kernel uses explicit fma() where the product is exact.
+HIPFLAGS   ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -Wall -Wno-unused-function
+CC         ?= gcc
+ORCFLAGS   ?= -O2 -ffp-contract=off -fopenmp -fPIC -Wall -Wextra
+
+LIBDIR     := cerebro_amd/lib
+CSRC       := cerebro_amd/csrc
+HIP_SRCS   := $(CSRC)/kernels.hip $(CSRC)/chip_api.hip $(CSRC)/pnp.hip
+HIP_OBJS   := $(HIP_SRCS:$(CSRC)/%.hip=$(LIBDIR)/%.o)
+ORC_SRCS   := $(wildcard oracle/*.c)
+
+all: lib oracle
+lib: $(LIBDIR)/libcerebro_hip.so
+oracle: oracle/_build/liboracle.so
+
+$(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/chip_internal.h include/cerebro_hip.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libcerebro_hip.so: $(HIP_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@
+
+oracle/_build/liboracle.so: $(ORC_SRCS) oracle/cerebro_oracle.h
+	@mkdir -p oracle/_build
+	$(CC) $(ORCFLAGS) -shared $(ORC_SRCS) -o $@ -lm
+
+clean:
+	rm -rf $(LIBDIR) oracle/_build
+
+.PHONY: all lib oracle clean

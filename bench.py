@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X loop-detection core.
+
+A "step" is one tick of Cerebro::descrip_N__dot__descrip_0_N (src/Cerebro.cpp:956-1100): the three newest
+descriptors (rows l-1, l-2, l-3) against the DB prefix [0, l-50), top-k, accept rule -- on the workload
+BASELINE.json's metric is quoted on: synthetic 4096-D fp32 descriptors x 1M keyframes.
+
+  python bench.py --gpus N --steps K --warmup W
+  N > 1 (torchrun, one rank per GPU): the 1M-row DB is row-sharded round-robin over the N GPUs (BASELINE
+  config 4, strong scaling); each tick = local scan -> RCCL all-gather of 3 x top-k (score,index) per rank
+  -> merge + decision on every rank.
+
+Prints ONE JSON line (rank 0).  `value` = ticks/s with the DB resident in HBM.  `roofline` prices the
+dominant kernel (db_scan_topk) by its ALGORITHMIC bytes (4*D*rows scanned per launch) over its
+mean duration measured with hipEvents on the kernel's own stream (chip_profile_*).  `cpu_baseline` times the
+oracle's reference-faithful fp64 path (three separate GEMVs, single thread like the reference's
+dot_product_th) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+D = 4096
+LAG = 50
+TOPK = 8
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
+SEED = 20190412
+
+
+def plan_ticks(rows_scanned: int, n_ticks: int):
+    """l_i = rows_scanned + LAG + 3*i ; every 4th tick is a planted revisit (fires the :1056 rule)."""
+    ls = [rows_scanned + LAG + 3 * i for i in range(n_ticks)]
+    rng = np.random.default_rng(1)
+    plants = []
+    expect = []
+    for i, l in enumerate(ls):
+        if i % 4 == 0:
+            p = int(rng.integers(1000, rows_scanned - 1000))
+            for j in range(3):
+                plants.append((l - 1 - j, p - j, 1))
+            expect.append((l - 1, p))
+        else:
+            expect.append(None)
+    return ls, sorted(plants), expect
+
+
+def cpu_baseline(sample_cols: int, budget_s: float):
+    """Reference-faithful CPU path (oracle port): fp64 column-major M, 3 separate GEMVs + maxCoeff + last-index
+    argmax (Cerebro.cpp:1023-1043), one thread.  Returns ticks/s extrapolated to the 1M-row tick."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib  # checker/baseline only -- never on the product path
+    M = oracle_lib.synth_rows(SEED, range(sample_cols + 3), D).astype(np.float64)
+    v, vm, vmm = M[sample_cols + 2].copy(), M[sample_cols + 1].copy(), M[sample_cols].copy()
+    oracle_lib.ref_scan_f64_colmajor(M, 1000, v, vm, vmm)  # touch
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        oracle_lib.ref_scan_f64_colmajor(M, sample_cols, v, vm, vmm)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 50:
+            break
+    cols_per_s = n * sample_cols / dt
+    return cols_per_s, n, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=1_000_000, help="DB rows scanned per tick (k)")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="columns in the CPU baseline sample")
+    ap.add_argument("--inflight", type=int, default=16)
+    args = ap.parse_args()
+
+    import torch
+    from cerebro_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+
+    n_ticks = args.warmup + args.steps
+    ls, plants, expect = plan_ticks(args.rows, n_ticks)
+    total_rows = ls[-1]
+
+    chip = capi.Chip(D, capacity_hint=total_rows, device=local_rank, shard_rank=rank, shard_count=world)
+    info = chip.info()
+    t_fill = time.perf_counter()
+    chip.append_synthetic(total_rows, SEED, plants)
+    t_fill = time.perf_counter() - t_fill
+    params = capi.default_dot_params()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        chip.synchronize()
+
+    results = []
+    if world == 1:
+        def run(tick_ls):
+            out = []
+            W = max(1, min(args.inflight, capi.CHIP_MAX_INFLIGHT - 1))
+            pending = []
+            for i, l in enumerate(tick_ls):
+                if len(pending) == W:
+                    out.append(chip.loop_tick_collect(pending.pop(0)))
+                s = i % W
+                chip.loop_tick_enqueue(l, s, params)
+                pending.append(s)
+            while pending:
+                out.append(chip.loop_tick_collect(pending.pop(0)))
+            return out
+    else:
+        stream = torch.cuda.current_stream()
+        chip.set_stream(stream.cuda_stream)
+        local = torch.zeros((3, TOPK, 2), dtype=torch.float64, device="cuda")
+        gathered = torch.zeros((world, 3, TOPK, 2), dtype=torch.float64, device="cuda")
+
+        def run(tick_ls):
+            out = []
+            for l in tick_ls:
+                st = chip.scan_local(l, local.data_ptr(), TOPK, params)
+                assert st == capi.CHIP_TICK_SCANNED
+                dist.all_gather_into_tensor(gathered, local)        # RCCL over xGMI: 384 B per rank
+                out.append(chip.merge_decide(l, gathered.data_ptr(), world, TOPK, params))
+            return out
+
+    chip.loop_reset()
+    barrier()
+    run(ls[:args.warmup])
+    chip.profile_enable(True)
+    chip.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    results = run(ls[args.warmup:])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    scan_ms, n_launch, bytes_last = chip.profile_scan()
+    chip.profile_enable(False)
+
+    # sanity (not the parity check -- that is tests/ -m gpu): planted revisits must fire with the planted index
+    exp = expect[args.warmup:]
+    for r, e in zip(results, exp):
+        if e is not None:
+            assert r.found == 1 and r.idx_curr == e[0] and r.idx_prev == e[1], (r.as_dict(), e)
+        else:
+            assert r.found == 0, r.as_dict()
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        local_rows = (args.rows + world - 1) // world
+        alg_bytes = 4.0 * D * local_rows                       # one pass of the fp32 DB prefix (this rank's share)
+        avg_s = scan_ms / 1e3 / max(1, n_launch)
+        achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        traffic = None
+        pj = ROOT / "profiles" / "scan_traffic.json"
+        if pj.exists():
+            try:
+                traffic = json.loads(pj.read_text()).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "loop-queries/sec (ticks of 3 descriptors vs 4096-D x 1M DB)",
+            "value": args.steps / elapsed,
+            "unit": "ticks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32 storage, f64 accumulate",
+            "data": "synthetic (on-device integer-domain generator, seed 20190412, planted revisits)",
+            "config": {"workload": f"4096-D fp32 descriptors x {args.rows} keyframe DB, 3 queries/tick, top-{TOPK} + accept rule",
+                       "db_rows": args.rows, "D": D, "queries_per_tick": 3, "topk": TOPK,
+                       "sharding": "single GPU" if world == 1 else f"row round-robin over {world} GPUs + RCCL all-gather of top-k",
+                       "descriptor_queries_per_s": 3 * args.steps / elapsed,
+                       "db_fill_s": t_fill, "arch": info["arch"], "n_cus": info["n_cus"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "db_scan_topk", "avg_kernel_ms": avg_s * 1e3, "launches": n_launch,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and args.cpu_budget > 0:
+            cols_per_s, n, dt = cpu_baseline(args.cpu_sample, args.cpu_budget)
+            out["cpu_baseline"] = {"value": cols_per_s / args.rows, "unit": "ticks/s", "cores": 1, "kind": "port",
+                                   "sample": f"{n} ticks of 3 fp64 GEMVs over a {args.cpu_sample}-column x 4096 column-major M "
+                                             f"({dt:.1f} s), scaled to {args.rows} columns; host has {os.cpu_count()} cores, "
+                                             "reference path is single-threaded (Eigen without OpenMP)"}
+        print(json.dumps(out), flush=True)
+
+    chip.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

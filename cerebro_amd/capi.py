@@ -1,0 +1,335 @@
+"""ctypes binding of libcerebro_hip.so (include/cerebro_hip.h).
+
+Plumbing only: every compute call goes through the C-ABI into the HIP kernels.  There is NO CPU
+fallback -- if the shared library is missing or a call fails, a ChipError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libcerebro_hip.so"
+
+CHIP_OK = 0
+CHIP_ERR_INVALID_ARG = -1
+CHIP_ERR_NO_DEVICE = -2
+CHIP_ERR_HIP = -3
+CHIP_ERR_OOM = -4
+CHIP_ERR_NOT_F32 = -5
+CHIP_ERR_NONFINITE = -6
+CHIP_ERR_RANGE = -7
+CHIP_ERR_UNSUPPORTED = -8
+CHIP_ERR_TOO_FEW_POINTS = -9
+CHIP_ERR_BUSY = -10
+
+CHIP_MAX_TOPK = 16
+CHIP_MAX_NQ = 4
+CHIP_DEFAULT_TOPK = 8
+CHIP_RING_ROWS = 64
+CHIP_MAX_INFLIGHT = 64
+CHIP_APPEND_ALLOW_ROUNDING = 1
+
+CHIP_TICK_SKIPPED, CHIP_TICK_TOO_SHORT, CHIP_TICK_SCANNED = 0, 1, 2
+
+
+class ChipError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{where}: status {status} ({_strerror(status)}){' -- ' + detail if detail else ''}")
+
+
+class DotParams(C.Structure):
+    _fields_ = [("locality", C.c_int32), ("lag", C.c_int32), ("min_new", C.c_int32), ("min_k", C.c_int32),
+                ("thresh", C.c_double)]
+
+
+class TickResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("found", C.c_int32), ("idx_curr", C.c_int64), ("idx_prev", C.c_int64),
+                ("score", C.c_double), ("argmax", C.c_int64 * 3), ("maxv", C.c_double * 3)]
+
+    def as_dict(self):
+        return dict(status=self.status, found=self.found, idx_curr=self.idx_curr, idx_prev=self.idx_prev,
+                    score=self.score, argmax=list(self.argmax), maxv=list(self.maxv))
+
+
+class TopkEntry(C.Structure):
+    _fields_ = [("score", C.c_double), ("idx", C.c_int64)]
+
+
+class RansacParams(C.Structure):
+    _fields_ = [("error_thresh", C.c_double), ("min_inlier_ratio", C.c_double), ("max_iterations", C.c_int32),
+                ("min_iterations", C.c_int32), ("use_mle", C.c_int32), ("sample_size", C.c_int32),
+                ("failure_probability", C.c_double), ("seed", C.c_uint64), ("n_hypotheses", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class RansacSummary(C.Structure):
+    _fields_ = [("n_iterations", C.c_int32), ("n_inliers", C.c_int32), ("best_hypothesis", C.c_int32),
+                ("n_models", C.c_int32), ("best_cost", C.c_double)]
+
+
+class Info(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("D", C.c_int32), ("device", C.c_int32), ("shard_rank", C.c_int32),
+                ("shard_count", C.c_int32), ("n_cus", C.c_int32), ("rows_global", C.c_int64),
+                ("rows_local", C.c_int64), ("capacity_local", C.c_int64), ("lossy_rows", C.c_int64),
+                ("arch", C.c_char * 32)]
+
+
+# every symbol include/cerebro_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_SIGS = {
+    "chip_strerror": (C.c_char_p, [C.c_int]),
+    "chip_abi_version": (C.c_int, []),
+    "chip_last_hip_error": (C.c_int, [_P, C.POINTER(C.c_char_p)]),
+    "chip_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "chip_destroy": (None, [_P]),
+    "chip_set_stream": (C.c_int, [_P, _P]),
+    "chip_synchronize": (C.c_int, [_P]),
+    "chip_db_append_f64": (C.c_int, [_P, _P, C.c_int64, C.c_uint32, C.POINTER(C.c_int64)]),
+    "chip_db_append_f32": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "chip_db_size": (C.c_int64, [_P]),
+    "chip_db_read_rows_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "chip_db_append_synthetic": (C.c_int, [_P, C.c_int64, C.c_uint64, _P, _P, _P, C.c_int64]),
+    "chip_query_rows": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
+    "chip_query_vectors_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
+    "chip_dot_params_default": (None, [C.POINTER(DotParams)]),
+    "chip_loop_tick": (C.c_int, [_P, C.c_int64, C.POINTER(DotParams), C.POINTER(TickResult)]),
+    "chip_loop_tick_enqueue": (C.c_int, [_P, C.c_int64, C.POINTER(DotParams), C.c_int32]),
+    "chip_loop_tick_collect": (C.c_int, [_P, C.c_int32, C.POINTER(TickResult)]),
+    "chip_loop_last_l": (C.c_int64, [_P]),
+    "chip_loop_reset": (None, [_P]),
+    "chip_scan_local": (C.c_int, [_P, C.c_int64, C.POINTER(DotParams), C.c_int32, _P, C.POINTER(C.c_int32)]),
+    "chip_merge_decide": (C.c_int, [_P, C.c_int64, C.POINTER(DotParams), _P, C.c_int32, C.c_int32, C.POINTER(TickResult)]),
+    "chip_ransac_params_default": (None, [C.POINTER(RansacParams)]),
+    "chip_pnp_ransac": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(RansacParams), _P, C.POINTER(C.c_float), _P,
+                                  C.POINTER(RansacSummary)]),
+    "chip_get_info": (C.c_int, [_P, C.POINTER(Info)]),
+    "chip_profile_enable": (C.c_int, [_P, C.c_int32]),
+    "chip_profile_reset": (C.c_int, [_P]),
+    "chip_profile_scan": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load_library(path: os.PathLike | None = None) -> C.CDLL:
+    """Load libcerebro_hip.so and bind every declared symbol.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise FileNotFoundError(
+            f"{p} not found: the HIP extension is not built. Run `make lib` (or __graft_entry__.build()). "
+            "cerebro_amd has no CPU fallback.")
+    lib = C.CDLL(str(p))
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def _strerror(status: int) -> str:
+    try:
+        return load_library().chip_strerror(status).decode()
+    except Exception:  # pragma: no cover
+        return "?"
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_dot_params() -> DotParams:
+    p = DotParams()
+    load_library().chip_dot_params_default(C.byref(p))
+    return p
+
+
+def default_ransac_params() -> RansacParams:
+    p = RansacParams()
+    load_library().chip_ransac_params_default(C.byref(p))
+    return p
+
+
+class Chip:
+    """Thin RAII wrapper over a chip_ctx (one per process per GPU)."""
+
+    def __init__(self, D: int, capacity_hint: int = 0, device: int = 0, shard_rank: int = 0, shard_count: int = 1):
+        self.lib = load_library()
+        self.D = int(D)
+        self.shard_rank, self.shard_count = shard_rank, shard_count
+        h = C.c_void_p()
+        st = self.lib.chip_create(C.byref(h), D, capacity_hint, device, shard_rank, shard_count)
+        if st != CHIP_OK:
+            raise ChipError(st, "chip_create")
+        self.h = h
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.chip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, st: int, where: str):
+        if st != CHIP_OK:
+            txt = C.c_char_p()
+            hip = self.lib.chip_last_hip_error(self.h, C.byref(txt)) if st in (CHIP_ERR_HIP, CHIP_ERR_OOM) else 0
+            raise ChipError(st, where, f"hipError {hip}: {txt.value.decode() if txt.value else ''}" if hip else "")
+
+    def set_stream(self, stream_ptr: int | None):
+        self._chk(self.lib.chip_set_stream(self.h, C.c_void_p(stream_ptr or 0)), "chip_set_stream")
+
+    def synchronize(self):
+        self._chk(self.lib.chip_synchronize(self.h), "chip_synchronize")
+
+    # -- DB
+    def append_f64(self, desc: np.ndarray, allow_rounding: bool = False) -> int:
+        desc = np.ascontiguousarray(desc, dtype=np.float64).reshape(-1, self.D)
+        first = C.c_int64()
+        self._chk(self.lib.chip_db_append_f64(self.h, _ptr(desc), desc.shape[0],
+                                              CHIP_APPEND_ALLOW_ROUNDING if allow_rounding else 0, C.byref(first)),
+                  "chip_db_append_f64")
+        return first.value
+
+    def append_f32(self, desc: np.ndarray) -> int:
+        desc = np.ascontiguousarray(desc, dtype=np.float32).reshape(-1, self.D)
+        first = C.c_int64()
+        self._chk(self.lib.chip_db_append_f32(self.h, _ptr(desc), desc.shape[0], C.byref(first)), "chip_db_append_f32")
+        return first.value
+
+    def append_synthetic(self, n: int, seed: int, plants=()):
+        plants = sorted(plants)
+        if plants:
+            dst = np.array([p[0] for p in plants], dtype=np.int64)
+            src = np.array([p[1] for p in plants], dtype=np.int64)
+            kind = np.array([p[2] for p in plants], dtype=np.int32)
+            st = self.lib.chip_db_append_synthetic(self.h, n, seed, _ptr(dst), _ptr(src), _ptr(kind), len(plants))
+        else:
+            st = self.lib.chip_db_append_synthetic(self.h, n, seed, None, None, None, 0)
+        self._chk(st, "chip_db_append_synthetic")
+
+    def size(self) -> int:
+        return int(self.lib.chip_db_size(self.h))
+
+    def read_rows(self, rows) -> np.ndarray:
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.empty((rows.size, self.D), dtype=np.float32)
+        self._chk(self.lib.chip_db_read_rows_f32(self.h, _ptr(rows), rows.size, _ptr(out)), "chip_db_read_rows_f32")
+        return out
+
+    # -- queries
+    def query_rows(self, k: int, rows, topk: int = CHIP_DEFAULT_TOPK):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        nq = rows.size
+        sc = np.empty((nq, topk), dtype=np.float64)
+        ix = np.empty((nq, topk), dtype=np.int64)
+        self._chk(self.lib.chip_query_rows(self.h, k, _ptr(rows), nq, topk, _ptr(sc), _ptr(ix)), "chip_query_rows")
+        return sc, ix
+
+    def query_vectors(self, k: int, q: np.ndarray, topk: int = CHIP_DEFAULT_TOPK):
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, self.D)
+        nq = q.shape[0]
+        sc = np.empty((nq, topk), dtype=np.float64)
+        ix = np.empty((nq, topk), dtype=np.int64)
+        self._chk(self.lib.chip_query_vectors_f32(self.h, k, _ptr(q), nq, topk, _ptr(sc), _ptr(ix)),
+                  "chip_query_vectors_f32")
+        return sc, ix
+
+    # -- tick
+    def loop_tick(self, l: int, params: DotParams | None = None) -> TickResult:
+        p = params or default_dot_params()
+        r = TickResult()
+        self._chk(self.lib.chip_loop_tick(self.h, l, C.byref(p), C.byref(r)), "chip_loop_tick")
+        return r
+
+    def loop_tick_enqueue(self, l: int, slot: int, params: DotParams | None = None):
+        p = params or default_dot_params()
+        self._chk(self.lib.chip_loop_tick_enqueue(self.h, l, C.byref(p), slot), "chip_loop_tick_enqueue")
+
+    def loop_tick_collect(self, slot: int) -> TickResult:
+        r = TickResult()
+        self._chk(self.lib.chip_loop_tick_collect(self.h, slot, C.byref(r)), "chip_loop_tick_collect")
+        return r
+
+    def loop_reset(self):
+        self.lib.chip_loop_reset(self.h)
+
+    def last_l(self) -> int:
+        return int(self.lib.chip_loop_last_l(self.h))
+
+    def scan_local(self, l: int, dev_out_ptr: int, topk: int = CHIP_DEFAULT_TOPK, params: DotParams | None = None) -> int:
+        p = params or default_dot_params()
+        status = C.c_int32()
+        self._chk(self.lib.chip_scan_local(self.h, l, C.byref(p), topk, C.c_void_p(dev_out_ptr), C.byref(status)),
+                  "chip_scan_local")
+        return status.value
+
+    def merge_decide(self, l: int, dev_gathered_ptr: int, n_lists: int, topk: int = CHIP_DEFAULT_TOPK,
+                     params: DotParams | None = None) -> TickResult:
+        p = params or default_dot_params()
+        r = TickResult()
+        self._chk(self.lib.chip_merge_decide(self.h, l, C.byref(p), C.c_void_p(dev_gathered_ptr), n_lists, topk,
+                                             C.byref(r)), "chip_merge_decide")
+        return r
+
+    # -- PnP
+    def pnp_ransac(self, X: np.ndarray, uv: np.ndarray, params: RansacParams | None = None):
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 3)
+        uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
+        N = X.shape[0]
+        assert uv.shape[0] == N
+        p = params or default_ransac_params()
+        T = np.empty(16, dtype=np.float64)
+        conf = C.c_float()
+        mask = np.zeros(max(N, 1), dtype=np.uint8)
+        summ = RansacSummary()
+        st = self.lib.chip_pnp_ransac(self.h, _ptr(X), _ptr(uv), N, C.byref(p), _ptr(T), C.byref(conf), _ptr(mask),
+                                      C.byref(summ))
+        if st == CHIP_ERR_TOO_FEW_POINTS:
+            return dict(status=st, confidence=-1.0, T=None, mask=None, summary=None)
+        self._chk(st, "chip_pnp_ransac")
+        return dict(status=st, confidence=float(conf.value), T=T.reshape(4, 4).T.copy(), mask=mask[:N].copy(),
+                    summary=dict(n_iterations=summ.n_iterations, n_inliers=summ.n_inliers,
+                                 best_hypothesis=summ.best_hypothesis, n_models=summ.n_models,
+                                 best_cost=summ.best_cost))
+
+    # -- introspection / profiling
+    def info(self) -> dict:
+        i = Info()
+        self._chk(self.lib.chip_get_info(self.h, C.byref(i)), "chip_get_info")
+        return {k: (getattr(i, k).decode() if k == "arch" else getattr(i, k)) for k, _ in Info._fields_}
+
+    def profile_enable(self, on: bool = True):
+        self._chk(self.lib.chip_profile_enable(self.h, 1 if on else 0), "chip_profile_enable")
+
+    def profile_reset(self):
+        self._chk(self.lib.chip_profile_reset(self.h), "chip_profile_reset")
+
+    def profile_scan(self):
+        ms, n, b = C.c_double(), C.c_int64(), C.c_double()
+        self._chk(self.lib.chip_profile_scan(self.h, C.byref(ms), C.byref(n), C.byref(b)), "chip_profile_scan")
+        return ms.value, n.value, b.value

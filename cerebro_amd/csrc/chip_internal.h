@@ -1,0 +1,144 @@
+// chip_internal.h -- private definitions shared by the translation units of libcerebro_hip.so.
+// gfx950 / CDNA4 only: wave = 64 lanes, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <mutex>
+#include <vector>
+#include "../../include/cerebro_hip.h"
+
+namespace chip {
+
+constexpr int kWave = 64;
+constexpr int kMaxSegs = 4096;          // segment table entries (device resident)
+constexpr int64_t kSegBytesTarget = 512ll << 20;  // ~512 MiB per DB segment
+
+// ---- launch argument blocks (passed by value; all members wave-uniform) ----
+struct ScanArgs {
+    const float *const *seg_table;  // device array of segment base pointers
+    int32_t seg_shift;              // local row r lives in segment r >> seg_shift ...
+    int64_t seg_mask;               // ... at row (r & seg_mask)
+    int64_t n_rows;                 // local rows [0, n_rows) are scanned
+    int32_t D;
+    int32_t K;
+    const float *q[CHIP_MAX_NQ];    // query descriptors (device, fp32, D each, 16-B aligned)
+    int64_t idx_mul, idx_add;       // global index = local * idx_mul + idx_add  (round-robin shard map)
+    chip_topk_entry *partial;       // [gridDim.x][NQ][K]
+};
+
+struct MergeArgs {
+    const chip_topk_entry *in;      // [n_lists][NQ][K]
+    int32_t n_lists;
+    int32_t K;
+    chip_topk_entry *out;           // [NQ][K]   (may be null)
+    chip_tick_result *result;       // decision record (may be null => no decision)
+    int64_t l;                      // tick position (for idx_curr)
+    int32_t locality;
+    double thresh;
+};
+
+struct Ctx;
+
+// kernels.hip
+int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid);
+int launch_merge(Ctx *c, hipStream_t s, const MergeArgs &a, int nq);
+int scan_grid_for(const Ctx *c, int64_t n_rows, int nq);
+int scan_configure(Ctx *c);  // one-time function attributes (dynamic LDS size)
+int launch_narrow_f64(Ctx *c, hipStream_t s, const double *src, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring);
+int launch_copy_f32(Ctx *c, hipStream_t s, const float *src, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring);
+int launch_synth(Ctx *c, hipStream_t s, int64_t first_global, int64_t n, uint64_t seed,
+                 const int64_t *plant_dst_dev, const int64_t *plant_src_dev, const int32_t *plant_kind_dev, int64_t n_plant);
+
+struct Slot {
+    hipEvent_t done = nullptr;
+    chip_tick_result *host = nullptr;   // pinned
+    chip_tick_result *dev = nullptr;
+    bool in_flight = false;
+    bool immediate = false;             // result already final on host (skipped / too short)
+};
+
+struct Ctx {
+    int32_t D = 0;
+    int32_t device = 0;
+    int32_t rank = 0, nranks = 1;
+    int32_t n_cus = 0;
+    char arch[32] = {0};
+
+    // --- DB storage: fixed-size segments, never moved once allocated ---
+    int32_t seg_shift = 0;
+    int64_t seg_rows = 0;
+    std::vector<float *> segs;           // host copy of the table
+    float **seg_table_dev = nullptr;     // device table [kMaxSegs]
+    float *ring_dev = nullptr;           // [CHIP_RING_ROWS][D]  most recent rows (all ranks)
+    int64_t rows_global = 0;             // published length (guarded by mu)
+    int64_t rows_local = 0;
+    int64_t lossy_rows = 0;
+    mutable std::mutex mu;               // guards rows_*, segs growth
+    std::mutex append_mu;                // serialises appenders
+    std::mutex query_mu;                 // serialises queriers (scratch buffers are per ctx)
+    std::mutex pnp_mu;
+
+    // --- streams ---
+    hipStream_t s_query = nullptr, s_append = nullptr, s_pnp = nullptr;
+    bool own_query_stream = true;
+
+    // --- append staging ---
+    void *stage_dev = nullptr;           // staging for host descriptors
+    size_t stage_bytes = 0;
+    uint32_t *flags_dev = nullptr;       // bit0: not-f32-representable, bit1: non-finite
+    uint32_t *flags_host = nullptr;      // pinned
+
+    // --- query scratch ---
+    chip_topk_entry *partial_dev = nullptr;   // [max_grid][CHIP_MAX_NQ][CHIP_MAX_TOPK]
+    int32_t max_grid = 0;
+    chip_topk_entry *topk_dev = nullptr;      // [CHIP_MAX_NQ][CHIP_MAX_TOPK]
+    chip_topk_entry *topk_host = nullptr;     // pinned
+    float *qvec_dev = nullptr;                // [CHIP_MAX_NQ][D] external query vectors
+    Slot slots[CHIP_MAX_INFLIGHT];
+    int64_t last_l = 0;
+
+    // --- scan tuning (resolved at create; CHIP_SCAN_* env overrides for A/B runs) ---
+    int32_t scan_block = 512;
+    int32_t scan_blocks_per_cu = 3;
+    int32_t scan_variant = 0;
+
+    // --- profiling ---
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;     // start/stop pairs
+    size_t prof_used = 0;
+    double prof_bytes_last = 0.0;
+
+    // --- pnp scratch (pnp.hip) ---
+    void *pnp_state = nullptr;
+
+    mutable hipError_t last_hip = hipSuccess;
+};
+
+#define CHIP_HIP(ctx, expr)                                  \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) {                              \
+            (ctx)->last_hip = _e;                            \
+            return _e == hipErrorOutOfMemory ? CHIP_ERR_OOM : CHIP_ERR_HIP; \
+        }                                                    \
+    } while (0)
+
+// global index <-> local row (round-robin sharding)
+inline bool owns_row(const Ctx *c, int64_t g) { return c->nranks == 1 || (g % c->nranks) == c->rank; }
+inline int64_t local_of(const Ctx *c, int64_t g) { return c->nranks == 1 ? g : g / c->nranks; }
+// number of local rows among global rows [0,k)
+inline int64_t local_count(const Ctx *c, int64_t k) {
+    if (c->nranks == 1) return k;
+    return k > c->rank ? (k - c->rank + c->nranks - 1) / c->nranks : 0;
+}
+inline float *row_ptr_host(const Ctx *c, int64_t local) {
+    return c->segs[(size_t)(local >> c->seg_shift)] + (local & (c->seg_rows - 1)) * (int64_t)c->D;
+}
+
+// pnp.hip
+int pnp_create(Ctx *c);
+void pnp_destroy(Ctx *c);
+
+}  // namespace chip
+
+struct chip_ctx : chip::Ctx {};

@@ -1,0 +1,218 @@
+/*
+ * cerebro_hip.h -- C-ABI of libcerebro_hip.so, the MI355X (gfx950) loop-detection core.
+ *
+ * The reference (mpkuse/cerebro) has no FFI seam for this path: the dot-product scan is inline in
+ * Cerebro::descrip_N__dot__descrip_0_N (src/Cerebro.cpp:903-1103) and the pose verifier is the static C++
+ * function StaticTheiaPoseCompute::PNP (src/DlsPnpWithRansac.cpp:132-245).  This header DEFINES the seam
+ * at exactly those cut lines; INTEGRATION.md shows the few-line patch a maintainer applies
+ * to Cerebro.cpp / DlsPnpWithRansac.cpp to call it.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch/Eigen types.
+ *   - every function returns an int status: CHIP_OK (0) or a negative CHIP_ERR_*; nothing throws or aborts
+ *     (the reference uses return false / -1 / exit(n); asserts are compiled out in Release, CMakeLists.txt:44).
+ *   - the caller owns every in/out buffer; the library owns device memory; nothing is retained after return.
+ *   - row index i of the descriptor DB == position i of Cerebro::wholeImageComputedList
+ *     (src/Cerebro.cpp:321-326); rows are append-only and never reordered.  Indices are int64 here (the
+ *     reference uses int).
+ *   - thread safety: one appender thread (desc_th, cerebro_node.cpp:487), one querier thread
+ *     (dot_product_th, :499) and one PnP caller (loopcandidate_consumer_th, :509) may use the same ctx
+ *     concurrently.  A query only ever reads rows that were fully appended before the call.
+ */
+#ifndef CEREBRO_HIP_H
+#define CEREBRO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHIP_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------------------------ status codes */
+enum {
+    CHIP_OK = 0,
+    CHIP_ERR_INVALID_ARG = -1,
+    CHIP_ERR_NO_DEVICE = -2,        /* no usable gfx950 device / HIP runtime failure at create            */
+    CHIP_ERR_HIP = -3,              /* a HIP runtime call failed; chip_last_hip_error() has the hipError_t */
+    CHIP_ERR_OOM = -4,
+    CHIP_ERR_NOT_F32 = -5,          /* an appended float64 is not exactly representable as float32        */
+    CHIP_ERR_NONFINITE = -6,        /* NaN/Inf in an appended descriptor (Eigen maxCoeff with NaN is unspecified) */
+    CHIP_ERR_RANGE = -7,            /* l / k / row index outside the appended range                       */
+    CHIP_ERR_UNSUPPORTED = -8,      /* e.g. D not a multiple of 4, topk > CHIP_MAX_TOPK, nq > CHIP_MAX_NQ  */
+    CHIP_ERR_TOO_FEW_POINTS = -9,   /* PnP with < 20 correspondences (DlsPnpWithRansac.cpp:136-139 returns -1) */
+    CHIP_ERR_BUSY = -10             /* async slot still in flight / not enqueued                          */
+};
+
+#define CHIP_MAX_TOPK 16
+#define CHIP_MAX_NQ 4
+#define CHIP_DEFAULT_TOPK 8
+
+typedef struct chip_ctx chip_ctx;
+
+const char *chip_strerror(int status);
+int chip_abi_version(void);
+/* last hipError_t seen by this ctx (0 = hipSuccess) and its hipGetErrorString text */
+int chip_last_hip_error(const chip_ctx *ctx, const char **text);
+
+/* ------------------------------------------------------------------------------------------ lifecycle
+ * Replaces  MatrixXd M = MatrixXd::Zero(descriptor_size, 29000)  (src/Cerebro.cpp:946): device-resident,
+ * fp32, row-major [row][D], growable (capacity_hint is only the initial reservation; the 29000 ceiling of
+ * the reference is not reproduced).
+ *
+ * Sharding (BASELINE config 4): with shard_count = G > 1 the ctx of rank r stores global rows i with
+ * i % G == r (round-robin keeps every prefix [0,k) balanced) plus a replicated ring of the most recent
+ * CHIP_RING_ROWS rows, from which the tick's three query descriptors are read.  Every rank must be fed the
+ * same append stream.  One process per GPU; the per-shard top-k lists are exchanged by the HOST
+ * (RCCL all-gather via torch.distributed, or any other transport) between chip_scan_local and
+ * chip_merge_decide.                                                                                   */
+#define CHIP_RING_ROWS 64
+int  chip_create(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device, int32_t shard_rank, int32_t shard_count);
+void chip_destroy(chip_ctx *ctx);
+/* Run all work of this ctx on an externally owned hipStream_t (e.g. torch's current stream). NULL -> own stream. */
+int  chip_set_stream(chip_ctx *ctx, void *hip_stream);
+int  chip_synchronize(chip_ctx *ctx);
+
+/* ------------------------------------------------------------------------------------------ DB append
+ * Replaces  M.col(_s) = ...getWholeImageDescriptor()  (src/Cerebro.cpp:1005-1006) and the f64 wire type of
+ * WholeImageDescriptorCompute.srv:4 / Cerebro.cpp:268-271.  n descriptors, each D contiguous values.
+ * The f64->f32 narrowing is done on the device and VERIFIED lossless ((double)(float)x == x); the default
+ * NetVLAD server emits float32 values (whole_image_desc_compute_server.py:631,648) so this holds.
+ * On CHIP_ERR_NOT_F32 / CHIP_ERR_NONFINITE nothing is appended.                                         */
+#define CHIP_APPEND_ALLOW_ROUNDING 1u   /* round-to-nearest instead of failing; sets info.lossy_rows      */
+int chip_db_append_f64(chip_ctx *ctx, const double *desc, int64_t n, uint32_t flags, int64_t *first_index);
+int chip_db_append_f32(chip_ctx *ctx, const float *desc, int64_t n, int64_t *first_index);
+int64_t chip_db_size(const chip_ctx *ctx);           /* global number of appended rows (== l)             */
+/* Read back rows (global indices; in sharded mode only rows owned by this rank or still in the ring). */
+int chip_db_read_rows_f32(chip_ctx *ctx, const int64_t *rows, int64_t n, float *out);
+
+/* Bench/test helper: append n rows of the integer-domain synthetic generator generated ON DEVICE
+ * (spec: oracle/dot_scan.c orc_synth_row_f32; SURVEY.md 8d allows on-device generation for the 1M DB).
+ * plant_* (may be NULL) list planted rows as GLOBAL row indices inside the appended range, sorted by dst:
+ * kind 1 = noisy copy of src (cos ~ 0.98), kind 2 = exact duplicate of src.                            */
+int chip_db_append_synthetic(chip_ctx *ctx, int64_t n, uint64_t seed,
+                             const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant);
+
+/* ------------------------------------------------------------------------------------------ scan + top-k
+ * Replaces  u = v.transpose() * M.leftCols(k); maxCoeff(); last-index argmax  (src/Cerebro.cpp:1026-1043)
+ * generalised to top-K (the compiled-out faiss variants use K=5, src/Cerebro.cpp:460).
+ * Scores are fp64 accumulations of exact fp32 products in the fixed order of DESIGN.md 3; ordering is
+ * (score descending, index DESCENDING) so K=1 is the reference's "last index attaining the max".
+ * Unused slots (k < K): score = -inf, idx = -1.  scores/idx are nq*topk, query-major.                   */
+int chip_query_rows(chip_ctx *ctx, int64_t k, const int64_t *query_rows, int32_t nq, int32_t topk,
+                    double *scores, int64_t *idx);
+int chip_query_vectors_f32(chip_ctx *ctx, int64_t k, const float *queries, int32_t nq, int32_t topk,
+                           double *scores, int64_t *idx);
+
+/* ------------------------------------------------------------------------------------------ the tick
+ * One pass of the while-loop body of Cerebro::descrip_N__dot__descrip_0_N (src/Cerebro.cpp:956-1100) for
+ * l = wholeImageComputedList_size().  Defaults (chip_dot_params_default): LOCALITY_THRESH 12 (:912),
+ * DOT_PROD_THRESH (double)(float)0.85 (:913,:1056), lag 50 (:914,:1019), >=3 new rows (:962), k > 5 (:1022). */
+typedef struct {
+    int32_t locality;
+    int32_t lag;
+    int32_t min_new;
+    int32_t min_k;
+    double  thresh;
+} chip_dot_params;
+void chip_dot_params_default(chip_dot_params *p);
+
+enum { CHIP_TICK_SKIPPED = 0,   /* l - last_l < min_new: nothing done, last_l NOT advanced (:962-966)     */
+       CHIP_TICK_TOO_SHORT = 1, /* ran, but k = l - lag <= min_k (:1022 else-branch); last_l = l          */
+       CHIP_TICK_SCANNED = 2 }; /* scan + decision executed; last_l = l                                   */
+
+typedef struct {
+    int32_t status;      /* CHIP_TICK_*                                                                   */
+    int32_t found;       /* 1 iff the :1056 criterion fired -> foundLoops.push_back (:1078-1081)          */
+    int64_t idx_curr;    /* l-1                (wholeImageComputedList index of t_curr)                   */
+    int64_t idx_prev;    /* u_argmax           (index of t_prev)                                          */
+    double  score;       /* u_max                                                                         */
+    int64_t argmax[3];   /* u_argmax, um_argmax, umm_argmax                                               */
+    double  maxv[3];     /* u_max, um_max, umm_max                                                        */
+} chip_tick_result;
+
+/* Synchronous tick (single-GPU ctx, shard_count == 1). */
+int chip_loop_tick(chip_ctx *ctx, int64_t l, const chip_dot_params *p, chip_tick_result *out);
+/* Pipelined form: enqueue up to CHIP_MAX_INFLIGHT ticks without host synchronisation, collect later. */
+#define CHIP_MAX_INFLIGHT 64
+int chip_loop_tick_enqueue(chip_ctx *ctx, int64_t l, const chip_dot_params *p, int32_t slot);
+int chip_loop_tick_collect(chip_ctx *ctx, int32_t slot, chip_tick_result *out);
+int64_t chip_loop_last_l(const chip_ctx *ctx);
+void chip_loop_reset(chip_ctx *ctx);
+
+/* Sharded tick, three phases (host does the exchange between 1 and 2):
+ *  1. chip_scan_local: scan this rank's share of rows [0,k), k = l - lag, for the three queries l-1,l-2,l-3 and
+ *     leave its 3 x topk list (chip_topk_entry, global indices) in DEVICE memory at dev_out (caller-owned,
+ *     3*topk*sizeof(chip_topk_entry) bytes), stream-ordered on the ctx stream.  *status gets CHIP_TICK_*;
+ *     when it is not CHIP_TICK_SCANNED nothing was enqueued and phases 2-3 are skipped by every rank alike.
+ *  2. host: all-gather dev_out of every rank -> gathered[G][3][topk].
+ *  3. chip_merge_decide: merge the G lists per query, apply the :1056 criterion, return the result.     */
+typedef struct { double score; int64_t idx; } chip_topk_entry;
+int chip_scan_local(chip_ctx *ctx, int64_t l, const chip_dot_params *p, int32_t topk, void *dev_out, int32_t *status);
+int chip_merge_decide(chip_ctx *ctx, int64_t l, const chip_dot_params *p, const void *dev_gathered, int32_t n_lists,
+                      int32_t topk, chip_tick_result *out);
+
+/* ------------------------------------------------------------------------------------------ PnP-RANSAC
+ * Replaces the body of StaticTheiaPoseCompute::PNP (src/DlsPnpWithRansac.cpp:192-240): theia::Ransac over
+ * the DlsPnpWithRansac estimator (src/DlsPnpWithRansac.h:42-100).
+ *   X  : N x 3 row-major, 3-D points in frame a            (w_X,  DlsPnpWithRansac.cpp:196)
+ *   uv : N x 2 row-major, normalized image coords in b     (c_uv_normalized, :197)
+ *   T  : 4x4 COLUMN-major b_T_a (Eigen Matrix4d layout)    (c_T_w = best_rel_pose.b_T_a, :239)
+ * Returns CHIP_ERR_TOO_FEW_POINTS for N < 20 (:136-139; the reference returns confidence -1).  When no
+ * hypothesis yields a model, status is CHIP_OK, *confidence = 0 and T is filled with NaN (the reference
+ * returns an UNINITIALISED Matrix4d, :204; its caller only NaN-checks, Cerebro.cpp:1678).
+ * n_hypotheses == 0: reference-faithful adaptive loop (<= max_iterations, early termination as
+ * theia::Ransac; hypotheses are generated in parallel and the sequential rule is replayed on the host).
+ * n_hypotheses  > 0: benchmark mode, exactly that many hypotheses, all scored, argmin cost with the lowest
+ * hypothesis index winning ties (BASELINE config 3 uses 1000).                                         */
+typedef struct {
+    double  error_thresh;        /* 0.03   DlsPnpWithRansac.cpp:208 */
+    double  min_inlier_ratio;    /* 0.7    :209 */
+    int32_t max_iterations;      /* 50     :210 */
+    int32_t min_iterations;      /* 5      :211 */
+    int32_t use_mle;             /* 1      :212 */
+    int32_t sample_size;         /* 15     DlsPnpWithRansac.h:45 */
+    double  failure_probability; /* 0.01   theia::RansacParameters default */
+    uint64_t seed;               /* counter-based sampler seed (Theia's is time-seeded => nondeterministic) */
+    int32_t n_hypotheses;        /* 0 = adaptive reference mode */
+    int32_t reserved;
+} chip_ransac_params;
+void chip_ransac_params_default(chip_ransac_params *p);
+
+typedef struct {
+    int32_t n_iterations;     /* summary.num_iterations (:229)                                   */
+    int32_t n_inliers;
+    int32_t best_hypothesis;  /* index of the winning hypothesis, -1 if none                      */
+    int32_t n_models;         /* hypotheses for which DlsPnp returned exactly one solution        */
+    double  best_cost;
+} chip_ransac_summary;
+
+int chip_pnp_ransac(chip_ctx *ctx, const double *X, const double *uv, int32_t N, const chip_ransac_params *p,
+                    double T_colmajor[16], float *confidence, uint8_t *inlier_mask /* N bytes, may be NULL */,
+                    chip_ransac_summary *summary /* may be NULL */);
+
+/* ------------------------------------------------------------------------------------------ introspection */
+typedef struct {
+    int32_t abi_version;
+    int32_t D;
+    int32_t device;
+    int32_t shard_rank, shard_count;
+    int32_t n_cus;              /* multiProcessorCount                                             */
+    int64_t rows_global;        /* == chip_db_size                                                 */
+    int64_t rows_local;         /* rows stored on this rank                                        */
+    int64_t capacity_local;     /* rows reserved on this rank                                      */
+    int64_t lossy_rows;         /* rows appended with CHIP_APPEND_ALLOW_ROUNDING that actually rounded */
+    char    arch[32];           /* gcnArchName, e.g. "gfx950:sramecc+:xnack-"                      */
+} chip_info;
+int chip_get_info(const chip_ctx *ctx, chip_info *info);
+
+/* Per-kernel timing on the ctx stream (hipEvents bracketing every scan launch). */
+int chip_profile_enable(chip_ctx *ctx, int32_t on);
+int chip_profile_reset(chip_ctx *ctx);
+/* after chip_synchronize: total ms and launch count of the dominant kernel (db_scan_topk) since reset */
+int chip_profile_scan(chip_ctx *ctx, double *total_ms, int64_t *n_launches, double *bytes_per_launch_last);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

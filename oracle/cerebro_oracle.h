@@ -1,0 +1,96 @@
+/*
+ * cerebro_oracle.h -- CPU restatement (plain C) of cerebro's loop-detection hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product (libcerebro_hip.so) never
+ * links, loads or calls anything in this directory.
+ *
+ * Parity status
+ *   - dot-product tick (Cerebro.cpp:903-1103): every branch below cites the reference line it
+ *     restates.  The reference holds NO golden vectors/tests for this path and
+ *     cannot be compiled here (ROS/Eigen/OpenCV absent), so the oracle is pinned by
+ *     construction from the cited lines plus an independent numpy mirror (tests/np_mirror.py).
+ *   - DLS-PnP / RANSAC (DlsPnpWithRansac.{h,cpp} + un-vendored Theia-SfM, version unpinned):
+ *     **parity unpinned** for the Theia internals -- see pnp_ransac.c header.
+ *
+ * All functions are reentrant; no global state.
+ */
+#ifndef CEREBRO_ORACLE_H
+#define CEREBRO_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ synthetic descriptors */
+/* Integer-domain generator shared (as a SPEC, not as code) with the device generator in
+ * cerebro_amd/csrc/synth.hip: bit-identical on any IEEE machine because the only floating
+ * point operations are one exact int->float conversion and one float multiply.            */
+uint64_t orc_splitmix64(uint64_t x);
+int32_t  orc_synth_i32(uint64_t seed, int64_t row, int32_t e);      /* Irwin-Hall(4) of 16-bit fields, centred */
+float    orc_synth_scale(int32_t D);                                 /* (float)(1/sqrt(D*var))                  */
+float    orc_synth_scale_planted(int32_t D);                         /* (float)(1/sqrt(D*var*26))               */
+/* kind: 0 = plain row, 1 = noisy copy of src (5*x_src + x_noise), 2 = exact duplicate of src */
+void     orc_synth_row_f32(uint64_t seed, int64_t row, int32_t D, int32_t kind, int64_t src, float *out);
+
+/* ------------------------------------------------------------------ dot products */
+/* Fixed summation tree of SURVEY.md Appendix B (the device kernel uses the same tree):
+ * lane L (0..63) accumulates elements j*256+4L+c, j ascending, c=0..3; then
+ * acc[L] += acc[L^m] for m=32,16,8,4,2,1.  Products of fp32 values are exact in fp64.   */
+double   orc_dot_tree_f32(const float *q, const float *row, int32_t D);
+/* Plain left-to-right fp64 dot (the most literal reading of v^T * M.col(i), Cerebro.cpp:1026). */
+double   orc_dot_seq_f64(const double *q, const double *col, int32_t D);
+
+/* Top-K of scores of nq queries against rows [0,k) of a row-major fp32 DB.
+ * Order: score descending, then index DESCENDING (K=1 == "last index attaining the max",
+ * Cerebro.cpp:1038-1043).  Empty slots: score=-inf, idx=-1.  out arrays are nq*K.        */
+void     orc_scan_topk_f32(const float *db, int64_t k, int32_t D,
+                           const float *queries, int32_t nq, int32_t K,
+                           double *out_scores, int64_t *out_idx);
+/* Same, rows produced on the fly by the synthetic generator (for 100k/1M checks without 16 GB of RAM).
+ * plant_dst/src/kind describe planted rows (sorted by dst, may be NULL).  nthreads<=0 -> 1. */
+void     orc_scan_topk_synth(uint64_t seed, int64_t k, int32_t D,
+                             const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant,
+                             const float *queries, int32_t nq, int32_t K,
+                             double *out_scores, int64_t *out_idx, int32_t nthreads);
+
+/* ------------------------------------------------------------------ the tick (Cerebro.cpp:956-1100) */
+typedef struct {
+    int32_t locality;   /* LOCALITY_THRESH = 12            Cerebro.cpp:912 */
+    double  thresh;     /* (double)(float)0.85             Cerebro.cpp:913,1056 */
+    int32_t lag;        /* start_adding_..._after = 50     Cerebro.cpp:914,1019 */
+    int32_t min_new;    /* l - last_l < 3 -> nothing       Cerebro.cpp:962 */
+    int32_t min_k;      /* if( k > 5 )                     Cerebro.cpp:1022 */
+} orc_dot_params;
+void orc_dot_params_default(orc_dot_params *p);
+
+typedef struct {
+    int32_t status;          /* 0 = skipped (<min_new new rows; last_l NOT advanced), 1 = ran, k<=min_k, 2 = scanned */
+    int32_t found;           /* 1 iff a loop candidate was accepted */
+    int64_t idx_curr;        /* l-1 */
+    int64_t idx_prev;        /* u_argmax */
+    double  score;           /* u_max */
+    int64_t argmax[3];       /* u, um, umm argmax (or -1) */
+    double  maxv[3];
+} orc_tick_result;
+
+typedef struct { int64_t last_l; } orc_loop_state;
+
+/* One pass of the while-loop body on a row-major fp32 DB holding >= l rows. */
+void orc_loop_tick_f32(orc_loop_state *st, const orc_dot_params *p, const float *db, int32_t D,
+                       int64_t l, orc_tick_result *out);
+
+/* Reference-faithful CPU path used as bench.py's cpu_baseline (kind "port"):
+ * fp64 COLUMN-major M (D x cap) exactly as Cerebro.cpp:946, three SEPARATE GEMVs (:1026-1028),
+ * three maxCoeff (:1035-1037), one last-index argmax loop (:1038-1043).  Single thread,
+ * like the reference's dot_product_th.  u/um/umm are caller-provided scratch of length k. */
+void orc_ref_scan_f64_colmajor(const double *M, int32_t D, int64_t k,
+                               const double *v, const double *vm, const double *vmm,
+                               double *u, double *um, double *umm,
+                               double maxv[3], int64_t argmax[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

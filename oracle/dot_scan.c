@@ -1,0 +1,225 @@
+/*
+ * dot_scan.c -- CPU oracle for cerebro's whole-image-descriptor dot-product scan + candidate select.
+ *
+ * TEST INFRASTRUCTURE ONLY (see cerebro_oracle.h).  Restates, line by line,
+ *   /root/reference/src/Cerebro.cpp:903-1103  (Cerebro::descrip_N__dot__descrip_0_N)
+ * Build: gcc -O2 -ffp-contract=off -fopenmp  (no -ffast-math: summation order is part of the spec).
+ */
+#include "cerebro_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---------------------------------------------------------------- synthetic generator (spec) */
+uint64_t orc_splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+static inline uint64_t synth_rowkey(uint64_t seed, int64_t row)
+{
+    return orc_splitmix64(seed + 0x632BE59BD9B4E019ULL * (uint64_t)row);
+}
+
+static inline int32_t synth_from_key(uint64_t rowkey, int32_t e)
+{
+    uint64_t h = orc_splitmix64(rowkey + (uint64_t)(uint32_t)e);
+    int32_t s = (int32_t)(h & 0xFFFF) + (int32_t)((h >> 16) & 0xFFFF) + (int32_t)((h >> 32) & 0xFFFF) + (int32_t)(h >> 48);
+    return s - 131070; /* centred Irwin-Hall(4) over 16-bit uniforms: |x| <= 131070 */
+}
+
+int32_t orc_synth_i32(uint64_t seed, int64_t row, int32_t e) { return synth_from_key(synth_rowkey(seed, row), e); }
+
+#define SYNTH_VAR 1431655765.0 /* 4 * (65536^2 - 1) / 12 */
+float orc_synth_scale(int32_t D) { return (float)(1.0 / sqrt((double)D * SYNTH_VAR)); }
+float orc_synth_scale_planted(int32_t D) { return (float)(1.0 / sqrt((double)D * SYNTH_VAR * 26.0)); }
+
+void orc_synth_row_f32(uint64_t seed, int64_t row, int32_t D, int32_t kind, int64_t src, float *out)
+{
+    const float c = orc_synth_scale(D), cp = orc_synth_scale_planted(D);
+    const uint64_t key = synth_rowkey(seed, row);
+    if (kind == 0) {
+        for (int32_t e = 0; e < D; e++) out[e] = (float)synth_from_key(key, e) * c;
+    } else {
+        const uint64_t skey = synth_rowkey(seed, src);
+        if (kind == 2)
+            for (int32_t e = 0; e < D; e++) out[e] = (float)synth_from_key(skey, e) * c;
+        else /* noisy copy: cos(angle) ~ 5/sqrt(26) = 0.98 */
+            for (int32_t e = 0; e < D; e++) out[e] = (float)(5 * synth_from_key(skey, e) + synth_from_key(key, e)) * cp;
+    }
+}
+
+/* ---------------------------------------------------------------- dot products */
+double orc_dot_tree_f32(const float *q, const float *row, int32_t D)
+{
+    double acc[64];
+    for (int L = 0; L < 64; L++) acc[L] = 0.0;
+    for (int32_t base = 0; base < D; base += 256)
+        for (int L = 0; L < 64; L++)
+            for (int c = 0; c < 4; c++) {
+                int32_t e = base + 4 * L + c;
+                if (e < D) acc[L] = acc[L] + (double)q[e] * (double)row[e]; /* product exact in fp64 */
+            }
+    for (int m = 32; m >= 1; m >>= 1) {
+        double nxt[64];
+        for (int L = 0; L < 64; L++) nxt[L] = acc[L] + acc[L ^ m];
+        memcpy(acc, nxt, sizeof acc);
+    }
+    return acc[0];
+}
+
+double orc_dot_seq_f64(const double *q, const double *col, int32_t D)
+{
+    double s = 0.0;
+    for (int32_t e = 0; e < D; e++) s = s + q[e] * col[e];
+    return s;
+}
+
+/* ---------------------------------------------------------------- top-K with (score desc, idx desc) */
+static inline int key_gt(double s, int64_t i, double s2, int64_t i2) { return s > s2 || (s == s2 && i > i2); }
+
+static void topk_init(double *sc, int64_t *ix, int32_t K)
+{
+    for (int32_t j = 0; j < K; j++) { sc[j] = -INFINITY; ix[j] = -1; }
+}
+static void topk_push(double *sc, int64_t *ix, int32_t K, double s, int64_t i)
+{
+    if (!(s == s)) return; /* NaN never enters (SURVEY App.B (6)) */
+    if (!key_gt(s, i, sc[K - 1], ix[K - 1])) return;
+    int32_t j = K - 1;
+    while (j > 0 && key_gt(s, i, sc[j - 1], ix[j - 1])) { sc[j] = sc[j - 1]; ix[j] = ix[j - 1]; j--; }
+    sc[j] = s; ix[j] = i;
+}
+
+void orc_scan_topk_f32(const float *db, int64_t k, int32_t D, const float *queries, int32_t nq, int32_t K,
+                       double *out_scores, int64_t *out_idx)
+{
+    for (int32_t q = 0; q < nq; q++) topk_init(out_scores + (size_t)q * K, out_idx + (size_t)q * K, K);
+    for (int64_t i = 0; i < k; i++)
+        for (int32_t q = 0; q < nq; q++)
+            topk_push(out_scores + (size_t)q * K, out_idx + (size_t)q * K, K,
+                      orc_dot_tree_f32(queries + (size_t)q * D, db + (size_t)i * D, D), i);
+}
+
+void orc_scan_topk_synth(uint64_t seed, int64_t k, int32_t D,
+                         const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant,
+                         const float *queries, int32_t nq, int32_t K,
+                         double *out_scores, int64_t *out_idx, int32_t nthreads)
+{
+    if (nthreads <= 0) nthreads = 1;
+    double *tsc = (double *)malloc(sizeof(double) * (size_t)nthreads * nq * K);
+    int64_t *tix = (int64_t *)malloc(sizeof(int64_t) * (size_t)nthreads * nq * K);
+    for (int32_t t = 0; t < nthreads * nq; t++) topk_init(tsc + (size_t)t * K, tix + (size_t)t * K, K);
+#pragma omp parallel num_threads(nthreads)
+    {
+#ifdef _OPENMP
+        int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        int t = 0, nt = 1;
+#endif
+        float *row = (float *)malloc(sizeof(float) * (size_t)D);
+        double *sc = tsc + (size_t)t * nq * K;
+        int64_t *ix = tix + (size_t)t * nq * K;
+        int64_t lo = k * t / nt, hi = k * (t + 1) / nt;
+        /* first planted row >= lo */
+        int64_t pp = 0;
+        while (pp < n_plant && plant_dst[pp] < lo) pp++;
+        for (int64_t i = lo; i < hi; i++) {
+            int32_t kind = 0; int64_t src = -1;
+            if (pp < n_plant && plant_dst[pp] == i) { kind = plant_kind[pp]; src = plant_src[pp]; pp++; }
+            orc_synth_row_f32(seed, i, D, kind, src, row);
+            for (int32_t q = 0; q < nq; q++)
+                topk_push(sc + (size_t)q * K, ix + (size_t)q * K, K, orc_dot_tree_f32(queries + (size_t)q * D, row, D), i);
+        }
+        free(row);
+    }
+    /* merge per-thread lists (exact top-K under a total order => partition independent) */
+    for (int32_t q = 0; q < nq; q++) {
+        double *sc = out_scores + (size_t)q * K; int64_t *ix = out_idx + (size_t)q * K;
+        topk_init(sc, ix, K);
+        for (int t = 0; t < nthreads; t++)
+            for (int32_t j = 0; j < K; j++) {
+                int64_t id = tix[((size_t)t * nq + q) * K + j];
+                if (id >= 0) topk_push(sc, ix, K, tsc[((size_t)t * nq + q) * K + j], id);
+            }
+    }
+    free(tsc); free(tix);
+}
+
+/* ---------------------------------------------------------------- the tick */
+void orc_dot_params_default(orc_dot_params *p)
+{
+    p->locality = 12;                 /* Cerebro.cpp:912  int LOCALITY_THRESH = 12 */
+    p->thresh = (double)(float)0.85;  /* Cerebro.cpp:913  float DOT_PROD_THRESH = 0.85, compared with a double at :1056 */
+    p->lag = 50;                      /* Cerebro.cpp:914 */
+    p->min_new = 3;                   /* Cerebro.cpp:962 */
+    p->min_k = 5;                     /* Cerebro.cpp:1022 (strict >) */
+}
+
+static int64_t i64abs(int64_t a) { return a < 0 ? -a : a; }
+
+void orc_loop_tick_f32(orc_loop_state *st, const orc_dot_params *p, const float *db, int32_t D, int64_t l, orc_tick_result *out)
+{
+    memset(out, 0, sizeof *out);
+    out->idx_curr = out->idx_prev = -1;
+    for (int q = 0; q < 3; q++) { out->argmax[q] = -1; out->maxv[q] = -INFINITY; }
+
+    if (l - st->last_l < p->min_new) { out->status = 0; return; } /* :962-966  (continue; last_l untouched) */
+
+    /* :987-989  v, vm, vmm = descriptors l-1, l-2, l-3 */
+    const float *qv[3] = { db + (size_t)(l - 1) * D, db + (size_t)(l - 2) * D, db + (size_t)(l - 3) * D };
+    /* :1005-1006 fill of M is the DB append itself (rows [last_l,l) already present in db) */
+    int64_t k = l - p->lag; /* :1019 */
+    out->status = 1;
+    if (k > p->min_k) {     /* :1022 */
+        out->status = 2;
+        for (int q = 0; q < 3; q++) {
+            /* :1026-1028 u = v^T M[:, :k];  :1035-1043 max + LAST index attaining it */
+            double best = -INFINITY; int64_t arg = -1;
+            for (int64_t i = 0; i < k; i++) {
+                double s = orc_dot_tree_f32(qv[q], db + (size_t)i * D, D);
+                if (s >= best) { best = s; arg = i; } /* >= : later index wins ties */
+            }
+            out->maxv[q] = best; out->argmax[q] = arg;
+        }
+        /* :1056 */
+        if (i64abs(out->argmax[0] - out->argmax[1]) < p->locality &&
+            i64abs(out->argmax[0] - out->argmax[2]) < p->locality && out->maxv[0] > p->thresh) {
+            out->found = 1;                /* :1078-1081 foundLoops.push_back( t[l-1], t[u_argmax], u_max ) */
+            out->idx_curr = l - 1;
+            out->idx_prev = out->argmax[0];
+            out->score = out->maxv[0];
+        }
+    }
+    st->last_l = l; /* :1098 */
+}
+
+/* ---------------------------------------------------------------- reference-faithful fp64 path (cpu_baseline) */
+void orc_ref_scan_f64_colmajor(const double *M, int32_t D, int64_t k,
+                               const double *v, const double *vm, const double *vmm,
+                               double *u, double *um, double *umm, double maxv[3], int64_t argmax[3])
+{
+    /* :1026-1028 three separate products => M is streamed three times, as Eigen does */
+    for (int64_t i = 0; i < k; i++) u[i] = orc_dot_seq_f64(v, M + (size_t)i * D, D);
+    for (int64_t i = 0; i < k; i++) um[i] = orc_dot_seq_f64(vm, M + (size_t)i * D, D);
+    for (int64_t i = 0; i < k; i++) umm[i] = orc_dot_seq_f64(vmm, M + (size_t)i * D, D);
+    /* :1035-1037 maxCoeff */
+    double a = u[0], b = um[0], c = umm[0];
+    for (int64_t i = 1; i < k; i++) { if (u[i] > a) a = u[i]; if (um[i] > b) b = um[i]; if (umm[i] > c) c = umm[i]; }
+    /* :1038-1043 */
+    int64_t ia = -1, ib = -1, ic = -1;
+    for (int64_t ii = 0; ii < k; ii++) {
+        if (u[ii] == a) ia = ii;
+        if (um[ii] == b) ib = ii;
+        if (umm[ii] == c) ic = ii;
+    }
+    maxv[0] = a; maxv[1] = b; maxv[2] = c;
+    argmax[0] = ia; argmax[1] = ib; argmax[2] = ic;
+}

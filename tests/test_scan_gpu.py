@@ -1,0 +1,227 @@
+"""GPU parity tests of the descriptor dot-product scan path: HIP kernels (through the C-ABI) vs the CPU oracle
+on identical inputs.  Bar: indices AND scores bit-exact (integer/index work; fp64 sums in a fixed order)."""
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import scenarios
+from cerebro_amd import capi
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_topk_equal(got, want):
+    (gs, gi), (ws, wi) = got, want
+    assert np.array_equal(gi, wi), (gi, wi)
+    assert np.array_equal(bits(gs), bits(ws)), (gs, ws)
+
+
+def same_tick(g, o):
+    g = g.as_dict() if hasattr(g, "as_dict") else g
+    for key in ("status", "found", "idx_curr", "idx_prev", "argmax"):
+        assert g[key] == o[key], (key, g, o)
+    assert float(g["score"]).hex() == float(o["score"]).hex()
+    assert [float(x).hex() for x in g["maxv"]] == [float(x).hex() for x in o["maxv"]]
+
+
+def test_golden_fixture_through_c_abi():
+    g = json.loads((GOLD / "dot_scan_golden.json").read_text())
+    for case in g["cases"]:
+        db = scenarios.build_db(case["seed"], case["N"], case["D"], [tuple(p) for p in case["plants"]])
+        with capi.Chip(case["D"]) as chip:
+            assert chip.append_f64(db.astype(np.float64)) == 0       # wire type float64[] (srv:4), lossless narrowing
+            got = []
+            for l in case["schedule"]:
+                r = chip.loop_tick(l)
+                if r.found:
+                    got.append([r.idx_curr, r.idx_prev, float(r.score).hex()])
+            assert got == case["found_loops"]
+            sc, ix = chip.query_rows(case["topk_k"], case["topk_rows"], case["K"])
+            assert ix.tolist() == case["topk_idx"]
+            assert [[float(x).hex() for x in row] for row in sc] == case["topk_scores_hex"]
+
+
+@pytest.mark.parametrize("D,N", [(4, 300), (252, 500), (256, 700), (1000, 900), (4096, 2500), (8192, 600)])
+def test_topk_parity_shapes(D, N):
+    plants, loops, ties = scenarios.loop_plants(N, 3, seed=D)
+    db = scenarios.build_db(1000 + D, N, D, plants)
+    with capi.Chip(D) as chip:
+        chip.append_f32(db)
+        rows = [N - 1, N - 2, N - 3, loops[0][1]]
+        for nq in (1, 2, 3, 4):
+            for K in (1, 5, 8, 16):
+                for k in (0, 1, 7, N - 50, N):
+                    want = oracle_lib.scan_topk(db, k, db[rows[:nq]], K)
+                    got = chip.query_rows(k, rows[:nq], K)
+                    assert_topk_equal(got, want)
+        # external query vectors take the same path
+        q = oracle_lib.synth_rows(5, [10, 11, 12], D)
+        assert_topk_equal(chip.query_vectors(N, q, 8), oracle_lib.scan_topk(db, N, q, 8))
+
+
+def test_tick_sequence_parity_and_tie_rule():
+    D, N = 1024, 1500
+    plants, loops, ties = scenarios.loop_plants(N, 6, seed=42)
+    db = scenarios.build_db(31337, N, D, plants)
+    assert ties, "scenario must contain exact duplicate rows"
+    orc = oracle_lib.LoopOracle(db)
+    with capi.Chip(D) as chip:
+        chip.append_f64(db[:700].astype(np.float64))
+        chip.append_f64(db[700:].astype(np.float64))
+        n_found = 0
+        # irregular schedule: skips (<3 new), jumps (>3 new), first ticks too short
+        sched = [1, 3, 5, 30, 55, 57, 58, 61] + list(range(64, N + 1, 3))
+        extra = [l + 1 for l in sched[10::17]] + [l + 2 for l in sched[11::13]]
+        for l in sorted(set(sched + [x for x in extra if x <= N])):
+            o = orc.tick(l)
+            g = chip.loop_tick(l)
+            same_tick(g, o)
+            assert chip.last_l() == orc.state.last_l
+            n_found += o["found"]
+        assert n_found >= len(loops)
+        s, t1, t2 = ties[0]
+        l, q, p = loops[0]
+        sc, ix = chip.query_rows(l - 50, [q], 3)
+        assert list(ix[0]) == [t2, t1, s] and sc[0][0] == sc[0][1] == sc[0][2]   # last index wins (Cerebro.cpp:1038-1043)
+
+
+def test_pipelined_ticks_match_sync():
+    D, N = 512, 1200
+    plants, loops, _ = scenarios.loop_plants(N, 5, seed=7)
+    db = scenarios.build_db(9, N, D, plants)
+    sched = scenarios.default_schedule(N)
+    with capi.Chip(D) as a, capi.Chip(D) as b:
+        a.append_f32(db)
+        b.append_f32(db)
+        sync = [a.loop_tick(l).as_dict() for l in sched]
+        out = []
+        for base in range(0, len(sched), 32):
+            chunk = sched[base:base + 32]
+            for s, l in enumerate(chunk):
+                b.loop_tick_enqueue(l, s)
+            out += [b.loop_tick_collect(s).as_dict() for s in range(len(chunk))]
+        assert out == sync
+        with pytest.raises(capi.ChipError):
+            b.loop_tick_collect(0)            # nothing in flight
+
+
+def test_append_validation_and_errors():
+    D = 256
+    good = oracle_lib.synth_rows(1, range(8), D).astype(np.float64)
+    with capi.Chip(D) as chip:
+        assert chip.append_f64(good) == 0
+        bad = good.copy()
+        bad[3, 17] = 0.1                       # not representable in float32
+        with pytest.raises(capi.ChipError) as e:
+            chip.append_f64(bad)
+        assert e.value.status == capi.CHIP_ERR_NOT_F32 and chip.size() == 8      # nothing appended
+        nan = good.copy()
+        nan[0, 0] = np.nan
+        with pytest.raises(capi.ChipError) as e:
+            chip.append_f64(nan)
+        assert e.value.status == capi.CHIP_ERR_NONFINITE and chip.size() == 8
+        assert chip.append_f64(bad, allow_rounding=True) == 8
+        assert chip.info()["lossy_rows"] > 0
+        back = chip.read_rows(range(16))
+        assert back[:8].tobytes() == good.astype(np.float32).tobytes()
+        assert back[8:].tobytes() == bad.astype(np.float32).tobytes()
+        with pytest.raises(capi.ChipError) as e:
+            chip.loop_tick(17)                 # l beyond the appended rows
+        assert e.value.status == capi.CHIP_ERR_RANGE
+        with pytest.raises(capi.ChipError) as e:
+            chip.query_rows(5, [99], 4)
+        assert e.value.status == capi.CHIP_ERR_RANGE
+        with pytest.raises(capi.ChipError) as e:
+            chip.query_rows(5, [1], 17)
+        assert e.value.status == capi.CHIP_ERR_UNSUPPORTED
+
+
+def test_device_generator_bit_identical_to_spec():
+    D, N = 4096, 3000
+    plants = [(100, 5, 1), (101, 6, 2), (2999, 2000, 1)]
+    with capi.Chip(D) as chip:
+        chip.append_synthetic(1000, 20190412, [p for p in plants if p[0] < 1000])
+        chip.append_synthetic(N - 1000, 20190412, [p for p in plants if p[0] >= 1000])   # appended in two calls
+        rows = [0, 1, 5, 6, 100, 101, 999, 1000, 2000, 2999]
+        got = chip.read_rows(rows)
+        want = oracle_lib.synth_rows(20190412, rows, D, plants)
+        assert got.tobytes() == want.tobytes()
+
+
+def test_growth_across_segments():
+    """DB segments are 512 MiB; with D=8192 (32 KiB rows) a segment holds 16384 rows -> cross it."""
+    D, N = 8192, 20000
+    with capi.Chip(D, capacity_hint=100) as chip:
+        chip.append_synthetic(N, 3, [(19990, 16383, 1), (19991, 16384, 1), (19992, 5, 2)])
+        info = chip.info()
+        assert info["rows_global"] == N and info["capacity_local"] >= N
+        q = oracle_lib.synth_rows(3, [19990, 19991, 19992], D, [(19990, 16383, 1), (19991, 16384, 1), (19992, 5, 2)])
+        sc, ix = chip.query_rows(N - 50, [19990, 19991, 19992], 2)
+        assert list(ix[:, 0]) == [16383, 16384, 5]
+        for i, r in enumerate([16383, 16384, 5]):
+            row = oracle_lib.synth_rows(3, [r], D)[0]
+            assert sc[i, 0] == oracle_lib.dot_tree(q[i], row)
+
+
+def test_sharded_scan_matches_single():
+    """Round-robin row shards (rank r keeps rows i % G == r) + merge == unsharded result, for G = 2, 3, 8.
+    All shard contexts live on the one GPU of the test box; the all-gather is emulated by a device concat."""
+    import torch
+    D, N = 512, 1400
+    plants, loops, ties = scenarios.loop_plants(N, 5, seed=11)
+    db = scenarios.build_db(17, N, D, plants)
+    orc_ticks = {}
+    orc = oracle_lib.LoopOracle(db)
+    sched = scenarios.default_schedule(N)
+    for l in sched:
+        orc_ticks[l] = orc.tick(l)
+    for G in (2, 3, 8):
+        chips = [capi.Chip(D, shard_rank=r, shard_count=G) for r in range(G)]
+        try:
+            K = 8
+            for c in chips:
+                c.append_f64(db[:333].astype(np.float64))
+                c.append_f32(db[333:])
+                assert c.info()["rows_local"] == len(range(c.shard_rank, N, G))
+            bufs = torch.zeros((G, 3, K, 2), dtype=torch.float64, device="cuda")
+            for l in sched:
+                st = [c.scan_local(l, bufs[r].data_ptr(), K) for r, c in enumerate(chips)]
+                assert len(set(st)) == 1
+                if st[0] != capi.CHIP_TICK_SCANNED:
+                    assert orc_ticks[l]["status"] == st[0]
+                    continue
+                for c in chips:
+                    c.synchronize()
+                res = [c.merge_decide(l, bufs.data_ptr(), G, K) for c in chips]
+                for r in res:
+                    same_tick(r, orc_ticks[l])
+        finally:
+            for c in chips:
+                c.close()
+
+
+def test_100k_full_oracle_parity():
+    """BASELINE config 2/3 scale (4096-D x 100k): full CPU oracle scan (threads) vs one GPU tick, bit-exact."""
+    D, N, seed = 4096, 100_053, 20190412
+    l = N
+    q, p = l - 1, 41234
+    plants = [(q - j, p - j, 1) for j in range(3)] + [(60000, p, 2)]     # a later exact duplicate of p -> tie rule
+    with capi.Chip(D, capacity_hint=N) as chip:
+        chip.append_synthetic(N, seed, plants)
+        chip.lib.chip_loop_reset(chip.h)
+        r = chip.loop_tick(l)
+        qrows = oracle_lib.synth_rows(seed, [l - 1, l - 2, l - 3], D, plants)
+        wsc, wix = oracle_lib.scan_topk_synth(seed, l - 50, D, qrows, 8, plants, nthreads=os.cpu_count() or 1)
+        assert r.status == capi.CHIP_TICK_SCANNED and r.found == 1
+        assert list(r.argmax) == list(wix[:, 0]) and r.idx_prev == 60000 and r.idx_curr == q
+        assert [float(x).hex() for x in r.maxv] == [float(x).hex() for x in wsc[:, 0]]
+        assert_topk_equal(chip.query_rows(l - 50, [l - 1, l - 2, l - 3], 8), (wsc, wix))
