@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -29,7 +30,7 @@ CHIP_ERR_BUSY = -10
 CHIP_MAX_TOPK = 16
 CHIP_MAX_NQ = 4
 CHIP_DEFAULT_TOPK = 8
-CHIP_RING_ROWS = 64
+CHIP_RING_ROWS = 4096
 CHIP_MAX_INFLIGHT = 64
 CHIP_APPEND_ALLOW_ROUNDING = 1
 
@@ -122,6 +123,14 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     if _lib is not None and path is None:
         return _lib
     p = Path(path) if path else LIB_PATH
+    # One HIP runtime per process.  The torch wheel bundles its own libamdhip64 (SONAME libamdhip64.so.7 but
+    # NEEDED by file name), so a torch imported AFTER this library maps a second runtime that sees no GPUs.
+    # When torch is installed, let it load its runtime first; this library then binds to the same one.
+    if p.exists() and "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch absent: the system ROCm runtime is used
+            pass
     if not p.exists():
         raise FileNotFoundError(
             f"{p} not found: the HIP extension is not built. Run `make lib` (or __graft_entry__.build()). "

@@ -155,10 +155,10 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
 
     c->scan_block = env_int("CHIP_SCAN_BLOCK", 512);
     if (c->scan_block != 256 && c->scan_block != 512) c->scan_block = 512;
-    c->scan_blocks_per_cu = env_int("CHIP_SCAN_BPC", 3);
+    c->scan_blocks_per_cu = env_int("CHIP_SCAN_BPC", 2);
     if (c->scan_blocks_per_cu < 1) c->scan_blocks_per_cu = 1;
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);
-    c->max_grid = c->n_cus * 8;
+    c->max_grid = c->n_cus * 4 < 1024 ? c->n_cus * 4 : 1024;  // topk_merge holds <= 16384 candidates per query
     CHIP_HIP(c, hipMalloc(&c->partial_dev, (size_t)c->max_grid * CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry)));
     CHIP_HIP(c, hipMalloc(&c->topk_dev, (size_t)CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry)));
     CHIP_HIP(c, hipHostMalloc(&c->topk_host, (size_t)CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry), hipHostMallocDefault));
@@ -229,13 +229,18 @@ static int enqueue_scan(Ctx *c, hipStream_t s, int64_t k, const float *const *q,
 // Pointers of the query rows (device).  Single GPU: straight into the DB; sharded: the replicated ring.
 static int query_row_ptrs(Ctx *c, const int64_t *rows, int nq, int64_t n_global, const float **q)
 {
+    int64_t total;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        total = c->rows_global;
+    }
     for (int i = 0; i < nq; i++) {
         const int64_t g = rows[i];
-        if (g < 0 || g >= n_global) return CHIP_ERR_RANGE;
+        if (g < 0 || g >= n_global || g >= total) return CHIP_ERR_RANGE;
         if (c->nranks == 1) {
             q[i] = row_ptr_host(c, g);
         } else {
-            if (g < n_global - CHIP_RING_ROWS) return CHIP_ERR_RANGE;
+            if (g < total - CHIP_RING_ROWS) return CHIP_ERR_RANGE;  // no longer in the replicated ring
             q[i] = c->ring_dev + (g % CHIP_RING_ROWS) * (int64_t)c->D;
         }
     }
@@ -330,37 +335,34 @@ static int append_impl(Ctx *c, const T *desc, int64_t n, uint32_t flags, int64_t
     int rc = ensure_capacity(c, local_count(c, first + n));
     if (rc != CHIP_OK) return rc;
 
-    // pass 1 writes the DB only (rows past the published length are invisible); the ring is updated after validation
-    *c->flags_host = 0;
-    rc = CHIP_OK;
-    do {
-        if (hipMemsetAsync(c->flags_dev, 0, sizeof(uint32_t), c->s_append) != hipSuccess) { rc = CHIP_ERR_HIP; break; }
+    // Upload rows [from, from+count) of this call in staging-sized chunks and run K3 on them.
+    auto pass = [&](int64_t from, int64_t count, bool ring) -> int {
         const int64_t chunk_rows = (int64_t)(c->stage_bytes / ((size_t)c->D * sizeof(T)));
-        for (int64_t off = 0; off < n && rc == CHIP_OK; off += chunk_rows) {
-            const int64_t m = (n - off) < chunk_rows ? (n - off) : chunk_rows;
-            hipError_t e = hipMemcpyAsync(c->stage_dev, desc + off * c->D, (size_t)m * c->D * sizeof(T), hipMemcpyHostToDevice, c->s_append);
-            if (e != hipSuccess) { c->last_hip = e; rc = CHIP_ERR_HIP; break; }
-            rc = is_f64 ? launch_narrow_f64(c, c->s_append, (const double *)c->stage_dev, m, first + off, c->flags_dev, false)
-                        : launch_copy_f32(c, c->s_append, (const float *)c->stage_dev, m, first + off, c->flags_dev, false);
+        for (int64_t off = from; off < from + count; off += chunk_rows) {
+            const int64_t m = (from + count - off) < chunk_rows ? (from + count - off) : chunk_rows;
+            CHIP_HIP(c, hipMemcpyAsync(c->stage_dev, desc + off * c->D, (size_t)m * c->D * sizeof(T), hipMemcpyHostToDevice, c->s_append));
+            const int r = is_f64 ? launch_narrow_f64(c, c->s_append, (const double *)c->stage_dev, m, first + off, c->flags_dev, ring)
+                                 : launch_copy_f32(c, c->s_append, (const float *)c->stage_dev, m, first + off, c->flags_dev, ring);
+            if (r != CHIP_OK) return r;
             // the staging buffer is reused by the next chunk: stream order serialises copy -> kernel -> copy
         }
-        if (rc != CHIP_OK) break;
-        hipError_t e = hipMemcpyAsync(c->flags_host, c->flags_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->s_append);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->s_append);
-        if (e != hipSuccess) { c->last_hip = e; rc = CHIP_ERR_HIP; break; }
-    } while (0);
+        return CHIP_OK;
+    };
+    // pass 1 writes the DB only (rows past the published length are invisible); the ring is updated after validation
+    *c->flags_host = 0;
+    CHIP_HIP(c, hipMemsetAsync(c->flags_dev, 0, sizeof(uint32_t), c->s_append));
+    rc = pass(0, n, false);
     if (rc != CHIP_OK) return rc;
+    CHIP_HIP(c, hipMemcpyAsync(c->flags_host, c->flags_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->s_append));
+    CHIP_HIP(c, hipStreamSynchronize(c->s_append));
 
     const uint32_t bad = *c->flags_host;
     if (bad & 2u) return CHIP_ERR_NONFINITE;
     if ((bad & 1u) && !(flags & CHIP_APPEND_ALLOW_ROUNDING)) return CHIP_ERR_NOT_F32;
 
-    if (c->ring_dev) {  // sharded: replicate the newest rows into the ring (second, tiny pass; DB store is idempotent)
+    if (c->ring_dev) {  // sharded: mirror the newest rows into the replicated ring (DB store is idempotent)
         const int64_t m = n < CHIP_RING_ROWS ? n : CHIP_RING_ROWS;
-        const int64_t off = n - m;
-        CHIP_HIP(c, hipMemcpyAsync(c->stage_dev, desc + off * c->D, (size_t)m * c->D * sizeof(T), hipMemcpyHostToDevice, c->s_append));
-        rc = is_f64 ? launch_narrow_f64(c, c->s_append, (const double *)c->stage_dev, m, first + off, c->flags_dev, true)
-                    : launch_copy_f32(c, c->s_append, (const float *)c->stage_dev, m, first + off, c->flags_dev, true);
+        rc = pass(n - m, m, true);
         if (rc != CHIP_OK) return rc;
         CHIP_HIP(c, hipStreamSynchronize(c->s_append));
     }

@@ -207,52 +207,69 @@ int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid)
 }
 
 // ------------------------------------------------------------------------------------------------ K2
-// One block, NQ groups of 256 threads.  K rounds of "largest key strictly below the previous winner".
+// One block of 1024 threads.  Per query: every thread loads its <= kMergeE candidates ONCE into registers
+// (one L2 latency instead of K dependent sweeps), then K rounds of {register argmax -> wave butterfly ->
+// 16-entry LDS reduce}; the owner of a winner retires it.  Keys are unique (indices are), empties are (-inf,-1).
+constexpr int kMergeThreads = 1024;
+constexpr int kMergeE = 16;   // n_lists * K <= kMergeThreads * kMergeE = 16384
+
 template <int NQ>
-__global__ __launch_bounds__(NQ * 256) void topk_merge(MergeArgs a)
+__global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a)
 {
-    __shared__ double red_s[NQ][4];
-    __shared__ int64_t red_i[NQ][4];
+    __shared__ double red_s[kMergeThreads / 64];
+    __shared__ int64_t red_i[kMergeThreads / 64];
     __shared__ double top_s[NQ];
     __shared__ int64_t top_i[NQ];
-    const int g = threadIdx.x >> 8;
-    const int t = threadIdx.x & 255;
+    const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
     const int K = a.K;
     const int n = a.n_lists * K;
 
-    double prev_s = INFINITY;
-    int64_t prev_i = INT64_MAX;
-    for (int j = 0; j < K; j++) {
-        double bs = -INFINITY;
-        int64_t bi = -1;
-        for (int c = t; c < n; c += 256) {
-            const chip_topk_entry e = a.in[((int64_t)(c / K) * NQ + g) * K + (c % K)];
-            if (key_gt(prev_s, prev_i, e.score, e.idx) && key_gt(e.score, e.idx, bs, bi)) { bs = e.score; bi = e.idx; }
-        }
+    for (int q = 0; q < NQ; q++) {
+        double cs[kMergeE];
+        int64_t ci[kMergeE];
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const double os = __shfl_xor(bs, m, 64);
-            const int64_t oi = __shfl_xor(bi, m, 64);
-            if (key_gt(os, oi, bs, bi)) { bs = os; bi = oi; }
+        for (int e = 0; e < kMergeE; e++) {
+            const int c = t + e * kMergeThreads;
+            if (c < n) {
+                const chip_topk_entry x = a.in[((int64_t)(c / K) * NQ + q) * K + (c % K)];
+                cs[e] = x.score;
+                ci[e] = x.idx;
+            } else { cs[e] = -INFINITY; ci[e] = -1; }
         }
-        if (lane == 0) { red_s[g][w] = bs; red_i[g][w] = bi; }
-        __syncthreads();
-        bs = red_s[g][0];
-        bi = red_i[g][0];
+        for (int j = 0; j < K; j++) {
+            double bs = cs[0];
+            int64_t bi = ci[0];
 #pragma unroll
-        for (int x = 1; x < 4; x++)
-            if (key_gt(red_s[g][x], red_i[g][x], bs, bi)) { bs = red_s[g][x]; bi = red_i[g][x]; }
-        __syncthreads();
-        if (t == 0) {
-            if (a.out) { chip_topk_entry e; e.score = bs; e.idx = bi; a.out[g * K + j] = e; }
-            if (j == 0) { top_s[g] = bs; top_i[g] = bi; }
+            for (int e = 1; e < kMergeE; e++)
+                if (key_gt(cs[e], ci[e], bs, bi)) { bs = cs[e]; bi = ci[e]; }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const double os = __shfl_xor(bs, m, 64);
+                const int64_t oi = __shfl_xor(bi, m, 64);
+                if (key_gt(os, oi, bs, bi)) { bs = os; bi = oi; }
+            }
+            if (lane == 0) { red_s[w] = bs; red_i[w] = bi; }
+            __syncthreads();
+            bs = red_s[0];
+            bi = red_i[0];
+#pragma unroll
+            for (int x = 1; x < kMergeThreads / 64; x++)
+                if (key_gt(red_s[x], red_i[x], bs, bi)) { bs = red_s[x]; bi = red_i[x]; }
+            __syncthreads();
+            if (bi >= 0) {
+#pragma unroll
+                for (int e = 0; e < kMergeE; e++)
+                    if (ci[e] == bi) { cs[e] = -INFINITY; ci[e] = -1; }
+            }
+            if (t == 0) {
+                if (a.out) { chip_topk_entry x; x.score = bs; x.idx = bi; a.out[q * K + j] = x; }
+                if (j == 0) { top_s[q] = bs; top_i[q] = bi; }
+            }
         }
-        prev_s = bs;
-        prev_i = bi;
     }
     __syncthreads();
-    if (a.result != nullptr && threadIdx.x == 0) {
+    if (a.result != nullptr && t == 0) {
         chip_tick_result r;
         r.status = CHIP_TICK_SCANNED;
         r.found = 0;
@@ -282,11 +299,12 @@ __global__ __launch_bounds__(NQ * 256) void topk_merge(MergeArgs a)
 
 int launch_merge(Ctx *c, hipStream_t s, const MergeArgs &a, int nq)
 {
+    if ((int64_t)a.n_lists * a.K > (int64_t)kMergeThreads * kMergeE) return CHIP_ERR_UNSUPPORTED;
     switch (nq) {
-        case 1: hipLaunchKernelGGL(topk_merge<1>, dim3(1), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(topk_merge<2>, dim3(1), dim3(512), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(topk_merge<3>, dim3(1), dim3(768), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(topk_merge<4>, dim3(1), dim3(1024), 0, s, a); break;
+        case 1: hipLaunchKernelGGL(topk_merge<1>, dim3(1), dim3(kMergeThreads), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(topk_merge<2>, dim3(1), dim3(kMergeThreads), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(topk_merge<3>, dim3(1), dim3(kMergeThreads), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(topk_merge<4>, dim3(1), dim3(kMergeThreads), 0, s, a); break;
         default: return CHIP_ERR_UNSUPPORTED;
     }
     CHIP_HIP(c, hipGetLastError());
@@ -303,6 +321,7 @@ struct StoreArgs {
     int32_t rank, nranks;
     int64_t first_global;
     int64_t n;
+    int64_t ring_from;   // only global rows >= ring_from are mirrored into the ring (the newest CHIP_RING_ROWS)
     uint32_t *flags;
 };
 
@@ -313,7 +332,7 @@ __device__ __forceinline__ void store_row4(const StoreArgs &a, int64_t g, int e,
         float *dst = a.seg_table[loc >> a.seg_shift] + (loc & a.seg_mask) * (int64_t)a.D + e;
         *reinterpret_cast<f32x4 *>(dst) = v;
     }
-    if (a.ring) *reinterpret_cast<f32x4 *>(a.ring + (g % CHIP_RING_ROWS) * (int64_t)a.D + e) = v;
+    if (a.ring && g >= a.ring_from) *reinterpret_cast<f32x4 *>(a.ring + (g % CHIP_RING_ROWS) * (int64_t)a.D + e) = v;
 }
 
 __global__ __launch_bounds__(256) void narrow_f64_rows(StoreArgs a, const double *__restrict__ src)
@@ -369,6 +388,7 @@ static StoreArgs make_store_args(Ctx *c, int64_t first_global, int64_t n, uint32
     a.nranks = c->nranks;
     a.first_global = first_global;
     a.n = n;
+    a.ring_from = first_global + n - CHIP_RING_ROWS;
     a.flags = flags;
     return a;
 }

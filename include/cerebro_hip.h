@@ -62,11 +62,13 @@ int chip_last_hip_error(const chip_ctx *ctx, const char **text);
  *
  * Sharding (BASELINE config 4): with shard_count = G > 1 the ctx of rank r stores global rows i with
  * i % G == r (round-robin keeps every prefix [0,k) balanced) plus a replicated ring of the most recent
- * CHIP_RING_ROWS rows, from which the tick's three query descriptors are read.  Every rank must be fed the
- * same append stream.  One process per GPU; the per-shard top-k lists are exchanged by the HOST
+ * CHIP_RING_ROWS rows (64 MiB at D=4096), from which the tick's three query descriptors are read: a sharded
+ * tick at l therefore needs chip_db_size() - l <= CHIP_RING_ROWS - 3 (else CHIP_ERR_RANGE) -- always true in
+ * live operation, where ticks trail the append head by a few rows.  Every rank must be fed the same append
+ * stream.  One process per GPU; the per-shard top-k lists are exchanged by the HOST
  * (RCCL all-gather via torch.distributed, or any other transport) between chip_scan_local and
  * chip_merge_decide.                                                                                   */
-#define CHIP_RING_ROWS 64
+#define CHIP_RING_ROWS 4096
 int  chip_create(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device, int32_t shard_rank, int32_t shard_count);
 void chip_destroy(chip_ctx *ctx);
 /* Run all work of this ctx on an externally owned hipStream_t (e.g. torch's current stream). NULL -> own stream. */

