@@ -107,14 +107,13 @@ static void destroy_ctx(chip_ctx *c)
     if (c->flags_dev) (void)hipFree(c->flags_dev);
     if (c->flags_host) (void)hipHostFree(c->flags_host);
     if (c->partial_dev) (void)hipFree(c->partial_dev);
-    if (c->topk_dev) (void)hipFree(c->topk_dev);
     if (c->topk_host) (void)hipHostFree(c->topk_host);
     if (c->qvec_dev) (void)hipFree(c->qvec_dev);
     for (Slot &s : c->slots) {
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.host) (void)hipHostFree(s.host);
-        if (s.dev) (void)hipFree(s.dev);
     }
+    if (c->ticket_dev) (void)hipFree(c->ticket_dev);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->s_query && c->own_query_stream) (void)hipStreamDestroy(c->s_query);
     if (c->s_append) (void)hipStreamDestroy(c->s_append);
@@ -158,15 +157,18 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
     c->scan_blocks_per_cu = env_int("CHIP_SCAN_BPC", 2);
     if (c->scan_blocks_per_cu < 1) c->scan_blocks_per_cu = 1;
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);
-    c->max_grid = c->n_cus * 4 < 1024 ? c->n_cus * 4 : 1024;  // topk_merge holds <= 16384 candidates per query
+    c->max_grid = c->scan_block;  // the last block of the fused scan keeps one partial list per thread
     CHIP_HIP(c, hipMalloc(&c->partial_dev, (size_t)c->max_grid * CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry)));
-    CHIP_HIP(c, hipMalloc(&c->topk_dev, (size_t)CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry)));
     CHIP_HIP(c, hipHostMalloc(&c->topk_host, (size_t)CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry), hipHostMallocDefault));
+    CHIP_HIP(c, hipHostGetDevicePointer((void **)&c->topk_dev, c->topk_host, 0));
     CHIP_HIP(c, hipMalloc(&c->qvec_dev, (size_t)CHIP_MAX_NQ * c->D * sizeof(float)));
+    CHIP_HIP(c, hipMalloc(&c->ticket_dev, sizeof(unsigned)));
+    CHIP_HIP(c, hipMemset(c->ticket_dev, 0, sizeof(unsigned)));
     for (Slot &s : c->slots) {
         CHIP_HIP(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        // pinned + mapped: the deciding workgroup stores the record here directly, no D2H copy kernel per tick
         CHIP_HIP(c, hipHostMalloc(&s.host, sizeof(chip_tick_result), hipHostMallocDefault));
-        CHIP_HIP(c, hipMalloc(&s.dev, sizeof(chip_tick_result)));
+        CHIP_HIP(c, hipHostGetDevicePointer((void **)&s.dev, s.host, 0));
     }
     int rc = pnp_create(c);
     if (rc != CHIP_OK) return rc;
@@ -178,9 +180,10 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
     return CHIP_OK;
 }
 
-// Enqueue K1 (+ K2) for nq queries over global prefix [0,k).  out_dev gets [nq][K]; res_dev (optional) the decision.
+// Enqueue the fused scan (K1: scan + top-k + last-block merge [+ decision]) for nq queries over global prefix [0,k).
+// out (device or pinned host, optional) gets [nq][K]; res (optional) the accept decision of Cerebro.cpp:1056.
 static int enqueue_scan(Ctx *c, hipStream_t s, int64_t k, const float *const *q, int nq, int K, int64_t l,
-                        const chip_dot_params *p, chip_topk_entry *out_dev, chip_tick_result *res_dev)
+                        const chip_dot_params *p, chip_topk_entry *out, chip_tick_result *res)
 {
     ScanArgs a;
     a.seg_table = c->seg_table_dev;
@@ -194,6 +197,13 @@ static int enqueue_scan(Ctx *c, hipStream_t s, int64_t k, const float *const *q,
     a.idx_add = c->nranks == 1 ? 0 : c->rank;
     a.partial = c->partial_dev;
     const int grid = scan_grid_for(c, a.n_rows, nq);
+    a.ticket = c->ticket_dev;
+    a.ticket_target = (unsigned)(c->ticket_total + (uint64_t)grid);  // cumulative: launches on one stream are serialised
+    a.out = out;
+    a.result = res;
+    a.l = l;
+    a.locality = p ? p->locality : 0;
+    a.thresh = p ? p->thresh : 0.0;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->prof_on) {
@@ -211,19 +221,15 @@ static int enqueue_scan(Ctx *c, hipStream_t s, int64_t k, const float *const *q,
         CHIP_HIP(c, hipEventRecord(e0, s));
     }
     int rc = launch_scan(c, s, a, nq, grid);
-    if (rc != CHIP_OK) return rc;
+    if (rc != CHIP_OK) {  // nothing ran: re-arm the arrival counter so that the host mirror cannot drift
+        (void)hipStreamSynchronize(s);
+        (void)hipMemset(c->ticket_dev, 0, sizeof(unsigned));
+        c->ticket_total = 0;
+        return rc;
+    }
+    c->ticket_total += (uint64_t)grid;
     if (e1) CHIP_HIP(c, hipEventRecord(e1, s));
-
-    MergeArgs m;
-    m.in = c->partial_dev;
-    m.n_lists = grid;
-    m.K = K;
-    m.out = out_dev;
-    m.result = res_dev;
-    m.l = l;
-    m.locality = p ? p->locality : 0;
-    m.thresh = p ? p->thresh : 0.0;
-    return launch_merge(c, s, m, nq);
+    return CHIP_OK;
 }
 
 // Pointers of the query rows (device).  Single GPU: straight into the DB; sharded: the replicated ring.
@@ -290,9 +296,8 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
     const float *q[3];
     rc = query_row_ptrs(c, rows, 3, l, q);
     if (rc != CHIP_OK) return rc;
-    rc = enqueue_scan(c, c->s_query, k, q, 3, CHIP_DEFAULT_TOPK, l, p, c->topk_dev, s.dev);
+    rc = enqueue_scan(c, c->s_query, k, q, 3, CHIP_DEFAULT_TOPK, l, p, nullptr, s.dev);
     if (rc != CHIP_OK) return rc;
-    CHIP_HIP(c, hipMemcpyAsync(s.host, s.dev, sizeof(chip_tick_result), hipMemcpyDeviceToHost, c->s_query));
     CHIP_HIP(c, hipEventRecord(s.done, c->s_query));
     s.immediate = false;
     s.in_flight = true;
@@ -310,8 +315,7 @@ static int tick_collect_slot(Ctx *c, Slot &s, chip_tick_result *out)
 
 static int sync_topk_out(Ctx *c, int nq, int K, double *scores, int64_t *idx)
 {
-    CHIP_HIP(c, hipMemcpyAsync(c->topk_host, c->topk_dev, (size_t)nq * K * sizeof(chip_topk_entry), hipMemcpyDeviceToHost, c->s_query));
-    CHIP_HIP(c, hipStreamSynchronize(c->s_query));
+    CHIP_HIP(c, hipStreamSynchronize(c->s_query));  // the last block stored the list into pinned host memory
     for (int i = 0; i < nq * K; i++) {
         if (scores) scores[i] = c->topk_host[i].score;
         if (idx) idx[i] = c->topk_host[i].idx;
@@ -625,7 +629,6 @@ int chip_merge_decide(chip_ctx *c, int64_t l, const chip_dot_params *p, const vo
     m.thresh = p->thresh;
     int rc = launch_merge(c, c->s_query, m, 3);
     if (rc != CHIP_OK) return rc;
-    CHIP_HIP(c, hipMemcpyAsync(s.host, s.dev, sizeof(chip_tick_result), hipMemcpyDeviceToHost, c->s_query));
     CHIP_HIP(c, hipStreamSynchronize(c->s_query));
     *out = *s.host;
     return CHIP_OK;

@@ -24,7 +24,109 @@ __device__ __forceinline__ bool key_gt(double s, int64_t i, double s2, int64_t i
     return s > s2 || (s == s2 && i > i2);
 }
 
+// Cross-workgroup hand-off of partial lists (cdna_hip_programming.md G16, form R1): the producer stores the payload
+// WRITE-THROUGH (relaxed agent-scope 8-byte atomic stores lower to `global_store_dwordx2 sc1`), so no release
+// fence (512 `buffer_wbl2` per launch cost ~50 us here); the consumer reads with sc1 loads (L1-bypassing).
+__device__ __forceinline__ void store_entry_sc1(chip_topk_entry *p, double s, int64_t i)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&p->score), (unsigned long long)__double_as_longlong(s),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&p->idx), (unsigned long long)i, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void load_entry_sc1(const chip_topk_entry *p, double &s, int64_t &i)
+{
+    chip_topk_entry *q = const_cast<chip_topk_entry *>(p);
+    s = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&q->score), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+    i = (int64_t)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&q->idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------------ list merge
+// Merge n_lists (<= blockDim.x) SORTED lists of K candidates per query into the global top-K and, optionally, apply
+// the accept rule of Cerebro.cpp:1056.  One workgroup.  Thread t keeps list t register-resident; K rounds of
+// {argmax over the list HEADS: wave butterfly + one LDS hop} ; the winner's owner shifts its list by one.
+// One barrier per round (LDS slots double-buffered by round parity).  smem: >= 1 KiB scratch.
+template <int NQ>
+__device__ __forceinline__ void merge_sorted_lists(const chip_topk_entry *in, int n_lists, int K, chip_topk_entry *out,
+                                                   chip_tick_result *result, int64_t l, int locality, double thresh, char *smem)
+{
+    double *red_s = reinterpret_cast<double *>(smem);              // [2][16]
+    int64_t *red_i = reinterpret_cast<int64_t *>(smem + 256);      // [2][16]
+    double *top_s = reinterpret_cast<double *>(smem + 512);        // [NQ]
+    int64_t *top_i = reinterpret_cast<int64_t *>(smem + 512 + 64); // [NQ]
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6, nw = blockDim.x >> 6;
+
+    for (int q = 0; q < NQ; q++) {
+        double es[CHIP_MAX_TOPK];
+        int64_t ei[CHIP_MAX_TOPK];
+#pragma unroll
+        for (int j = 0; j < CHIP_MAX_TOPK; j++) {
+            if (j < K && t < n_lists) load_entry_sc1(in + ((int64_t)t * NQ + q) * K + j, es[j], ei[j]);
+            else { es[j] = -INFINITY; ei[j] = -1; }
+        }
+        for (int r = 0; r < K; r++) {
+            double bs = es[0];
+            int64_t bi = ei[0];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const double os = __shfl_xor(bs, m, 64);
+                const int64_t oi = __shfl_xor(bi, m, 64);
+                if (key_gt(os, oi, bs, bi)) { bs = os; bi = oi; }
+            }
+            const int par = (r & 1) * 16;
+            if (lane == 0) { red_s[par + w] = bs; red_i[par + w] = bi; }
+            __syncthreads();
+            bs = red_s[par];
+            bi = red_i[par];
+            for (int x = 1; x < nw; x++)
+                if (key_gt(red_s[par + x], red_i[par + x], bs, bi)) { bs = red_s[par + x]; bi = red_i[par + x]; }
+            if (bi >= 0 && ei[0] == bi) {  // indices are unique: exactly one owner
+#pragma unroll
+                for (int j = 0; j + 1 < CHIP_MAX_TOPK; j++) { es[j] = es[j + 1]; ei[j] = ei[j + 1]; }
+                es[CHIP_MAX_TOPK - 1] = -INFINITY;
+                ei[CHIP_MAX_TOPK - 1] = -1;
+            }
+            if (t == 0) {
+                if (out) { chip_topk_entry x; x.score = bs; x.idx = bi; out[q * K + r] = x; }
+                if (r == 0) { top_s[q] = bs; top_i[q] = bi; }
+            }
+        }
+        __syncthreads();  // red_* slots are reused by the next query
+    }
+    if (result != nullptr && t == 0) {
+        chip_tick_result res;
+        res.status = CHIP_TICK_SCANNED;
+        res.found = 0;
+        res.idx_curr = -1;
+        res.idx_prev = -1;
+        res.score = 0.0;
+        for (int q = 0; q < 3; q++) {
+            res.argmax[q] = q < NQ ? top_i[q] : -1;
+            res.maxv[q] = q < NQ ? top_s[q] : -INFINITY;
+        }
+        if (NQ >= 3 && res.argmax[0] >= 0 && res.argmax[1] >= 0 && res.argmax[2] >= 0) {
+            // Cerebro.cpp:1056  abs(u_argmax-um_argmax) < LOCALITY && abs(u_argmax-umm_argmax) < LOCALITY && u_max > THRESH
+            int64_t d1 = res.argmax[0] - res.argmax[1];
+            int64_t d2 = res.argmax[0] - res.argmax[2];
+            if (d1 < 0) d1 = -d1;
+            if (d2 < 0) d2 = -d2;
+            if (d1 < locality && d2 < locality && res.maxv[0] > thresh) {
+                res.found = 1;
+                res.idx_curr = l - 1;  // Cerebro.cpp:1080
+                res.idx_prev = res.argmax[0];
+                res.score = res.maxv[0];
+            }
+        }
+        *result = res;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ K1
+// One launch per tick: scan -> per-wave register top-K -> per-block LDS merge -> partial list to global ->
+// agent-scope release + ticket; the LAST block to arrive acquires, merges all partial lists and writes the
+// top-K (and the accept decision) to `out` / `result` (device memory or pinned host memory).
 template <int NQ, int U, bool FULL>
 __global__ __launch_bounds__(512) void db_scan_topk(ScanArgs a)
 {
@@ -109,7 +211,7 @@ __global__ __launch_bounds__(512) void db_scan_topk(ScanArgs a)
         }
     }
 
-    // ---- block merge: wpb lists of K per query -> one list of K, by waves 0..NQ-1 ----
+    // ---- block merge: wpb sorted lists of K per query -> one sorted list of K, by waves 0..NQ-1 ----
     __syncthreads();  // all waves done with qs; reuse LDS
     chip_topk_entry *cand = reinterpret_cast<chip_topk_entry *>(smem);  // [wpb][NQ][K]
     if (lane < K) {
@@ -148,9 +250,22 @@ __global__ __launch_bounds__(512) void db_scan_topk(ScanArgs a)
             }
             if (ci[0] == bi && cs[0] == bs) { cs[0] = -INFINITY; ci[0] = -1; }
             if (ci[1] == bi && cs[1] == bs) { cs[1] = -INFINITY; ci[1] = -1; }
-            if (lane == 0) { chip_topk_entry t; t.score = bs; t.idx = bi; outp[j] = t; }
+            if (lane == 0) store_entry_sc1(outp + j, bs, bi);
         }
     }
+
+    // ---- publish + ticket (placement-independent; write-through payload, every storing wave drains, ONE ticket) ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int *is_last = reinterpret_cast<int *>(smem + 1024);
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *is_last = (old + 1u == a.ticket_target) ? 1 : 0;   // tickets are cumulative over launches: never reset
+    }
+    __syncthreads();
+    if (*is_last == 0) return;
+    // last arriver: every other block's sc1 stores were drained before its ticket; the sc1 loads below bypass L1
+    merge_sorted_lists<NQ>(a.partial, (int)gridDim.x, K, a.out, a.result, a.l, a.locality, a.thresh, smem);
 }
 
 template <int NQ, int U>
@@ -196,7 +311,8 @@ int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid)
     size_t lds_q = (size_t)nq * a.D * sizeof(float);
     size_t lds_m = (size_t)wpb * nq * a.K * sizeof(chip_topk_entry);
     size_t lds = lds_q > lds_m ? lds_q : lds_m;
-    if (lds > 160 * 1024) return CHIP_ERR_UNSUPPORTED;
+    if (lds < 2048) lds = 2048;  // merge scratch + ticket flag
+    if (lds > 160 * 1024 || grid > c->scan_block) return CHIP_ERR_UNSUPPORTED;  // the last block holds one list per thread
     switch (nq) {
         case 1: return launch_scan_q<1>(c, s, a, grid, lds);
         case 2: return launch_scan_q<2>(c, s, a, grid, lds);
@@ -207,104 +323,22 @@ int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid)
 }
 
 // ------------------------------------------------------------------------------------------------ K2
-// One block of 1024 threads.  Per query: every thread loads its <= kMergeE candidates ONCE into registers
-// (one L2 latency instead of K dependent sweeps), then K rounds of {register argmax -> wave butterfly ->
-// 16-entry LDS reduce}; the owner of a winner retires it.  Keys are unique (indices are), empties are (-inf,-1).
-constexpr int kMergeThreads = 1024;
-constexpr int kMergeE = 16;   // n_lists * K <= kMergeThreads * kMergeE = 16384
-
+// Stand-alone merge (+ decision) of per-GPU lists after the RCCL all-gather: one workgroup of 512 threads.
 template <int NQ>
-__global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a)
+__global__ __launch_bounds__(512) void topk_merge(MergeArgs a)
 {
-    __shared__ double red_s[kMergeThreads / 64];
-    __shared__ int64_t red_i[kMergeThreads / 64];
-    __shared__ double top_s[NQ];
-    __shared__ int64_t top_i[NQ];
-    const int t = threadIdx.x;
-    const int lane = t & 63, w = t >> 6;
-    const int K = a.K;
-    const int n = a.n_lists * K;
-
-    for (int q = 0; q < NQ; q++) {
-        double cs[kMergeE];
-        int64_t ci[kMergeE];
-#pragma unroll
-        for (int e = 0; e < kMergeE; e++) {
-            const int c = t + e * kMergeThreads;
-            if (c < n) {
-                const chip_topk_entry x = a.in[((int64_t)(c / K) * NQ + q) * K + (c % K)];
-                cs[e] = x.score;
-                ci[e] = x.idx;
-            } else { cs[e] = -INFINITY; ci[e] = -1; }
-        }
-        for (int j = 0; j < K; j++) {
-            double bs = cs[0];
-            int64_t bi = ci[0];
-#pragma unroll
-            for (int e = 1; e < kMergeE; e++)
-                if (key_gt(cs[e], ci[e], bs, bi)) { bs = cs[e]; bi = ci[e]; }
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                const double os = __shfl_xor(bs, m, 64);
-                const int64_t oi = __shfl_xor(bi, m, 64);
-                if (key_gt(os, oi, bs, bi)) { bs = os; bi = oi; }
-            }
-            if (lane == 0) { red_s[w] = bs; red_i[w] = bi; }
-            __syncthreads();
-            bs = red_s[0];
-            bi = red_i[0];
-#pragma unroll
-            for (int x = 1; x < kMergeThreads / 64; x++)
-                if (key_gt(red_s[x], red_i[x], bs, bi)) { bs = red_s[x]; bi = red_i[x]; }
-            __syncthreads();
-            if (bi >= 0) {
-#pragma unroll
-                for (int e = 0; e < kMergeE; e++)
-                    if (ci[e] == bi) { cs[e] = -INFINITY; ci[e] = -1; }
-            }
-            if (t == 0) {
-                if (a.out) { chip_topk_entry x; x.score = bs; x.idx = bi; a.out[q * K + j] = x; }
-                if (j == 0) { top_s[q] = bs; top_i[q] = bi; }
-            }
-        }
-    }
-    __syncthreads();
-    if (a.result != nullptr && t == 0) {
-        chip_tick_result r;
-        r.status = CHIP_TICK_SCANNED;
-        r.found = 0;
-        r.idx_curr = -1;
-        r.idx_prev = -1;
-        r.score = 0.0;
-        for (int q = 0; q < 3; q++) {
-            r.argmax[q] = q < NQ ? top_i[q] : -1;
-            r.maxv[q] = q < NQ ? top_s[q] : -INFINITY;
-        }
-        if (NQ >= 3 && r.argmax[0] >= 0 && r.argmax[1] >= 0 && r.argmax[2] >= 0) {
-            // Cerebro.cpp:1056  abs(u_argmax-um_argmax) < LOCALITY && abs(u_argmax-umm_argmax) < LOCALITY && u_max > THRESH
-            int64_t d1 = r.argmax[0] - r.argmax[1];
-            int64_t d2 = r.argmax[0] - r.argmax[2];
-            if (d1 < 0) d1 = -d1;
-            if (d2 < 0) d2 = -d2;
-            if (d1 < a.locality && d2 < a.locality && r.maxv[0] > a.thresh) {
-                r.found = 1;
-                r.idx_curr = a.l - 1;       // Cerebro.cpp:1080
-                r.idx_prev = r.argmax[0];
-                r.score = r.maxv[0];
-            }
-        }
-        *a.result = r;
-    }
+    __shared__ __attribute__((aligned(16))) char smem[2048];
+    merge_sorted_lists<NQ>(a.in, a.n_lists, a.K, a.out, a.result, a.l, a.locality, a.thresh, smem);
 }
 
 int launch_merge(Ctx *c, hipStream_t s, const MergeArgs &a, int nq)
 {
-    if ((int64_t)a.n_lists * a.K > (int64_t)kMergeThreads * kMergeE) return CHIP_ERR_UNSUPPORTED;
+    if (a.n_lists > 512) return CHIP_ERR_UNSUPPORTED;
     switch (nq) {
-        case 1: hipLaunchKernelGGL(topk_merge<1>, dim3(1), dim3(kMergeThreads), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(topk_merge<2>, dim3(1), dim3(kMergeThreads), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(topk_merge<3>, dim3(1), dim3(kMergeThreads), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(topk_merge<4>, dim3(1), dim3(kMergeThreads), 0, s, a); break;
+        case 1: hipLaunchKernelGGL(topk_merge<1>, dim3(1), dim3(512), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(topk_merge<2>, dim3(1), dim3(512), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(topk_merge<3>, dim3(1), dim3(512), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(topk_merge<4>, dim3(1), dim3(512), 0, s, a); break;
         default: return CHIP_ERR_UNSUPPORTED;
     }
     CHIP_HIP(c, hipGetLastError());

@@ -90,6 +90,43 @@ void orc_ref_scan_f64_colmajor(const double *M, int32_t D, int64_t k,
                                double *u, double *um, double *umm,
                                double maxv[3], int64_t argmax[3]);
 
+
+/* ================================================================== PnP / RANSAC (pnp_ransac.c) */
+typedef struct {
+    double  error_thresh;        /* 0.03   DlsPnpWithRansac.cpp:208 */
+    double  min_inlier_ratio;    /* 0.7    :209 */
+    int32_t max_iterations;      /* 50     :210 */
+    int32_t min_iterations;      /* 5      :211 */
+    int32_t use_mle;             /* 1      :212 */
+    int32_t sample_size;         /* 15     DlsPnpWithRansac.h:45 */
+    double  failure_probability; /* 0.01   theia default */
+    uint64_t seed;
+    int32_t n_hypotheses;        /* 0 = adaptive reference mode, >0 = fixed count, all scored */
+    int32_t reserved;
+} orc_ransac_params;
+typedef struct {
+    int32_t n_iterations, n_inliers, best_hypothesis, n_models;
+    double  best_cost;
+} orc_ransac_summary;
+
+uint64_t orc_rng_draw(uint64_t seed, uint32_t hyp, uint32_t draw);
+void   orc_ransac_sample(uint64_t seed, int32_t hyp, int32_t N, int32_t S, int32_t *out);
+void   orc_dls_linear_form(uint64_t seed, int32_t hyp, double u[4]);
+double orc_reproj_error(const double *T_colmajor, const double *X, const double *uv);
+void   orc_score_model(const double *T_colmajor, const double *X, const double *uv, int32_t N, double thresh, int32_t use_mle,
+                       double *cost, int32_t *n_inliers, uint8_t *mask);
+void   orc_dls_monomial_positions(int32_t pos[8][8][8]);
+void   orc_dls_cubics(const double *X, const double *uv, int32_t n, double Tfac[27], double f[3][20]);
+int    orc_dls_action_matrix(const double f[3][20], const double u[4], double S[27 * 27]);
+int    orc_eig27_real(const double S[27 * 27], double lambda[27], double v4[27][4]);
+int    orc_dls_pnp(const double *X, const double *uv, int32_t n, const double u[4], double *Rs, double *ts, int32_t max_out);
+int    orc_pnp_hypothesis(const double *X, const double *uv, int32_t N, uint64_t seed, int32_t hyp, int32_t S,
+                          double T[16], int32_t *sample_out);
+void   orc_ransac_params_default(orc_ransac_params *p);
+int32_t orc_ransac_max_iterations(int32_t S, double ratio, double log_fail, int32_t min_it, int32_t max_it);
+int    orc_pnp_ransac(const double *X, const double *uv, int32_t N, const orc_ransac_params *p,
+                      double T[16], float *confidence, uint8_t *mask, orc_ransac_summary *summary);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,159 @@
+"""Independent numpy implementation of DLS-PnP (Hesch & Roumeliotis, ICCV 2011) used ONLY to validate
+oracle/pnp_ransac.c: polynomials as {exponent-tuple: coeff} dicts, dense np.linalg.solve for the Schur
+complement, np.linalg.eig for the action matrix.  Written from the paper's formulation, not from the C code."""
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+
+
+def padd(p, q, s=1.0):
+    r = dict(p)
+    for k, v in q.items():
+        r[k] = r.get(k, 0.0) + s * v
+    return r
+
+
+def pmul(p, q):
+    r = {}
+    for (a, b, c), v in p.items():
+        for (d, e, f), w in q.items():
+            k = (a + d, b + e, c + f)
+            r[k] = r.get(k, 0.0) + v * w
+    return r
+
+
+def pdiff(p, var):
+    r = {}
+    for k, v in p.items():
+        if k[var] > 0:
+            kk = list(k); kk[var] -= 1
+            r[tuple(kk)] = r.get(tuple(kk), 0.0) + v * k[var]
+    return r
+
+
+def peval(p, s):
+    return sum(v * s[0] ** k[0] * s[1] ** k[1] * s[2] ** k[2] for k, v in p.items())
+
+
+ONE = {(0, 0, 0): 1.0}
+S1, S2, S3 = {(1, 0, 0): 1.0}, {(0, 1, 0): 1.0}, {(0, 0, 1): 1.0}
+
+
+def cayley_rbar():
+    """Rbar(s) = (1 - s.s) I + 2 [s]x + 2 s s^T as 3x3 of polynomials."""
+    s = [S1, S2, S3]
+    ss = padd(padd(pmul(S1, S1), pmul(S2, S2)), pmul(S3, S3))
+    R = [[None] * 3 for _ in range(3)]
+    skew = [[{}, padd({}, S3, -1), S2], [S3, {}, padd({}, S1, -1)], [padd({}, S2, -1), S1, {}]]
+    for i in range(3):
+        for j in range(3):
+            e = padd({}, pmul(s[i], s[j]), 2.0)
+            e = padd(e, skew[i][j], 2.0)
+            if i == j:
+                e = padd(e, padd(ONE, ss, -1.0))
+            R[i][j] = e
+    return R
+
+
+def dls_cost_matrix(X, uv):
+    n = X.shape[0]
+    z = np.concatenate([uv, np.ones((n, 1))], axis=1)
+    z /= np.linalg.norm(z, axis=1, keepdims=True)
+    def L(p):
+        M = np.zeros((3, 9)); M[0, 0:3] = p; M[1, 3:6] = p; M[2, 6:9] = p
+        return M
+    H = np.linalg.inv(n * np.eye(3) - sum(np.outer(zi, zi) for zi in z))
+    T = H @ sum((np.outer(zi, zi) - np.eye(3)) @ L(p) for zi, p in zip(z, X))
+    M9 = sum((L(p) + T).T @ (np.eye(3) - np.outer(zi, zi)) @ (L(p) + T) for zi, p in zip(z, X))
+    return T, M9
+
+
+def dls_cubics(X, uv):
+    T, M9 = dls_cost_matrix(X, uv)
+    R = cayley_rbar()
+    r = [R[i][j] for i in range(3) for j in range(3)]   # row-major vec
+    J = {}
+    for a in range(9):
+        for b in range(9):
+            J = padd(J, pmul(r[a], r[b]), M9[a, b])
+    return T, [pdiff(J, v) for v in range(3)]
+
+
+def monomials(deg):
+    return [(a, b, c) for a in range(deg + 1) for b in range(deg + 1 - a) for c in range(deg + 1 - a - b)]
+
+
+def action_matrix(f, u):
+    f0 = {(0, 0, 0): u[0], (1, 0, 0): u[1], (0, 1, 0): u[2], (0, 0, 1): u[3]}
+    mons = monomials(7)
+    red = [m for m in mons if max(m) <= 2]
+    red.sort(key=lambda m: 9 * m[0] + 3 * m[1] + m[2])
+    rest = [m for m in mons if max(m) > 2]
+    order = red + rest
+    pos = {m: i for i, m in enumerate(order)}
+    Mm = np.zeros((120, 120))
+    for m in order:
+        if max(m) <= 2:
+            poly, mult = f0, m
+        elif m[0] >= 3:
+            poly, mult = f[0], (m[0] - 3, m[1], m[2])
+        elif m[1] >= 3:
+            poly, mult = f[1], (m[0], m[1] - 3, m[2])
+        else:
+            poly, mult = f[2], (m[0], m[1], m[2] - 3)
+        for k, v in pmul({mult: 1.0}, poly).items():
+            Mm[pos[m], pos[k]] = v
+    A, B, C, Dm = Mm[:27, :27], Mm[:27, 27:], Mm[27:, :27], Mm[27:, 27:]
+    return A - B @ np.linalg.solve(Dm, C), np.linalg.cond(Dm)
+
+
+def quat_R(s):
+    q = np.array([1.0, s[0], s[1], s[2]]); q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def dls_pnp(X, uv, u, eps=1e-6):
+    """All cheirality-valid real solutions [(R, t)], plus diagnostics."""
+    T, f = dls_cubics(X, uv)
+    S, cond = action_matrix(f, u)
+    w, V = np.linalg.eig(S)
+    sols, roots = [], []
+    for i in range(27):
+        v = V[:, i] / V[0, i]
+        s = np.array([v[9], v[3], v[1]])
+        if np.all(np.abs(s.imag) < eps) and np.all(np.isfinite(s)):
+            s = s.real
+            roots.append(s)
+            R = quat_R(s)
+            t = T @ R.reshape(9)
+            if np.all((X @ R.T + t)[:, 2] >= 0):
+                sols.append((R, t))
+    return sols, dict(S=S, cond=cond, eigvals=w, roots=roots, f=f, T=T)
+
+
+# ------------------------------------------------------------------ synthetic PnP scene
+def make_scene(N=512, outlier_frac=0.3, noise_px=0.5, seed=4242, focal=458.0):
+    rng = np.random.default_rng(seed)
+    yaw = np.deg2rad(rng.uniform(-30, 30)); pitch = np.deg2rad(rng.uniform(-5, 5)); roll = np.deg2rad(rng.uniform(-5, 5))
+    cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+    R = Ry @ Rx @ Rz
+    t = rng.standard_normal(3); t *= rng.uniform(0, 1) / np.linalg.norm(t)
+    # points in the frustum of camera b, depth 0.5..20 m, expressed in frame a, rounded to float32 (CV_32FC3)
+    depth = rng.uniform(0.5, 20.0, N)
+    uvb = np.stack([rng.uniform(-0.8, 0.8, N), rng.uniform(-0.5, 0.5, N)], axis=1)
+    Xb = np.concatenate([uvb * depth[:, None], depth[:, None]], axis=1)
+    Xa = ((Xb - t) @ R).astype(np.float32).astype(np.float64)           # X_a = R^T (X_b - t)
+    proj = Xa @ R.T + t
+    uv = proj[:, :2] / proj[:, 2:3] + rng.standard_normal((N, 2)) * (noise_px / focal)
+    out = rng.random(N) < outlier_frac
+    uv[out] = np.stack([rng.uniform(-0.8, 0.8, out.sum()), rng.uniform(-0.5, 0.5, out.sum())], axis=1)
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    return Xa, uv, T, ~out

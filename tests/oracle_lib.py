@@ -146,3 +146,123 @@ def ref_scan_f64_colmajor(M: np.ndarray, k: int, v, vm, vmm):
     maxv = np.empty(3); arg = np.empty(3, dtype=np.int64)
     load().orc_ref_scan_f64_colmajor(_p(M), D, k, _p(v), _p(vm), _p(vmm), _p(u), _p(um), _p(umm), _p(maxv), _p(arg))
     return maxv, arg, (u, um, umm)
+
+
+# ================================================================== PnP / RANSAC oracle bindings
+class OrcRansacParams(C.Structure):
+    _fields_ = [("error_thresh", C.c_double), ("min_inlier_ratio", C.c_double), ("max_iterations", C.c_int32),
+                ("min_iterations", C.c_int32), ("use_mle", C.c_int32), ("sample_size", C.c_int32),
+                ("failure_probability", C.c_double), ("seed", C.c_uint64), ("n_hypotheses", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class OrcRansacSummary(C.Structure):
+    _fields_ = [("n_iterations", C.c_int32), ("n_inliers", C.c_int32), ("best_hypothesis", C.c_int32),
+                ("n_models", C.c_int32), ("best_cost", C.c_double)]
+
+
+def _bind_pnp():
+    lib = load()
+    if getattr(lib, "_pnp_bound", False):
+        return lib
+    V = C.c_void_p
+    lib.orc_rng_draw.restype = C.c_uint64
+    lib.orc_rng_draw.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+    lib.orc_ransac_sample.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, V]
+    lib.orc_dls_linear_form.argtypes = [C.c_uint64, C.c_int32, V]
+    lib.orc_reproj_error.restype = C.c_double
+    lib.orc_reproj_error.argtypes = [V, V, V]
+    lib.orc_score_model.argtypes = [V, V, V, C.c_int32, C.c_double, C.c_int32, V, V, V]
+    lib.orc_dls_monomial_positions.argtypes = [V]
+    lib.orc_dls_cubics.argtypes = [V, V, C.c_int32, V, V]
+    lib.orc_dls_action_matrix.restype = C.c_int
+    lib.orc_dls_action_matrix.argtypes = [V, V, V]
+    lib.orc_eig27_real.restype = C.c_int
+    lib.orc_eig27_real.argtypes = [V, V, V]
+    lib.orc_dls_pnp.restype = C.c_int
+    lib.orc_dls_pnp.argtypes = [V, V, C.c_int32, V, V, V, C.c_int32]
+    lib.orc_pnp_hypothesis.restype = C.c_int
+    lib.orc_pnp_hypothesis.argtypes = [V, V, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, V, V]
+    lib.orc_ransac_params_default.argtypes = [C.POINTER(OrcRansacParams)]
+    lib.orc_ransac_max_iterations.restype = C.c_int32
+    lib.orc_ransac_max_iterations.argtypes = [C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_int32]
+    lib.orc_pnp_ransac.restype = C.c_int
+    lib.orc_pnp_ransac.argtypes = [V, V, C.c_int32, C.POINTER(OrcRansacParams), V, C.POINTER(C.c_float), V,
+                                   C.POINTER(OrcRansacSummary)]
+    lib._pnp_bound = True
+    return lib
+
+
+def ransac_params(**kw) -> OrcRansacParams:
+    p = OrcRansacParams()
+    _bind_pnp().orc_ransac_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def ransac_sample(seed, hyp, N, S=15):
+    out = np.empty(S, dtype=np.int32)
+    _bind_pnp().orc_ransac_sample(seed, hyp, N, S, _p(out))
+    return out
+
+
+def dls_linear_form(seed, hyp):
+    u = np.empty(4)
+    _bind_pnp().orc_dls_linear_form(seed, hyp, _p(u))
+    return u
+
+
+def dls_cubics(X, uv):
+    X = np.ascontiguousarray(X, dtype=np.float64); uv = np.ascontiguousarray(uv, dtype=np.float64)
+    T = np.empty(27); f = np.empty((3, 20))
+    _bind_pnp().orc_dls_cubics(_p(X), _p(uv), X.shape[0], _p(T), _p(f))
+    return T.reshape(3, 9), f
+
+
+def dls_action_matrix(f, u):
+    f = np.ascontiguousarray(f, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+    S = np.empty((27, 27))
+    rc = _bind_pnp().orc_dls_action_matrix(_p(f), _p(u), _p(S))
+    return rc, S
+
+
+def eig27_real(S):
+    S = np.ascontiguousarray(S, dtype=np.float64)
+    lam = np.empty(27); v4 = np.empty((27, 4))
+    n = _bind_pnp().orc_eig27_real(_p(S), _p(lam), _p(v4))
+    return n, lam[:max(n, 0)], v4[:max(n, 0)]
+
+
+def dls_pnp(X, uv, u, max_out=8):
+    X = np.ascontiguousarray(X, dtype=np.float64); uv = np.ascontiguousarray(uv, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    Rs = np.empty((max_out, 3, 3)); ts = np.empty((max_out, 3))
+    n = _bind_pnp().orc_dls_pnp(_p(X), _p(uv), X.shape[0], _p(u), _p(Rs), _p(ts), max_out)
+    return n, Rs[:max(0, min(n, max_out))], ts[:max(0, min(n, max_out))]
+
+
+def pnp_hypothesis(X, uv, seed, hyp, S=15):
+    X = np.ascontiguousarray(X, dtype=np.float64); uv = np.ascontiguousarray(uv, dtype=np.float64)
+    T = np.empty(16); smp = np.empty(S, dtype=np.int32)
+    ok = _bind_pnp().orc_pnp_hypothesis(_p(X), _p(uv), X.shape[0], seed, hyp, S, _p(T), _p(smp))
+    return ok, T.reshape(4, 4).T.copy(), smp
+
+
+def score_model(T, X, uv, thresh=0.03, use_mle=1):
+    X = np.ascontiguousarray(X, dtype=np.float64); uv = np.ascontiguousarray(uv, dtype=np.float64)
+    Tc = np.ascontiguousarray(np.asarray(T, dtype=np.float64).T.reshape(16))  # column-major
+    cost = C.c_double(); nin = C.c_int32(); mask = np.zeros(X.shape[0], dtype=np.uint8)
+    _bind_pnp().orc_score_model(_p(Tc), _p(X), _p(uv), X.shape[0], thresh, use_mle, C.byref(cost), C.byref(nin), _p(mask))
+    return cost.value, nin.value, mask
+
+
+def pnp_ransac(X, uv, params: OrcRansacParams | None = None):
+    X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 3)
+    uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
+    p = params or ransac_params()
+    T = np.empty(16); conf = C.c_float(); mask = np.zeros(max(1, X.shape[0]), dtype=np.uint8); s = OrcRansacSummary()
+    rc = _bind_pnp().orc_pnp_ransac(_p(X), _p(uv), X.shape[0], C.byref(p), _p(T), C.byref(conf), _p(mask), C.byref(s))
+    return dict(status=rc, confidence=float(conf.value), T=T.reshape(4, 4).T.copy(), mask=mask[:X.shape[0]].copy(),
+                summary=dict(n_iterations=s.n_iterations, n_inliers=s.n_inliers, best_hypothesis=s.best_hypothesis,
+                             n_models=s.n_models, best_cost=s.best_cost))
