@@ -1,0 +1,111 @@
+"""GPU parity tests of the DLS-PnP-in-RANSAC path: HIP kernels (through chip_pnp_ransac) vs the CPU oracle on
+identical inputs and seeds.  Bar (BASELINE north_star): inlier masks bit-exact, poses within 1e-4 relative
+Frobenius; in practice the kernels reproduce the oracle's operation order, so poses are compared bit for bit too."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import np_mirror_pnp as M
+import oracle_lib as O
+from cerebro_amd import capi
+
+pytestmark = pytest.mark.gpu
+GOLD = Path(__file__).parent / "golden"
+
+
+def rel_frob(A, B):
+    return np.linalg.norm(A - B) / np.linalg.norm(B)
+
+
+def gparams(**kw):
+    p = capi.default_ransac_params()
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def check_against_oracle(chip, X, uv, **kw):
+    o = O.pnp_ransac(X, uv, O.ransac_params(**kw))
+    g = chip.pnp_ransac(X, uv, gparams(**kw))
+    assert g["status"] == 0 and o["status"] == 0
+    assert g["summary"]["best_hypothesis"] == o["summary"]["best_hypothesis"], (g["summary"], o["summary"])
+    assert g["summary"]["n_iterations"] == o["summary"]["n_iterations"]
+    assert g["summary"]["n_models"] == o["summary"]["n_models"]
+    assert g["summary"]["n_inliers"] == o["summary"]["n_inliers"]
+    assert np.array_equal(g["mask"], o["mask"])                                   # inlier mask bit-exact
+    if o["summary"]["best_hypothesis"] >= 0:
+        assert rel_frob(g["T"], o["T"]) <= 1e-4                                    # north_star tolerance
+        assert np.array_equal(g["T"].view(np.uint64), o["T"].view(np.uint64))     # and in fact bit-identical
+        assert float(g["summary"]["best_cost"]).hex() == float(o["summary"]["best_cost"]).hex()
+        assert g["confidence"] == o["confidence"]
+    else:
+        assert np.isnan(g["T"]).all() and g["confidence"] == 0.0 and g["mask"].sum() == 0
+    return g, o
+
+
+def test_golden_fixture_through_c_abi():
+    g = json.loads((GOLD / "pnp_golden.json").read_text())
+    X = np.array(g["X"]); uv = np.array(g["uv"])
+    with capi.Chip(256) as chip:
+        for case in g["cases"]:
+            r = chip.pnp_ransac(X, uv, gparams(n_hypotheses=case["n_hypotheses"], seed=case["seed"]))
+            assert r["summary"]["best_hypothesis"] == case["best_hypothesis"]
+            assert r["summary"]["n_iterations"] == case["n_iterations"]
+            assert r["summary"]["n_models"] == case["n_models"]
+            assert np.packbits(r["mask"]).tobytes().hex() == case["mask_hex"]
+            Tg = np.array([float.fromhex(x) for x in case["T_colmajor_hex"]]).reshape(4, 4).T
+            assert rel_frob(r["T"], Tg) <= 1e-4
+            assert [float(x).hex() for x in r["T"].T.reshape(16)] == case["T_colmajor_hex"]
+
+
+@pytest.mark.parametrize("N,outl,noise,seed", [(20, 0.0, 0.0, 1), (64, 0.1, 0.3, 2), (100, 0.3, 0.5, 3), (512, 0.3, 0.5, 4242),
+                                                (777, 0.5, 1.0, 5), (3000, 0.2, 0.5, 6)])
+def test_random_scenes_both_modes(N, outl, noise, seed):
+    X, uv, T, inl = M.make_scene(N=N, outlier_frac=outl, noise_px=noise, seed=seed)
+    with capi.Chip(256) as chip:
+        check_against_oracle(chip, X, uv, seed=seed)                              # reference-faithful adaptive mode
+        check_against_oracle(chip, X, uv, seed=seed + 100, n_hypotheses=200)      # benchmark mode
+        check_against_oracle(chip, X, uv, seed=seed, use_mle=0, n_hypotheses=64)  # inlier-count quality measure
+
+
+def test_config3_512_correspondences_1000_hypotheses():
+    """BASELINE config 3: 512-correspondence DlsPnpWithRansac, 1k hypotheses."""
+    X, uv, T, inl = M.make_scene(N=512, outlier_frac=0.3, noise_px=0.5, seed=4242)
+    with capi.Chip(256) as chip:
+        g, o = check_against_oracle(chip, X, uv, seed=4242, n_hypotheses=1000)
+        assert g["summary"]["n_models"] > 100
+        assert rel_frob(g["T"][:3, :3], T[:3, :3]) < 0.02                          # and it is the right pose
+        assert (g["mask"].astype(bool) & inl).sum() > 0.9 * inl.sum()
+
+
+def test_role_swap_like_the_caller():
+    """Cerebro.cpp:1518,1572: PNP(a->b) and PNP(b->a) on the same match set; op2 is inverted by the caller (:1582)."""
+    X, uv, T, inl = M.make_scene(N=400, outlier_frac=0.1, noise_px=0.3, seed=9)
+    Xb = (X @ T[:3, :3].T + T[:3, 3]).astype(np.float32).astype(np.float64)
+    uva = X[:, :2] / X[:, 2:3]
+    with capi.Chip(256) as chip:
+        g1, _ = check_against_oracle(chip, X, uv, seed=1, n_hypotheses=100)
+        g2, _ = check_against_oracle(chip, Xb, uva, seed=2, n_hypotheses=100)
+        assert rel_frob(np.linalg.inv(g2["T"])[:3, :3], g1["T"][:3, :3]) < 0.05
+
+
+def test_edge_cases():
+    X, uv, T, inl = M.make_scene(N=64, outlier_frac=0.0, noise_px=0.0, seed=1)
+    with capi.Chip(256) as chip:
+        r = chip.pnp_ransac(X[:19], uv[:19])
+        assert r["status"] == capi.CHIP_ERR_TOO_FEW_POINTS and r["confidence"] == -1.0   # DlsPnpWithRansac.cpp:136-139
+        check_against_oracle(chip, X[:20], uv[:20], seed=3)
+        rng = np.random.default_rng(0)
+        Xg = rng.uniform(-1, 1, (40, 3)); Xg[:, 2] = -np.abs(Xg[:, 2]) - 1.0
+        check_against_oracle(chip, Xg, rng.uniform(-1, 1, (40, 2)), n_hypotheses=20)
+        # degenerate: all points identical -> singular systems everywhere, must not hang or crash
+        Xd = np.tile(X[:1], (30, 1)); uvd = np.tile(uv[:1], (30, 1))
+        g = chip.pnp_ransac(Xd, uvd, gparams(n_hypotheses=16))
+        o = O.pnp_ransac(Xd, uvd, O.ransac_params(n_hypotheses=16))
+        assert g["summary"]["best_hypothesis"] == o["summary"]["best_hypothesis"]
+        p = gparams(sample_size=17)
+        st = chip.lib.chip_pnp_ransac(chip.h, X.ctypes.data, uv.ctypes.data, 64, p, np.empty(16).ctypes.data,
+                                      capi.C.byref(capi.C.c_float()), None, None)
+        assert st == capi.CHIP_ERR_UNSUPPORTED
