@@ -15,9 +15,10 @@ HIP_SRCS   := $(CSRC)/kernels.hip $(CSRC)/chip_api.hip $(CSRC)/pnp.hip
 HIP_OBJS   := $(HIP_SRCS:$(CSRC)/%.hip=$(LIBDIR)/%.o)
 ORC_SRCS   := $(wildcard oracle/*.c)
 
-all: lib oracle
+all: lib oracle host
 lib: $(LIBDIR)/libcerebro_hip.so
 oracle: oracle/_build/liboracle.so
+host: $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay
 
 $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/chip_internal.h include/cerebro_hip.h
 	@mkdir -p $(LIBDIR)
@@ -26,6 +27,15 @@ $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/chip_internal.h include/cerebro_hip.h
 $(LIBDIR)/libcerebro_hip.so: $(HIP_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@
 
+# ---- ROS-free C++ host side (mirror of the Cerebro / StaticTheiaPoseCompute::PNP surface) + replay harness ----
+HOSTDIR    := cerebro_amd/host
+CXX        ?= g++
+$(LIBDIR)/libcerebro_host.so: $(HOSTDIR)/cerebro_host.cc $(HOSTDIR)/cerebro_host.h include/cerebro_hip.h $(LIBDIR)/libcerebro_hip.so
+	$(CXX) -O2 -std=c++17 -fPIC -shared -Wall -Wextra $(HOSTDIR)/cerebro_host.cc -o $@ -L$(LIBDIR) -lcerebro_hip -Wl,-rpath,'$$ORIGIN' -lpthread
+
+$(LIBDIR)/cerebro_replay: $(HOSTDIR)/cerebro_replay.cc $(LIBDIR)/libcerebro_host.so
+	$(CXX) -O2 -std=c++17 -Wall -Wextra $(HOSTDIR)/cerebro_replay.cc -o $@ -L$(LIBDIR) -lcerebro_host -lcerebro_hip -Wl,-rpath,'$$ORIGIN' -lpthread
+
 oracle/_build/liboracle.so: $(ORC_SRCS) oracle/cerebro_oracle.h
 	@mkdir -p oracle/_build
 	$(CC) $(ORCFLAGS) -shared $(ORC_SRCS) -o $@ -lm
@@ -33,4 +43,4 @@ oracle/_build/liboracle.so: $(ORC_SRCS) oracle/cerebro_oracle.h
 clean:
 	rm -rf $(LIBDIR) oracle/_build
 
-.PHONY: all lib oracle clean
+.PHONY: all lib oracle host clean

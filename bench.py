@@ -74,6 +74,51 @@ def cpu_baseline(sample_cols: int, budget_s: float):
     return cols_per_s, n, dt
 
 
+def pnp_leg(chip, cpu_budget_s: float):
+    """BASELINE config 3: 512 correspondences x 1000 hypotheses of 15 samples (DlsPnpWithRansac), whole call through
+    chip_pnp_ransac (includes the 20 KB H2D of the correspondences and the host-side K7 selection)."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import np_mirror_pnp as M   # scene generator only
+    from cerebro_amd import capi
+    X, uv, T, inl = M.make_scene(N=512, outlier_frac=0.3, noise_px=0.5, seed=4242)
+    p = capi.default_ransac_params()
+    p.n_hypotheses = 1000
+    p.seed = 4242
+    for _ in range(3):
+        r = chip.pnp_ransac(X, uv, p)
+    reps = 50
+    t0 = time.perf_counter()
+    for i in range(reps):
+        p.seed = 4242 + i
+        r = chip.pnp_ransac(X, uv, p)
+    dt = time.perf_counter() - t0
+    p.n_hypotheses = 0
+    t1 = time.perf_counter()
+    for i in range(reps):
+        p.seed = 99 + i
+        chip.pnp_ransac(X, uv, p)
+    dt_ref = time.perf_counter() - t1
+    out = {"metric": "PnP-RANSAC hypotheses/sec (512 correspondences, 1000 hypotheses of 15 samples, DLS + L1 reprojection scoring)",
+           "value": reps * 1000 / dt, "unit": "hypotheses/s", "ms_per_call_1000_hyp": 1e3 * dt / reps,
+           "reference_mode_ms_per_call": 1e3 * dt_ref / reps, "reference_mode": "<=50 iterations, theia early termination",
+           "dtype": "f64", "n_models_last": r["summary"]["n_models"],
+           "roofline": {"bound": "latency (fp64 VALU + LDS); neither HBM nor MFMA", "flops_per_hypothesis_est": 1.3e6,
+                        "achieved_gflops_est": reps * 1000 * 1.3e6 / dt / 1e9, "note": "see DESIGN.md 5"}}
+    if cpu_budget_s > 0:
+        import oracle_lib
+        n = 0
+        t2 = time.perf_counter()
+        while True:
+            oracle_lib.pnp_ransac(X, uv, oracle_lib.ransac_params(n_hypotheses=1000, seed=4242 + n))
+            n += 1
+            d = time.perf_counter() - t2
+            if d > cpu_budget_s or n >= 20:
+                break
+        out["cpu_baseline"] = {"value": n * 1000 / d, "unit": "hypotheses/s", "cores": 1, "kind": "port",
+                               "sample": f"{n} oracle calls of 1000 hypotheses ({d:.1f} s), single thread"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +128,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="columns in the CPU baseline sample")
     ap.add_argument("--inflight", type=int, default=16)
+    ap.add_argument("--no-pnp", action="store_true", help="skip the auxiliary PnP-RANSAC leg (config 3)")
     args = ap.parse_args()
 
     import torch
@@ -137,18 +183,15 @@ def main():
                 out.append(chip.loop_tick_collect(pending.pop(0)))
             return out
     else:
-        stream = torch.cuda.current_stream()
-        chip.set_stream(stream.cuda_stream)
-        local = torch.zeros((3, TOPK, 2), dtype=torch.float64, device="cuda")
-        gathered = torch.zeros((world, 3, TOPK, 2), dtype=torch.float64, device="cuda")
+        from cerebro_amd.sharded import ShardedLoopDetector
+        det = ShardedLoopDetector(chip, topk=TOPK, device=torch.device("cuda", local_rank))
 
         def run(tick_ls):
             out = []
             for l in tick_ls:
-                st = chip.scan_local(l, local.data_ptr(), TOPK, params)
-                assert st == capi.CHIP_TICK_SCANNED
-                dist.all_gather_into_tensor(gathered, local)        # RCCL over xGMI: 384 B per rank
-                out.append(chip.merge_decide(l, gathered.data_ptr(), world, TOPK, params))
+                r = det.tick(l, params)        # scan_local -> RCCL all-gather (384 B/rank over xGMI) -> merge_decide
+                assert r.status == capi.CHIP_TICK_SCANNED
+                out.append(r)
             return out
 
     chip.loop_reset()
@@ -190,7 +233,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "loop-queries/sec (ticks of 3 descriptors vs 4096-D x 1M DB)",
+            "metric": "loop-queries/sec (ticks of 3 descriptors vs 4096-D x 1M DB) [+ PnP-RANSAC hypotheses/sec in \"pnp\"]",
             "value": args.steps / elapsed,
             "unit": "ticks/s",
             "n_gpus": world,
@@ -212,6 +255,8 @@ def main():
                          "kernel": "db_scan_topk", "avg_kernel_ms": avg_s * 1e3, "launches": n_launch,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if world == 1 and not args.no_pnp:
+            out["pnp"] = pnp_leg(chip, min(args.cpu_budget, 5.0))
         if world == 1 and args.cpu_budget > 0:
             cols_per_s, n, dt = cpu_baseline(args.cpu_sample, args.cpu_budget)
             out["cpu_baseline"] = {"value": cols_per_s / args.rows, "unit": "ticks/s", "cores": 1, "kind": "port",

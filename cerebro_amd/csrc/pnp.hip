@@ -2,7 +2,7 @@
 // /root/reference/src/DlsPnpWithRansac.cpp:192-240, i.e. theia::Ransac over the DlsPnpWithRansac estimator of
 // src/DlsPnpWithRansac.h:42-100).  All hypotheses of a call are generated and scored in parallel:
 //
-//   K4+K5a  pnp_build_solve   one 256-thread workgroup per hypothesis (LDS ~90 KB): counter-based sampler,
+//   K4+K5a  pnp_build_solve   one 512-thread workgroup per hypothesis (LDS ~90 KB): counter-based sampler,
 //                             DLS cost matrix -> three Cayley cubics -> degree-7 Macaulay matrix [D|C] (93x120) in LDS
 //                             -> LU with partial pivoting (wave-0 DPP max + ballot pivot search, 2 barriers per step)
 //                             -> 27x27 action matrix S = A - B D^-1 C.
@@ -155,7 +155,9 @@ struct SolveArgs {
     int32_t *ok;        // [H] 1 = S valid, 0 = singular D
 };
 
-__global__ __launch_bounds__(256) void pnp_build_solve(SolveArgs a)
+constexpr int kSolveThreads = 512;
+
+__global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *E = reinterpret_cast<double *>(smem);                 // [93][kLD]
@@ -174,8 +176,9 @@ __global__ __launch_bounds__(256) void pnp_build_solve(SolveArgs a)
     double *fc = sm;            sm += 60;                         // f[3][20]
     double *uu = sm;            sm += 4;
     double *Xb = sm;            sm += 27 * 27;                    // X[66+t][c]
-    int *perm = reinterpret_cast<int *>(sm);                      // [93] logical -> physical row of E
-    int *smp = perm + 96;                                          // [16]
+    double *Lcol = sm;          sm += 96;                         // multipliers of the current elimination step
+    double *prow_buf = sm;      sm += 128;                        // copy of the pivot row (broadcast operand of the update)
+    int *smp = reinterpret_cast<int *>(sm);                       // [16]
     int *fy_key = smp + 16;                                        // sparse Fisher-Yates map (<= 32 entries)
     int *fy_val = fy_key + 32;
     int *flag = fy_val + 32;                                       // [2] : singular, spare
@@ -315,50 +318,64 @@ __global__ __launch_bounds__(256) void pnp_build_solve(SolveArgs a)
         fc[tid] = (double)tb.fmul[k][mth] * c4[tb.fsrc[k][mth]];
     }
     // ---- Macaulay [D | C] ----
-    for (int e = tid; e < kNR * kLD; e += 256) E[e] = 0.0;
-    if (tid < kNR) perm[tid] = tid;
+    for (int e = tid; e < kNR * kLD; e += kSolveThreads) E[e] = 0.0;
     __syncthreads();
-    for (int e = tid; e < kNR * 20; e += 256) {
+    for (int e = tid; e < kNR * 20; e += kSolveThreads) {
         const int row = e / 20, term = e % 20;
         E[row * kLD + tb.row_dst[row][term]] = fc[20 * tb.row_which[row] + term];
     }
     __syncthreads();
 
-    // ---- LU with partial pivoting on the logical rows perm[] (no physical swaps) ----
+    // ---- LU with partial (row) pivoting.  Per step: wave 0 finds the pivot (DPP max + ballot = first row attaining the
+    //      max), swaps it into row k, copies it to prow_buf and writes the multipliers; then all threads update. ----
     for (int k = 0; k < kNR; k++) {
         if (wave == 0) {
-            // pivot = first row (smallest logical index) attaining max |E[i][k]|, i >= k
             const int i0 = k + lane, i1 = k + 64 + lane;
-            const int p0 = i0 < kNR ? perm[i0] : -1, p1 = i1 < kNR ? perm[i1] : -1;
-            const double e0 = p0 >= 0 ? E[p0 * kLD + k] : 0.0, e1 = p1 >= 0 ? E[p1 * kLD + k] : 0.0;
-            const double v0 = p0 >= 0 ? fabs(e0) : -1.0, v1 = p1 >= 0 ? fabs(e1) : -1.0;
+            const double e0 = i0 < kNR ? E[i0 * kLD + k] : 0.0, e1 = i1 < kNR ? E[i1 * kLD + k] : 0.0;
+            const double v0 = i0 < kNR ? fabs(e0) : -1.0, v1 = i1 < kNR ? fabs(e1) : -1.0;
             double vm = v0 > v1 ? v0 : v1;
             if (!(vm >= 0.0)) vm = 0.0;           // NaN / empty lanes do not take part (NaN never wins in the oracle either)
             const double best = wave_max_nonneg(vm);
             const unsigned long long b0 = __ballot(v0 == best), b1 = __ballot(v1 == best);
-            const int prow = b0 ? k + __builtin_ctzll(b0) : k + 64 + __builtin_ctzll(b1 ? b1 : 1ull);
             const bool singular = !(best > 0.0) || (b0 == 0 && b1 == 0);
             if (singular) { if (lane == 0) flag[0] = 1; }
             else {
-                const int pk = perm[k], pp = perm[prow];   // physical rows (pre-swap)
-                const double piv = E[pp * kLD + k];
-                // multipliers of the logical rows i > k after the swap: row prow now holds the old row k
-                if (i0 > k && p0 >= 0) { const int ph = (i0 == prow) ? pk : p0; const double l = E[ph * kLD + k] / piv; E[ph * kLD + k] = l; }
-                if (p1 >= 0) { const int ph = (i1 == prow) ? pk : p1; const double l = E[ph * kLD + k] / piv; E[ph * kLD + k] = l; }
-                if (lane == 0) { perm[k] = pp; perm[prow] = pk; }
+                const int prow = b0 ? k + __builtin_ctzll(b0) : k + 64 + __builtin_ctzll(b1);
+                const int src_lane = (prow - k) & 63;
+                const double piv = __shfl(prow - k >= 64 ? e1 : e0, src_lane, 64);   // E[prow][k]
+                const double ek = __shfl(e0, 0, 64);                                  // E[k][k] (moves to row prow)
+                // multipliers of rows i > k AFTER the swap (row prow then holds the old row k)
+                if (i0 > k && i0 < kNR) Lcol[i0] = (i0 == prow ? ek : e0) / piv;
+                if (i1 < kNR) Lcol[i1] = (i1 == prow ? ek : e1) / piv;
+                // swap rows k <-> prow on columns k..119 and publish the pivot row
+                for (int j = k + lane; j < kNC; j += 64) {
+                    const double aold = E[k * kLD + j], bnew = E[prow * kLD + j];
+                    prow_buf[j] = bnew;
+                    E[k * kLD + j] = bnew;
+                    E[prow * kLD + j] = aold;
+                }
             }
         }
         __syncthreads();
         if (flag[0]) break;
         {
-            const int tx = tid & 127, ty = tid >> 7;
+            const int tx = tid & 127, ty = tid >> 7;   // column lane, row phase (kSolveThreads / 128 phases)
             const int j = k + 1 + tx;
             if (j < kNC) {
-                const double ukj = E[perm[k] * kLD + j];
-                for (int i = k + 1 + ty; i < kNR; i += 2) {
-                    const int ph = perm[i];
-                    const double l = E[ph * kLD + k];
-                    if (l != 0.0) E[ph * kLD + j] = E[ph * kLD + j] - l * ukj;
+                constexpr int NTY = kSolveThreads / 128, UNR = 6;
+                const double ukj = prow_buf[j];
+                for (int ib = k + 1 + ty; ib < kNR; ib += NTY * UNR) {
+                    double ev[UNR], lv[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; u++) {   // batched, mutually independent LDS loads
+                        const int i = ib + u * NTY;
+                        if (i < kNR) { ev[u] = E[i * kLD + j]; lv[u] = Lcol[i]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNR; u++) {
+                        const int i = ib + u * NTY;
+                        if (i < kNR && lv[u] != 0.0) E[i * kLD + j] = ev[u] - lv[u] * ukj;
+                    }
                 }
             }
         }
@@ -372,15 +389,14 @@ __global__ __launch_bounds__(256) void pnp_build_solve(SolveArgs a)
     if (tid < 27) {
         const int c = tid;
         for (int i = kNR - 1; i >= kNR - 27; i--) {
-            const int ph = perm[i];
-            double s = E[ph * kLD + 93 + c];
-            for (int j = i + 1; j < kNR; j++) s = s - E[ph * kLD + j] * Xb[(j - 66) * 27 + c];
-            Xb[(i - 66) * 27 + c] = s / E[ph * kLD + i];
+            double s = E[i * kLD + 93 + c];
+            for (int j = i + 1; j < kNR; j++) s = s - E[i * kLD + j] * Xb[(j - 66) * 27 + c];
+            Xb[(i - 66) * 27 + c] = s / E[i * kLD + i];
         }
     }
     __syncthreads();
     // ---- S = A - B X ----
-    for (int e = tid; e < 729; e += 256) {
+    for (int e = tid; e < 729; e += kSolveThreads) {
         const int r = e / 27, j = e % 27;
         double s = 0.0;
         for (int t = 0; t < 4; t++)
@@ -803,7 +819,7 @@ int pnp_create(Ctx *c)
     build_tables(t);
     CHIP_HIP(c, hipMalloc(&st->tab_dev, sizeof(PnpTables)));
     CHIP_HIP(c, hipMemcpy(st->tab_dev, &t, sizeof t, hipMemcpyHostToDevice));
-    CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(pnp_build_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(pnp_build_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 102 * 1024));
     return CHIP_OK;
 }
 
@@ -913,8 +929,8 @@ extern "C" int chip_pnp_ransac(chip_ctx *c, const double *X, const double *uv, i
     SolveArgs sa;
     sa.X = st->X; sa.uv = st->uv; sa.N = N; sa.S = S; sa.seed = p->seed; sa.tab = st->tab_dev;
     sa.Sg = st->Sg; sa.Tg = st->Tg; sa.sample = st->sample; sa.ok = st->ok;
-    const size_t lds = sizeof(double) * (kNR * kLD + kSampleMax * 8 + 9 + 9 + 27 + 27 + 81 + 90 + 100 + 36 + 60 + 4 + 27 * 27) + sizeof(int) * (96 + 16 + 32 + 32 + 2);
-    hipLaunchKernelGGL(pnp_build_solve, dim3(H), dim3(256), lds, s, sa);
+    const size_t lds = sizeof(double) * (kNR * kLD + kSampleMax * 8 + 9 + 9 + 27 + 27 + 81 + 90 + 100 + 36 + 60 + 4 + 27 * 27 + 96 + 128) + sizeof(int) * (16 + 32 + 32 + 2);
+    hipLaunchKernelGGL(pnp_build_solve, dim3(H), dim3(kSolveThreads), lds, s, sa);
     CHIP_HIP(c, hipGetLastError());
 
     EigArgs ea;

@@ -1,0 +1,103 @@
+// cerebro_host.h -- ROS-free C++ host side above the C ABI (include/cerebro_hip.h).
+//
+// Mirrors, name for name, the part of the reference's `class Cerebro` that touches the hot path
+// (/root/reference/src/Cerebro.h:89-174) and `StaticTheiaPoseCompute::PNP`
+// (/root/reference/src/DlsPnpWithRansac.h:175-177), so that the reference's call sites keep reading the same:
+//   wholeImageComputedList_size/_at   Cerebro.h:105-106, Cerebro.cpp:309-326
+//   foundLoops_count/_i/_as_JSON      Cerebro.h:152-154, Cerebro.cpp:1113-1164
+//   descrip_N__dot__descrip_0_N       Cerebro.cpp:903-1103  (run() :350-357 calls it)
+// ros::Time is replaced by the POD `Time`; Eigen types by plain arrays (column-major Matrix4d layout).
+// Nothing here computes: every dot product, top-k, accept decision and PnP hypothesis runs in libcerebro_hip.so.
+#pragma once
+#include <array>
+#include <atomic>
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/cerebro_hip.h"
+
+namespace cerebro_hip {
+
+struct Time {  // ros::Time
+    uint32_t sec = 0, nsec = 0;
+    double toSec() const { return (double)sec + 1e-9 * (double)nsec; }
+    bool operator==(const Time &o) const { return sec == o.sec && nsec == o.nsec; }
+};
+
+// POD mirror of cerebro/LoopEdge (msg/LoopEdge.msg:1-5); quaternion as geometry_msgs/Pose (x,y,z,w)
+struct LoopEdgePOD {
+    Time timestamp0, timestamp1;
+    double position[3];
+    double orientation_xyzw[4];
+    float weight;
+    std::string description;
+};
+
+class Cerebro {
+public:
+    // descriptor_size: learnt by the reference from a zero-image service call (Cerebro.cpp:75-120)
+    explicit Cerebro(int descriptor_size, int device = 0, int64_t capacity_hint = 29000 /* Cerebro.cpp:946 */);
+    ~Cerebro();
+    Cerebro(const Cerebro &) = delete;
+    Cerebro &operator=(const Cerebro &) = delete;
+    bool ok() const { return ctx_ != nullptr; }
+    int last_status() const { return status_; }
+    chip_ctx *ctx() { return ctx_; }
+
+    // ---- producer side (desc_th): Cerebro.cpp:268-275 = setWholeImageDescriptor + wholeImageComputedList_pushback
+    bool descriptor_available(const Time &stamp, const double *desc, int n);
+
+    // ---- thread-safe accessors (Cerebro.h:105-106)
+    int wholeImageComputedList_size() const;
+    Time wholeImageComputedList_at(int k) const;
+
+    // ---- consumer side (dot_product_th)
+    // One iteration of the while-loop body of descrip_N__dot__descrip_0_N (Cerebro.cpp:956-1100) for the current
+    // l = wholeImageComputedList_size() (or an explicit l when replaying a recorded schedule).  Returns true iff a
+    // loop candidate was pushed to foundLoops.
+    bool descrip_N__dot__descrip_0_N_once(int64_t l = -1, chip_tick_result *detail = nullptr);
+    // The thread main (Cerebro.cpp:350-357): polls at `rate_hz` until run_thread_disable().
+    void run(double rate_hz = 10.0);
+    void run_thread_enable() { b_run_thread = true; }
+    void run_thread_disable() { b_run_thread = false; }
+
+    // ---- foundLoops (Cerebro.h:152-158)
+    int foundLoops_count() const;
+    std::tuple<Time, Time, double> foundLoops_i(int i) const;
+    // Same keys as Cerebro.cpp:1149-1159; global_a/global_b are indices into wholeImageComputedList here (the
+    // reference reports the index into DataManager's data_map, which is out of scope).
+    std::string foundLoops_as_JSON() const;
+
+    chip_dot_params params;  // LOCALITY_THRESH / DOT_PROD_THRESH / lag  (Cerebro.cpp:912-914)
+
+private:
+    chip_ctx *ctx_ = nullptr;
+    int status_ = 0;
+    int D_ = 0;
+    mutable std::mutex m_wholeImageComputedList;
+    std::vector<Time> wholeImageComputedList;
+    mutable std::mutex m_foundLoops;
+    std::vector<std::tuple<Time, Time, double>> foundLoops;
+    std::atomic<bool> b_run_thread{false};
+};
+
+struct StaticTheiaPoseCompute {
+    // float PNP(w_X, c_uv_normalized, c_T_w, pnp__msg)  (DlsPnpWithRansac.cpp:132-245).  c_T_w: column-major 4x4.
+    // Returns summary.confidence, or -1 for fewer than 20 points (:136-139) / on a library error.
+    static float PNP(chip_ctx *ctx, const std::vector<std::array<double, 3>> &w_X,
+                     const std::vector<std::array<double, 2>> &c_uv_normalized, double c_T_w[16], std::string &pnp__msg,
+                     const chip_ransac_params *params = nullptr, std::vector<uint8_t> *inliers = nullptr);
+};
+
+// geometry_msgs::Pose from a column-major 4x4 (PoseManipUtils::eigenmat_to_geometry_msgs_Pose,
+// src/utils/PoseManipUtils.cpp:31-45: position = T(0..2,3), orientation = Quaterniond(T.topLeftCorner<3,3>()))
+void matrix4_to_pose(const double T_colmajor[16], double position[3], double orientation_xyzw[4]);
+
+// ProcessedLoopCandidate::makeLoopEdgeMsg (src/ProcessedLoopCandidate.cpp:16-36)
+LoopEdgePOD make_loop_edge(const Time &t_node_1, const Time &t_node_2, const double _3d2d__2T1[16], float ransac_confidence,
+                           int idx_from_datamanager_1, int idx_from_datamanager_2);
+
+}  // namespace cerebro_hip

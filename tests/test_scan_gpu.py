@@ -267,3 +267,35 @@ def test_1M_full_size_parity_and_properties():
             if not np.isscalar(prev_best):
                 assert np.all(best >= prev_best)
             prev_best = best
+
+
+def test_sharded_tick_over_rccl_world1():
+    """The sharded orchestration (cerebro_amd/sharded.py) on the real RCCL backend, as far as a 1-GPU box allows:
+    world_size 1, kernels + all_gather_into_tensor on torch's current stream (chip_set_stream), merge + decision."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from cerebro_amd import sharded
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        D, N = 1024, 900
+        plants, loops, _ = scenarios.loop_plants(N, 4, seed=3)
+        db = scenarios.build_db(5, N, D, plants)
+        orc = oracle_lib.LoopOracle(db)
+        with capi.Chip(D, shard_rank=0, shard_count=1) as chip:
+            chip.append_f32(db)
+            det = sharded.ShardedLoopDetector(chip, topk=8, device=torch.device("cuda", 0))
+            for l in [2, 40] + scenarios.default_schedule(N):
+                o = orc.tick(l)
+                g = det.tick(l)
+                assert g.status == o["status"]
+                if o["status"] == 2:
+                    same_tick(g, o)
+            chip.set_stream(None)
+    finally:
+        dist.destroy_process_group()
