@@ -89,6 +89,7 @@ _SIGS = {
     "chip_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "chip_destroy": (None, [_P]),
     "chip_set_stream": (C.c_int, [_P, _P]),
+    "chip_reset_stream": (C.c_int, [_P]),
     "chip_synchronize": (C.c_int, [_P]),
     "chip_db_append_f64": (C.c_int, [_P, _P, C.c_int64, C.c_uint32, C.POINTER(C.c_int64)]),
     "chip_db_append_f32": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
@@ -105,13 +106,14 @@ _SIGS = {
     "chip_loop_reset": (None, [_P]),
     "chip_scan_local": (C.c_int, [_P, C.c_int64, C.POINTER(DotParams), C.c_int32, _P, C.POINTER(C.c_int32)]),
     "chip_merge_decide": (C.c_int, [_P, C.c_int64, C.POINTER(DotParams), _P, C.c_int32, C.c_int32, C.POINTER(TickResult)]),
+    "chip_merge_decide_enqueue": (C.c_int, [_P, C.c_int64, C.POINTER(DotParams), _P, C.c_int32, C.c_int32, C.c_int32]),
     "chip_ransac_params_default": (None, [C.POINTER(RansacParams)]),
     "chip_pnp_ransac": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(RansacParams), _P, C.POINTER(C.c_float), _P,
                                   C.POINTER(RansacSummary)]),
     "chip_get_info": (C.c_int, [_P, C.POINTER(Info)]),
     "chip_profile_enable": (C.c_int, [_P, C.c_int32]),
     "chip_profile_reset": (C.c_int, [_P]),
-    "chip_profile_scan": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "chip_profile_scan": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None
@@ -210,7 +212,11 @@ class Chip:
             raise ChipError(st, where, f"hipError {hip}: {txt.value.decode() if txt.value else ''}" if hip else "")
 
     def set_stream(self, stream_ptr: int | None):
-        self._chk(self.lib.chip_set_stream(self.h, C.c_void_p(stream_ptr or 0)), "chip_set_stream")
+        """None -> back to the ctx's private stream; an int is a hipStream_t handle (0 = HIP's null stream)."""
+        if stream_ptr is None:
+            self._chk(self.lib.chip_reset_stream(self.h), "chip_reset_stream")
+        else:
+            self._chk(self.lib.chip_set_stream(self.h, C.c_void_p(stream_ptr)), "chip_set_stream")
 
     def synchronize(self):
         self._chk(self.lib.chip_synchronize(self.h), "chip_synchronize")
@@ -305,6 +311,12 @@ class Chip:
                                              C.byref(r)), "chip_merge_decide")
         return r
 
+    def merge_decide_enqueue(self, l: int, dev_gathered_ptr: int, n_lists: int, slot: int, topk: int = CHIP_DEFAULT_TOPK,
+                             params: DotParams | None = None):
+        p = params or default_dot_params()
+        self._chk(self.lib.chip_merge_decide_enqueue(self.h, l, C.byref(p), C.c_void_p(dev_gathered_ptr), n_lists, topk, slot),
+                  "chip_merge_decide_enqueue")
+
     # -- PnP
     def pnp_ransac(self, X: np.ndarray, uv: np.ndarray, params: RansacParams | None = None):
         X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 3)
@@ -339,6 +351,6 @@ class Chip:
         self._chk(self.lib.chip_profile_reset(self.h), "chip_profile_reset")
 
     def profile_scan(self):
-        ms, n, b = C.c_double(), C.c_int64(), C.c_double()
-        self._chk(self.lib.chip_profile_scan(self.h, C.byref(ms), C.byref(n), C.byref(b)), "chip_profile_scan")
-        return ms.value, n.value, b.value
+        ms, n, b, span = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        self._chk(self.lib.chip_profile_scan(self.h, C.byref(ms), C.byref(n), C.byref(b), C.byref(span)), "chip_profile_scan")
+        return ms.value, n.value, b.value, span.value

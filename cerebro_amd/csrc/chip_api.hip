@@ -106,16 +106,20 @@ static void destroy_ctx(chip_ctx *c)
     if (c->stage_dev) (void)hipFree(c->stage_dev);
     if (c->flags_dev) (void)hipFree(c->flags_dev);
     if (c->flags_host) (void)hipHostFree(c->flags_host);
-    if (c->partial_dev) (void)hipFree(c->partial_dev);
+    for (int i = 0; i < Ctx::kRing; i++) {
+        if (c->partial_dev[i]) (void)hipFree(c->partial_dev[i]);
+        if (c->ev_scan[i]) (void)hipEventDestroy(c->ev_scan[i]);
+        if (c->ev_merged[i]) (void)hipEventDestroy(c->ev_merged[i]);
+    }
+    if (c->s_scan) (void)hipStreamDestroy(c->s_scan);
     if (c->topk_host) (void)hipHostFree(c->topk_host);
     if (c->qvec_dev) (void)hipFree(c->qvec_dev);
     for (Slot &s : c->slots) {
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.host) (void)hipHostFree(s.host);
     }
-    if (c->ticket_dev) (void)hipFree(c->ticket_dev);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
-    if (c->s_query && c->own_query_stream) (void)hipStreamDestroy(c->s_query);
+    if (c->own_query_stream && c->s_query) (void)hipStreamDestroy(c->s_query);
     if (c->s_append) (void)hipStreamDestroy(c->s_append);
     if (c->s_pnp) (void)hipStreamDestroy(c->s_pnp);
     delete c;
@@ -157,13 +161,16 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
     c->scan_blocks_per_cu = env_int("CHIP_SCAN_BPC", 2);
     if (c->scan_blocks_per_cu < 1) c->scan_blocks_per_cu = 1;
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);
-    c->max_grid = c->scan_block;  // the last block of the fused scan keeps one partial list per thread
-    CHIP_HIP(c, hipMalloc(&c->partial_dev, (size_t)c->max_grid * CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry)));
+    c->max_grid = 512;  // K2 (one 512-thread workgroup) keeps one partial list per thread
+    CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_scan, hipStreamNonBlocking));
+    for (int i = 0; i < Ctx::kRing; i++) {
+        CHIP_HIP(c, hipMalloc(&c->partial_dev[i], (size_t)c->max_grid * CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry)));
+        CHIP_HIP(c, hipEventCreateWithFlags(&c->ev_scan[i], hipEventDisableTiming));
+        CHIP_HIP(c, hipEventCreateWithFlags(&c->ev_merged[i], hipEventDisableTiming));
+    }
     CHIP_HIP(c, hipHostMalloc(&c->topk_host, (size_t)CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry), hipHostMallocDefault));
     CHIP_HIP(c, hipHostGetDevicePointer((void **)&c->topk_dev, c->topk_host, 0));
     CHIP_HIP(c, hipMalloc(&c->qvec_dev, (size_t)CHIP_MAX_NQ * c->D * sizeof(float)));
-    CHIP_HIP(c, hipMalloc(&c->ticket_dev, sizeof(unsigned)));
-    CHIP_HIP(c, hipMemset(c->ticket_dev, 0, sizeof(unsigned)));
     for (Slot &s : c->slots) {
         CHIP_HIP(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         // pinned + mapped: the deciding workgroup stores the record here directly, no D2H copy kernel per tick
@@ -180,11 +187,14 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
     return CHIP_OK;
 }
 
-// Enqueue the fused scan (K1: scan + top-k + last-block merge [+ decision]) for nq queries over global prefix [0,k).
-// out (device or pinned host, optional) gets [nq][K]; res (optional) the accept decision of Cerebro.cpp:1056.
-static int enqueue_scan(Ctx *c, hipStream_t s, int64_t k, const float *const *q, int nq, int K, int64_t l,
-                        const chip_dot_params *p, chip_topk_entry *out, chip_tick_result *res)
+// Enqueue K1 (scan + per-workgroup top-k, on s_scan) and K2 (cross-workgroup merge [+ accept decision], on the ctx
+// stream behind an event) for nq queries over the global prefix [0,k).  out (device or pinned host, optional) gets
+// [nq][K]; res (optional) the decision record of Cerebro.cpp:1056.  Consecutive calls pipeline: scans run back to
+// back on s_scan while the previous merge (and whatever the caller enqueues after it on the ctx stream) proceeds.
+static int enqueue_scan_merge(Ctx *c, int64_t k, const float *const *q, int nq, int K, int64_t l,
+                              const chip_dot_params *p, chip_topk_entry *out, chip_tick_result *res)
 {
+    const int b = (int)(c->n_enqueued++ % Ctx::kRing);
     ScanArgs a;
     a.seg_table = c->seg_table_dev;
     a.seg_shift = c->seg_shift;
@@ -195,16 +205,12 @@ static int enqueue_scan(Ctx *c, hipStream_t s, int64_t k, const float *const *q,
     for (int i = 0; i < CHIP_MAX_NQ; i++) a.q[i] = i < nq ? q[i] : nullptr;
     a.idx_mul = c->nranks;
     a.idx_add = c->nranks == 1 ? 0 : c->rank;
-    a.partial = c->partial_dev;
+    a.partial = c->partial_dev[b];
     const int grid = scan_grid_for(c, a.n_rows, nq);
-    a.ticket = c->ticket_dev;
-    a.ticket_target = (unsigned)(c->ticket_total + (uint64_t)grid);  // cumulative: launches on one stream are serialised
-    a.out = out;
-    a.result = res;
-    a.l = l;
-    a.locality = p ? p->locality : 0;
-    a.thresh = p ? p->thresh : 0.0;
 
+    // The merge that last read this buffer ran kRing ticks ago; only when it is not already complete (a stalled ctx
+    // stream) does the scan stream need a barrier packet -- in steady state this costs nothing.
+    if (hipEventQuery(c->ev_merged[b]) != hipSuccess) CHIP_HIP(c, hipStreamWaitEvent(c->s_scan, c->ev_merged[b], 0));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->prof_on) {
         if (c->prof_used + 2 > c->prof_ev.size()) {
@@ -218,17 +224,26 @@ static int enqueue_scan(Ctx *c, hipStream_t s, int64_t k, const float *const *q,
         e1 = c->prof_ev[c->prof_used + 1];
         c->prof_used += 2;
         c->prof_bytes_last = (double)a.n_rows * c->D * 4.0;
-        CHIP_HIP(c, hipEventRecord(e0, s));
+        CHIP_HIP(c, hipEventRecord(e0, c->s_scan));
     }
-    int rc = launch_scan(c, s, a, nq, grid);
-    if (rc != CHIP_OK) {  // nothing ran: re-arm the arrival counter so that the host mirror cannot drift
-        (void)hipStreamSynchronize(s);
-        (void)hipMemset(c->ticket_dev, 0, sizeof(unsigned));
-        c->ticket_total = 0;
-        return rc;
-    }
-    c->ticket_total += (uint64_t)grid;
-    if (e1) CHIP_HIP(c, hipEventRecord(e1, s));
+    int rc = launch_scan(c, c->s_scan, a, nq, grid);
+    if (rc != CHIP_OK) return rc;
+    if (e1) CHIP_HIP(c, hipEventRecord(e1, c->s_scan));
+    CHIP_HIP(c, hipEventRecord(c->ev_scan[b], c->s_scan));
+    CHIP_HIP(c, hipStreamWaitEvent(c->s_query, c->ev_scan[b], 0));
+
+    MergeArgs m;
+    m.in = c->partial_dev[b];
+    m.n_lists = grid;
+    m.K = K;
+    m.out = out;
+    m.result = res;
+    m.l = l;
+    m.locality = p ? p->locality : 0;
+    m.thresh = p ? p->thresh : 0.0;
+    rc = launch_merge(c, c->s_query, m, nq);
+    if (rc != CHIP_OK) return rc;
+    CHIP_HIP(c, hipEventRecord(c->ev_merged[b], c->s_query));
     return CHIP_OK;
 }
 
@@ -296,7 +311,7 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
     const float *q[3];
     rc = query_row_ptrs(c, rows, 3, l, q);
     if (rc != CHIP_OK) return rc;
-    rc = enqueue_scan(c, c->s_query, k, q, 3, CHIP_DEFAULT_TOPK, l, p, nullptr, s.dev);
+    rc = enqueue_scan_merge(c, k, q, 3, CHIP_DEFAULT_TOPK, l, p, nullptr, s.dev);
     if (rc != CHIP_OK) return rc;
     CHIP_HIP(c, hipEventRecord(s.done, c->s_query));
     s.immediate = false;
@@ -411,13 +426,22 @@ int chip_set_stream(chip_ctx *c, void *hip_stream)
     if (!c) return CHIP_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->query_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
-    if (c->own_query_stream) {
-        CHIP_HIP(c, hipStreamSynchronize(c->s_query));
-        if (hip_stream) { CHIP_HIP(c, hipStreamDestroy(c->s_query)); c->s_query = (hipStream_t)hip_stream; c->own_query_stream = false; }
-    } else {
-        if (hip_stream) c->s_query = (hipStream_t)hip_stream;
-        else { CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_query, hipStreamNonBlocking)); c->own_query_stream = true; }
-    }
+    CHIP_HIP(c, hipStreamSynchronize(c->s_query));
+    if (c->own_query_stream) CHIP_HIP(c, hipStreamDestroy(c->s_query));
+    c->s_query = (hipStream_t)hip_stream;   // may be 0: HIP's null stream is a valid external stream
+    c->own_query_stream = false;
+    return CHIP_OK;
+}
+
+int chip_reset_stream(chip_ctx *c)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->query_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    if (c->own_query_stream) return CHIP_OK;
+    CHIP_HIP(c, hipStreamSynchronize(c->s_query));
+    CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_query, hipStreamNonBlocking));
+    c->own_query_stream = true;
     return CHIP_OK;
 }
 
@@ -426,6 +450,7 @@ int chip_synchronize(chip_ctx *c)
     if (!c) return CHIP_ERR_INVALID_ARG;
     CHIP_HIP(c, hipSetDevice(c->device));
     CHIP_HIP(c, hipStreamSynchronize(c->s_append));
+    CHIP_HIP(c, hipStreamSynchronize(c->s_scan));
     CHIP_HIP(c, hipStreamSynchronize(c->s_query));
     CHIP_HIP(c, hipStreamSynchronize(c->s_pnp));
     return CHIP_OK;
@@ -540,7 +565,7 @@ int chip_query_rows(chip_ctx *c, int64_t k, const int64_t *query_rows, int32_t n
     const float *q[CHIP_MAX_NQ];
     rc = query_row_ptrs(c, query_rows, nq, n, q);
     if (rc != CHIP_OK) return rc;
-    rc = enqueue_scan(c, c->s_query, k, q, nq, topk, 0, nullptr, c->topk_dev, nullptr);
+    rc = enqueue_scan_merge(c, k, q, nq, topk, 0, nullptr, c->topk_dev, nullptr);
     if (rc != CHIP_OK) return rc;
     return sync_topk_out(c, nq, topk, scores, idx);
 }
@@ -553,10 +578,11 @@ int chip_query_vectors_f32(chip_ctx *c, int64_t k, const float *queries, int32_t
     if (!queries) return CHIP_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> qlk(c->query_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
-    CHIP_HIP(c, hipMemcpyAsync(c->qvec_dev, queries, (size_t)nq * c->D * sizeof(float), hipMemcpyHostToDevice, c->s_query));
+    // on the scan stream: K1 reads qvec_dev there (the previous synchronous call has fully drained, so no WAR hazard)
+    CHIP_HIP(c, hipMemcpyAsync(c->qvec_dev, queries, (size_t)nq * c->D * sizeof(float), hipMemcpyHostToDevice, c->s_scan));
     const float *q[CHIP_MAX_NQ];
     for (int i = 0; i < nq; i++) q[i] = c->qvec_dev + (size_t)i * c->D;
-    rc = enqueue_scan(c, c->s_query, k, q, nq, topk, 0, nullptr, c->topk_dev, nullptr);
+    rc = enqueue_scan_merge(c, k, q, nq, topk, 0, nullptr, c->topk_dev, nullptr);
     if (rc != CHIP_OK) return rc;
     return sync_topk_out(c, nq, topk, scores, idx);
 }
@@ -607,7 +633,30 @@ int chip_scan_local(chip_ctx *c, int64_t l, const chip_dot_params *p, int32_t to
     const float *q[3];
     rc = query_row_ptrs(c, rows, 3, l, q);
     if (rc != CHIP_OK) return rc;
-    return enqueue_scan(c, c->s_query, k, q, 3, topk, l, nullptr, (chip_topk_entry *)dev_out, nullptr);
+    // scan on s_scan, then (behind an event) the local merge on the ctx stream writes this rank's 3 x topk list to
+    // dev_out: everything the caller enqueues next on the ctx stream (the all-gather) is ordered after it, while the
+    // next tick's scan is free to start as soon as this scan ends.
+    return enqueue_scan_merge(c, k, q, 3, topk, l, nullptr, (chip_topk_entry *)dev_out, nullptr);
+}
+
+static int merge_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, const void *dev_gathered, int32_t n_lists, int32_t topk, Slot &s)
+{
+    if (s.in_flight) return CHIP_ERR_BUSY;
+    MergeArgs m;
+    m.in = (const chip_topk_entry *)dev_gathered;
+    m.n_lists = n_lists;
+    m.K = topk;
+    m.out = nullptr;
+    m.result = s.dev;   // pinned + mapped: no D2H copy
+    m.l = l;
+    m.locality = p->locality;
+    m.thresh = p->thresh;
+    int rc = launch_merge(c, c->s_query, m, 3);
+    if (rc != CHIP_OK) return rc;
+    CHIP_HIP(c, hipEventRecord(s.done, c->s_query));
+    s.immediate = false;
+    s.in_flight = true;
+    return CHIP_OK;
 }
 
 int chip_merge_decide(chip_ctx *c, int64_t l, const chip_dot_params *p, const void *dev_gathered, int32_t n_lists,
@@ -618,20 +667,19 @@ int chip_merge_decide(chip_ctx *c, int64_t l, const chip_dot_params *p, const vo
     std::lock_guard<std::mutex> qlk(c->query_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
     Slot &s = c->slots[CHIP_MAX_INFLIGHT - 1];
-    MergeArgs m;
-    m.in = (const chip_topk_entry *)dev_gathered;
-    m.n_lists = n_lists;
-    m.K = topk;
-    m.out = c->topk_dev;
-    m.result = s.dev;
-    m.l = l;
-    m.locality = p->locality;
-    m.thresh = p->thresh;
-    int rc = launch_merge(c, c->s_query, m, 3);
+    int rc = merge_enqueue_slot(c, l, p, dev_gathered, n_lists, topk, s);
     if (rc != CHIP_OK) return rc;
-    CHIP_HIP(c, hipStreamSynchronize(c->s_query));
-    *out = *s.host;
-    return CHIP_OK;
+    return tick_collect_slot(c, s, out);
+}
+
+int chip_merge_decide_enqueue(chip_ctx *c, int64_t l, const chip_dot_params *p, const void *dev_gathered, int32_t n_lists,
+                              int32_t topk, int32_t slot)
+{
+    if (!c || !p || !dev_gathered || n_lists < 1 || slot < 0 || slot >= CHIP_MAX_INFLIGHT - 1) return CHIP_ERR_INVALID_ARG;
+    if (topk < 1 || topk > CHIP_MAX_TOPK) return CHIP_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    return merge_enqueue_slot(c, l, p, dev_gathered, n_lists, topk, c->slots[slot]);
 }
 
 // ------------------------------------------------------------------------------------------------ introspection
@@ -670,21 +718,25 @@ int chip_profile_reset(chip_ctx *c)
     return CHIP_OK;
 }
 
-int chip_profile_scan(chip_ctx *c, double *total_ms, int64_t *n_launches, double *bytes_per_launch_last)
+int chip_profile_scan(chip_ctx *c, double *total_ms, int64_t *n_launches, double *bytes_per_launch_last, double *span_ms)
 {
     if (!c) return CHIP_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> qlk(c->query_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
+    CHIP_HIP(c, hipStreamSynchronize(c->s_scan));
     CHIP_HIP(c, hipStreamSynchronize(c->s_query));
-    double tot = 0.0;
+    double tot = 0.0, span = 0.0;
     for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
         float ms = 0.f;
         CHIP_HIP(c, hipEventElapsedTime(&ms, c->prof_ev[i], c->prof_ev[i + 1]));
         tot += ms;
+        CHIP_HIP(c, hipEventElapsedTime(&ms, c->prof_ev[0], c->prof_ev[i + 1]));  // launches alternate between two streams
+        if (ms > span) span = ms;
     }
     if (total_ms) *total_ms = tot;
     if (n_launches) *n_launches = (int64_t)(c->prof_used / 2);
     if (bytes_per_launch_last) *bytes_per_launch_last = c->prof_bytes_last;
+    if (span_ms) *span_ms = span;
     return CHIP_OK;
 }
 

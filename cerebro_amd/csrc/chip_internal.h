@@ -24,13 +24,6 @@ struct ScanArgs {
     const float *q[CHIP_MAX_NQ];    // query descriptors (device, fp32, D each, 16-B aligned)
     int64_t idx_mul, idx_add;       // global index = local * idx_mul + idx_add  (round-robin shard map)
     chip_topk_entry *partial;       // [gridDim.x][NQ][K]
-    unsigned *ticket;               // cumulative arrival counter (never reset; see chip_api.hip)
-    unsigned ticket_target;         // value the LAST block of this launch observes after its increment
-    chip_topk_entry *out;           // [NQ][K] final list (device or pinned host; may be null)
-    chip_tick_result *result;       // accept decision (may be null)
-    int64_t l;                      // tick position (idx_curr = l-1)
-    int32_t locality;
-    double thresh;
 };
 
 struct MergeArgs {
@@ -96,12 +89,20 @@ struct Ctx {
     uint32_t *flags_host = nullptr;      // pinned
 
     // --- query scratch ---
-    chip_topk_entry *partial_dev = nullptr;   // [max_grid][CHIP_MAX_NQ][CHIP_MAX_TOPK]
+    // Scans run back-to-back on s_scan; the merge of tick i runs on the ctx stream (s_query) behind ev_scan[b], so
+    // it (and, sharded, the all-gather + global merge that follow it on the ctx stream) overlaps the scan of tick
+    // i+1.  Partial lists live in a ring of kRing buffers; a scan waits for the merge that last read its buffer.
+    static constexpr int kRing = 4;
+    hipStream_t s_scan = nullptr;
+    chip_topk_entry *partial_dev[kRing] = {nullptr, nullptr, nullptr, nullptr};   // [max_grid][CHIP_MAX_NQ][CHIP_MAX_TOPK]
+    int32_t partial_lists[kRing] = {0, 0, 0, 0};                                  // grid of the scan that filled it
+    hipEvent_t ev_scan[kRing] = {nullptr, nullptr, nullptr, nullptr};             // scan into buffer b finished
+    hipEvent_t ev_merged[kRing] = {nullptr, nullptr, nullptr, nullptr};           // merge out of buffer b finished
+    uint64_t n_enqueued = 0;
     int32_t max_grid = 0;
     chip_topk_entry *topk_dev = nullptr;      // [CHIP_MAX_NQ][CHIP_MAX_TOPK]
     chip_topk_entry *topk_host = nullptr;     // pinned, device-visible: the last block writes results straight here
-    unsigned *ticket_dev = nullptr;           // arrival counter of the fused scan
-    uint64_t ticket_total = 0;                // sum of the grids launched so far (host mirror)
+
     float *qvec_dev = nullptr;                // [CHIP_MAX_NQ][D] external query vectors
     Slot slots[CHIP_MAX_INFLIGHT];
     int64_t last_l = 0;

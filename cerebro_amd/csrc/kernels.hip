@@ -24,77 +24,151 @@ __device__ __forceinline__ bool key_gt(double s, int64_t i, double s2, int64_t i
     return s > s2 || (s == s2 && i > i2);
 }
 
-// Cross-workgroup hand-off of partial lists (cdna_hip_programming.md G16, form R1): the producer stores the payload
-// WRITE-THROUGH (relaxed agent-scope 8-byte atomic stores lower to `global_store_dwordx2 sc1`), so no release
-// fence (512 `buffer_wbl2` per launch cost ~50 us here); the consumer reads with sc1 loads (L1-bypassing).
-__device__ __forceinline__ void store_entry_sc1(chip_topk_entry *p, double s, int64_t i)
+// ------------------------------------------------------------------------------------------------ list merge
+// Exact top-K of n_lists (<= blockDim.x = 512) SORTED lists of K candidates per query, by ONE workgroup, plus the
+// accept rule of Cerebro.cpp:1056.  Selection instead of K serial block-wide argmax rounds:
+//   1. thread t loads the HEAD of list t;                       2. every wave ranks its 64 heads (v_readlane loops)
+//   and posts its K best to LDS;  3. one wave per query ranks those <= 8K heads: T1 = K-th best head overall.
+//   Every global top-K entry is >= T1 (K heads already are), and only the K lists whose head >= T1 can contribute,
+//   each at most K entries => at most K*K <= 256 survivors;     4. survivors are appended to an LDS list (LDS atomic
+//   cursor) and ranked by one wave per query; rank r < K is written to out[r].  Keys (score desc, idx desc) are
+//   unique for valid entries (indices are), so ranks are a permutation and the result is partition independent.
+// smem: kMergeSmem bytes.
+constexpr int kMergeSmem = 28 * 1024;
+constexpr int kSurvCap = CHIP_MAX_TOPK * CHIP_MAX_TOPK;  // 256
+
+__device__ __forceinline__ double readlane_f64(double v, int j)
 {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&p->score), (unsigned long long)__double_as_longlong(s),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&p->idx), (unsigned long long)i, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), j);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), j);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ void load_entry_sc1(const chip_topk_entry *p, double &s, int64_t &i)
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, int j)
 {
-    chip_topk_entry *q = const_cast<chip_topk_entry *>(p);
-    s = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&q->score), __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT));
-    i = (int64_t)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&q->idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), j);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), j);
+    return ((int64_t)hi << 32) | (unsigned int)lo;
 }
 
-// ------------------------------------------------------------------------------------------------ list merge
-// Merge n_lists (<= blockDim.x) SORTED lists of K candidates per query into the global top-K and, optionally, apply
-// the accept rule of Cerebro.cpp:1056.  One workgroup.  Thread t keeps list t register-resident; K rounds of
-// {argmax over the list HEADS: wave butterfly + one LDS hop} ; the winner's owner shifts its list by one.
-// One barrier per round (LDS slots double-buffered by round parity).  smem: >= 1 KiB scratch.
 template <int NQ>
 __device__ __forceinline__ void merge_sorted_lists(const chip_topk_entry *in, int n_lists, int K, chip_topk_entry *out,
                                                    chip_tick_result *result, int64_t l, int locality, double thresh, char *smem)
 {
-    double *red_s = reinterpret_cast<double *>(smem);              // [2][16]
-    int64_t *red_i = reinterpret_cast<int64_t *>(smem + 256);      // [2][16]
-    double *top_s = reinterpret_cast<double *>(smem + 512);        // [NQ]
-    int64_t *top_i = reinterpret_cast<int64_t *>(smem + 512 + 64); // [NQ]
+    chip_topk_entry *candA = reinterpret_cast<chip_topk_entry *>(smem);                    // [NQ][8 waves * 16]
+    chip_topk_entry *surv = candA + CHIP_MAX_NQ * 8 * CHIP_MAX_TOPK;                        // [NQ][kSurvCap]
+    chip_topk_entry *T1s = surv + CHIP_MAX_NQ * kSurvCap;                                   // [NQ]
+    chip_topk_entry *tops = T1s + CHIP_MAX_NQ;                                              // [NQ]
+    int *cnt = reinterpret_cast<int *>(tops + CHIP_MAX_NQ);                                 // [NQ]
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6, nw = blockDim.x >> 6;
 
+    // ---- 1. heads ----
+    double hs[NQ];
+    int64_t hi[NQ];
+#pragma unroll
     for (int q = 0; q < NQ; q++) {
-        double es[CHIP_MAX_TOPK];
-        int64_t ei[CHIP_MAX_TOPK];
-#pragma unroll
-        for (int j = 0; j < CHIP_MAX_TOPK; j++) {
-            if (j < K && t < n_lists) load_entry_sc1(in + ((int64_t)t * NQ + q) * K + j, es[j], ei[j]);
-            else { es[j] = -INFINITY; ei[j] = -1; }
-        }
-        for (int r = 0; r < K; r++) {
-            double bs = es[0];
-            int64_t bi = ei[0];
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                const double os = __shfl_xor(bs, m, 64);
-                const int64_t oi = __shfl_xor(bi, m, 64);
-                if (key_gt(os, oi, bs, bi)) { bs = os; bi = oi; }
-            }
-            const int par = (r & 1) * 16;
-            if (lane == 0) { red_s[par + w] = bs; red_i[par + w] = bi; }
-            __syncthreads();
-            bs = red_s[par];
-            bi = red_i[par];
-            for (int x = 1; x < nw; x++)
-                if (key_gt(red_s[par + x], red_i[par + x], bs, bi)) { bs = red_s[par + x]; bi = red_i[par + x]; }
-            if (bi >= 0 && ei[0] == bi) {  // indices are unique: exactly one owner
-#pragma unroll
-                for (int j = 0; j + 1 < CHIP_MAX_TOPK; j++) { es[j] = es[j + 1]; ei[j] = ei[j + 1]; }
-                es[CHIP_MAX_TOPK - 1] = -INFINITY;
-                ei[CHIP_MAX_TOPK - 1] = -1;
-            }
-            if (t == 0) {
-                if (out) { chip_topk_entry x; x.score = bs; x.idx = bi; out[q * K + r] = x; }
-                if (r == 0) { top_s[q] = bs; top_i[q] = bi; }
-            }
-        }
-        __syncthreads();  // red_* slots are reused by the next query
+        if (t < n_lists) { const chip_topk_entry x = in[((int64_t)t * NQ + q) * K]; hs[q] = x.score; hi[q] = x.idx; }
+        else { hs[q] = -INFINITY; hi[q] = -1; }
     }
+    if (t < NQ) cnt[t] = 0;
+    // ---- 2. per-wave rank of the heads; the K best of each wave go to candA[q][w*K + rank] ----
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        int rank = 0;
+#pragma unroll 8
+        for (int j = 0; j < 64; j++) rank += key_gt(readlane_f64(hs[q], j), readlane_i64(hi[q], j), hs[q], hi[q]) ? 1 : 0;
+        const bool valid = hi[q] >= 0;
+        const int nvalid = __popcll(__ballot(valid));
+        chip_topk_entry *dst = candA + (q * 8 + w) * CHIP_MAX_TOPK;
+        if (valid && rank < K) { dst[rank].score = hs[q]; dst[rank].idx = hi[q]; }
+        if (lane < K && lane >= nvalid) { dst[lane].score = -INFINITY; dst[lane].idx = -1; }
+    }
+    __syncthreads();
+    // ---- 3. T1[q] = K-th best head overall (or "everything survives" when fewer than K lists are non-empty) ----
+    if (w < NQ) {
+        const int q = w;
+        double cs[2];
+        int64_t ci[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int c = lane + 64 * h;  // candidate (wave c / K, slot c % K)
+            if (c < nw * K) { const chip_topk_entry x = candA[(q * 8 + c / K) * CHIP_MAX_TOPK + (c % K)]; cs[h] = x.score; ci[h] = x.idx; }
+            else { cs[h] = -INFINITY; ci[h] = -1; }
+        }
+        int r0 = 0, r1 = 0;
+#pragma unroll 8
+        for (int j = 0; j < 64; j++) {
+            const double a0 = readlane_f64(cs[0], j), a1 = readlane_f64(cs[1], j);
+            const int64_t b0 = readlane_i64(ci[0], j), b1 = readlane_i64(ci[1], j);
+            r0 += (key_gt(a0, b0, cs[0], ci[0]) ? 1 : 0) + (key_gt(a1, b1, cs[0], ci[0]) ? 1 : 0);
+            r1 += (key_gt(a0, b0, cs[1], ci[1]) ? 1 : 0) + (key_gt(a1, b1, cs[1], ci[1]) ? 1 : 0);
+        }
+        const int nv = __popcll(__ballot(ci[0] >= 0)) + __popcll(__ballot(ci[1] >= 0));
+        if (nv >= K) {
+            if (ci[0] >= 0 && r0 == K - 1) { T1s[q].score = cs[0]; T1s[q].idx = ci[0]; }
+            if (ci[1] >= 0 && r1 == K - 1) { T1s[q].score = cs[1]; T1s[q].idx = ci[1]; }
+        } else if (lane == 0) { T1s[q].score = -INFINITY; T1s[q].idx = -1; }
+    }
+    __syncthreads();
+    // ---- 4. survivors: the prefix of every list whose head >= T1 ----
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const double ts = T1s[q].score;
+        const int64_t ti = T1s[q].idx;
+        if (t < n_lists && hi[q] >= 0 && !key_gt(ts, ti, hs[q], hi[q])) {
+            double es[CHIP_MAX_TOPK];
+            int64_t ei[CHIP_MAX_TOPK];
+            es[0] = hs[q]; ei[0] = hi[q];
+#pragma unroll
+            for (int j = 1; j < CHIP_MAX_TOPK; j++) {
+                if (j < K) { const chip_topk_entry x = in[((int64_t)t * NQ + q) * K + j]; es[j] = x.score; ei[j] = x.idx; }
+                else { es[j] = -INFINITY; ei[j] = -1; }
+            }
+            int c = 1;
+#pragma unroll
+            for (int j = 1; j < CHIP_MAX_TOPK; j++)
+                if (c == j && ei[j] >= 0 && !key_gt(ts, ti, es[j], ei[j])) c = j + 1;   // sorted: survivors are a prefix
+            const int base = atomicAdd(&cnt[q], c);
+#pragma unroll
+            for (int j = 0; j < CHIP_MAX_TOPK; j++)
+                if (j < c && base + j < kSurvCap) { surv[q * kSurvCap + base + j].score = es[j]; surv[q * kSurvCap + base + j].idx = ei[j]; }
+        }
+    }
+    __syncthreads();
+    // ---- 5. rank the survivors; rank r < K -> out[r] ----
+    if (w < NQ) {
+        const int q = w;
+        int n = cnt[q];
+        if (n > kSurvCap) n = kSurvCap;  // cannot happen (<= K*K), keeps the loops bounded
+        double cs[4];
+        int64_t ci[4];
+        int rk[4];
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const int c = lane + 64 * h;
+            if (c < n) { cs[h] = surv[q * kSurvCap + c].score; ci[h] = surv[q * kSurvCap + c].idx; }
+            else { cs[h] = -INFINITY; ci[h] = -1; }
+            rk[h] = 0;
+        }
+        for (int j = 0; j < n; j++) {
+            const chip_topk_entry x = surv[q * kSurvCap + j];  // LDS broadcast
+#pragma unroll
+            for (int h = 0; h < 4; h++) rk[h] += key_gt(x.score, x.idx, cs[h], ci[h]) ? 1 : 0;
+        }
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            if (ci[h] >= 0 && rk[h] < K) {
+                if (out) { out[q * K + rk[h]].score = cs[h]; out[q * K + rk[h]].idx = ci[h]; }
+                if (rk[h] == 0) { tops[q].score = cs[h]; tops[q].idx = ci[h]; }
+            }
+        }
+        if (lane < K && lane >= n) {  // fewer than K candidates in total: pad
+            if (out) { out[q * K + lane].score = -INFINITY; out[q * K + lane].idx = -1; }
+            if (lane == 0) { tops[q].score = -INFINITY; tops[q].idx = -1; }
+        }
+    }
+    __syncthreads();
     if (result != nullptr && t == 0) {
         chip_tick_result res;
         res.status = CHIP_TICK_SCANNED;
@@ -103,8 +177,8 @@ __device__ __forceinline__ void merge_sorted_lists(const chip_topk_entry *in, in
         res.idx_prev = -1;
         res.score = 0.0;
         for (int q = 0; q < 3; q++) {
-            res.argmax[q] = q < NQ ? top_i[q] : -1;
-            res.maxv[q] = q < NQ ? top_s[q] : -INFINITY;
+            res.argmax[q] = q < NQ ? tops[q].idx : -1;
+            res.maxv[q] = q < NQ ? tops[q].score : -INFINITY;
         }
         if (NQ >= 3 && res.argmax[0] >= 0 && res.argmax[1] >= 0 && res.argmax[2] >= 0) {
             // Cerebro.cpp:1056  abs(u_argmax-um_argmax) < LOCALITY && abs(u_argmax-umm_argmax) < LOCALITY && u_max > THRESH
@@ -124,10 +198,10 @@ __device__ __forceinline__ void merge_sorted_lists(const chip_topk_entry *in, in
 }
 
 // ------------------------------------------------------------------------------------------------ K1
-// One launch per tick: scan -> per-wave register top-K -> per-block LDS merge -> partial list to global ->
-// agent-scope release + ticket; the LAST block to arrive acquires, merges all partial lists and writes the
-// top-K (and the accept decision) to `out` / `result` (device memory or pinned host memory).
-template <int NQ, int U, bool FULL>
+// scan -> per-wave register top-K -> per-block LDS merge -> one sorted partial list per workgroup in global memory.
+// The cross-workgroup merge (+ accept decision) is K2 on the ctx stream, behind an event, so that it overlaps the
+// NEXT tick's scan (a fused last-workgroup merge was measured to serialise ~28 us per tick).
+template <int NQ, int U, bool FULL, bool NT, int R>
 __global__ __launch_bounds__(512) void db_scan_topk(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -156,18 +230,30 @@ __global__ __launch_bounds__(512) void db_scan_topk(ScanArgs a)
 
     const int64_t tw = (int64_t)gridDim.x * wpb;
     const int e0 = lane * 4;
-    for (int64_t r = (int64_t)blockIdx.x * wpb + wave; r < a.n_rows; r += tw) {
-        const float *row = a.seg_table[r >> a.seg_shift] + (r & a.seg_mask) * (int64_t)D;
-        double acc[NQ];
+    // each wave owns rows w, w+tw, ... ; R of them are in flight together (R independent accumulator sets)
+    for (int64_t r0 = (int64_t)blockIdx.x * wpb + wave; r0 < a.n_rows; r0 += tw * R) {
+        const float *row[R];
+        double acc[R][NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; q++) acc[q] = 0.0;
-
+        for (int rr = 0; rr < R; rr++) {
+            const int64_t r = r0 + rr * tw;
+            const int64_t rc = r < a.n_rows ? r : r0;   // clamp (result of a clamped row is discarded)
+            row[rr] = a.seg_table[rc >> a.seg_shift] + (rc & a.seg_mask) * (int64_t)D;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) acc[rr][q] = 0.0;
+        }
         for (int base = 0; base < D; base += 256 * U) {
-            f32x4 v[U];
+            f32x4 v[R][U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int e = base + u * 256 + e0;
-                if (FULL || e < D) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(row + e));
+            for (int rr = 0; rr < R; rr++) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int e = base + u * 256 + e0;
+                    if (FULL || e < D) {
+                        const f32x4 *p = reinterpret_cast<const f32x4 *>(row[rr] + e);
+                        v[rr][u] = NT ? __builtin_nontemporal_load(p) : *p;
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -176,37 +262,46 @@ __global__ __launch_bounds__(512) void db_scan_topk(ScanArgs a)
 #pragma unroll
                     for (int q = 0; q < NQ; q++) {
                         const f32x4 w = *reinterpret_cast<const f32x4 *>(qs + q * D + e);
-                        // exact products, one rounding per add: fma == mul-then-add here
-                        acc[q] = __builtin_fma((double)w.x, (double)v[u].x, acc[q]);
-                        acc[q] = __builtin_fma((double)w.y, (double)v[u].y, acc[q]);
-                        acc[q] = __builtin_fma((double)w.z, (double)v[u].z, acc[q]);
-                        acc[q] = __builtin_fma((double)w.w, (double)v[u].w, acc[q]);
+                        const double w0 = (double)w.x, w1 = (double)w.y, w2 = (double)w.z, w3 = (double)w.w;
+#pragma unroll
+                        for (int rr = 0; rr < R; rr++) {
+                            // exact products, one rounding per add: fma == mul-then-add here
+                            acc[rr][q] = __builtin_fma(w0, (double)v[rr][u].x, acc[rr][q]);
+                            acc[rr][q] = __builtin_fma(w1, (double)v[rr][u].y, acc[rr][q]);
+                            acc[rr][q] = __builtin_fma(w2, (double)v[rr][u].z, acc[rr][q]);
+                            acc[rr][q] = __builtin_fma(w3, (double)v[rr][u].w, acc[rr][q]);
+                        }
                     }
                 }
             }
         }
-        // fixed butterfly: acc[L] += acc[L ^ m], m = 32..1  (every lane ends with the same bits)
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
+        for (int rr = 0; rr < R; rr++) {
+            const int64_t r = r0 + rr * tw;
+            if (r >= a.n_rows) break;   // wave-uniform
+            // fixed butterfly: acc[L] += acc[L ^ m], m = 32..1  (every lane ends with the same bits)
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) acc[q] = acc[q] + __shfl_xor(acc[q], m, 64);
-        }
-        const int64_t gi = r * a.idx_mul + a.idx_add;
+            for (int q = 0; q < NQ; q++) {
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            const double s = acc[q];
-            if (key_gt(s, gi, thr_s[q], thr_i[q])) {  // wave-uniform, rare after warm-up; NaN never enters
-                const bool worse = key_gt(s, gi, my_s[q], my_i[q]);
-                const unsigned long long m = __ballot(worse) & ((1ull << K) - 1ull);
-                const int pos = __builtin_ctzll(m);
-                const double up_s = __shfl_up(my_s[q], 1, 64);
-                const int64_t up_i = __shfl_up(my_i[q], 1, 64);
-                if (lane < K) {
-                    if (lane > pos) { my_s[q] = up_s; my_i[q] = up_i; }
-                    else if (lane == pos) { my_s[q] = s; my_i[q] = gi; }
+                for (int m = 32; m >= 1; m >>= 1) acc[rr][q] = acc[rr][q] + __shfl_xor(acc[rr][q], m, 64);
+            }
+            const int64_t gi = r * a.idx_mul + a.idx_add;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const double s = acc[rr][q];
+                if (key_gt(s, gi, thr_s[q], thr_i[q])) {  // wave-uniform, rare after warm-up; NaN never enters
+                    const bool worse = key_gt(s, gi, my_s[q], my_i[q]);
+                    const unsigned long long m = __ballot(worse) & ((1ull << K) - 1ull);
+                    const int pos = __builtin_ctzll(m);
+                    const double up_s = __shfl_up(my_s[q], 1, 64);
+                    const int64_t up_i = __shfl_up(my_i[q], 1, 64);
+                    if (lane < K) {
+                        if (lane > pos) { my_s[q] = up_s; my_i[q] = up_i; }
+                        else if (lane == pos) { my_s[q] = s; my_i[q] = gi; }
+                    }
+                    thr_s[q] = __shfl(my_s[q], K - 1, 64);
+                    thr_i[q] = __shfl(my_i[q], K - 1, 64);
                 }
-                thr_s[q] = __shfl(my_s[q], K - 1, 64);
-                thr_i[q] = __shfl(my_i[q], K - 1, 64);
             }
         }
     }
@@ -250,48 +345,43 @@ __global__ __launch_bounds__(512) void db_scan_topk(ScanArgs a)
             }
             if (ci[0] == bi && cs[0] == bs) { cs[0] = -INFINITY; ci[0] = -1; }
             if (ci[1] == bi && cs[1] == bs) { cs[1] = -INFINITY; ci[1] = -1; }
-            if (lane == 0) store_entry_sc1(outp + j, bs, bi);
+            if (lane == 0) { chip_topk_entry t; t.score = bs; t.idx = bi; outp[j] = t; }
         }
     }
-
-    // ---- publish + ticket (placement-independent; write-through payload, every storing wave drains, ONE ticket) ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int *is_last = reinterpret_cast<int *>(smem + 1024);
-    if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *is_last = (old + 1u == a.ticket_target) ? 1 : 0;   // tickets are cumulative over launches: never reset
-    }
-    __syncthreads();
-    if (*is_last == 0) return;
-    // last arriver: every other block's sc1 stores were drained before its ticket; the sc1 loads below bypass L1
-    merge_sorted_lists<NQ>(a.partial, (int)gridDim.x, K, a.out, a.result, a.l, a.locality, a.thresh, smem);
 }
 
-template <int NQ, int U>
-static int launch_scan_t(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds, bool full)
+template <int NQ, int U, bool FULL, bool NT, int R>
+static int launch_scan_k(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds)
 {
-    if (full) {
-        if (lds > 65536) CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_scan_topk<NQ, U, true>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((db_scan_topk<NQ, U, true>), dim3(grid), dim3(c->scan_block), lds, s, a);
-    } else {
-        if (lds > 65536) CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_scan_topk<NQ, U, false>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((db_scan_topk<NQ, U, false>), dim3(grid), dim3(c->scan_block), lds, s, a);
-    }
+    if (lds > 65536) CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_scan_topk<NQ, U, FULL, NT, R>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((db_scan_topk<NQ, U, FULL, NT, R>), dim3(grid), dim3(c->scan_block), lds, s, a);
     CHIP_HIP(c, hipGetLastError());
     return CHIP_OK;
 }
 
+template <int NQ, int U, bool NT, int R>
+static int launch_scan_t(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds)
+{
+    return a.D % (256 * U) == 0 ? launch_scan_k<NQ, U, true, NT, R>(c, s, a, grid, lds) : launch_scan_k<NQ, U, false, NT, R>(c, s, a, grid, lds);
+}
+
+// scan_variant (CHIP_SCAN_VARIANT, tuning/A-B only): 0 = production (U=8, non-temporal loads, 1 row in flight per wave)
 template <int NQ>
 static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds)
 {
+#ifdef CHIP_SCAN_TUNING_VARIANTS
     switch (c->scan_variant) {
-        case 1: return launch_scan_t<NQ, 4>(c, s, a, grid, lds, a.D % (256 * 4) == 0);
-        case 2: return launch_scan_t<NQ, 16>(c, s, a, grid, lds, a.D % (256 * 16) == 0);
-        default: return launch_scan_t<NQ, 8>(c, s, a, grid, lds, a.D % (256 * 8) == 0);
+        case 1: return launch_scan_t<NQ, 4, true, 1>(c, s, a, grid, lds);
+        case 2: return launch_scan_t<NQ, 16, true, 1>(c, s, a, grid, lds);
+        case 3: return launch_scan_t<NQ, 8, false, 1>(c, s, a, grid, lds);
+        case 4: return launch_scan_t<NQ, 4, true, 2>(c, s, a, grid, lds);
+        case 5: return launch_scan_t<NQ, 8, true, 2>(c, s, a, grid, lds);
+        case 6: return launch_scan_t<NQ, 4, false, 2>(c, s, a, grid, lds);
+        default: break;
     }
+#endif
+    return launch_scan_t<NQ, 8, true, 1>(c, s, a, grid, lds);
 }
 
 int scan_grid_for(const Ctx *c, int64_t n_rows, int /*nq*/)
@@ -311,8 +401,7 @@ int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid)
     size_t lds_q = (size_t)nq * a.D * sizeof(float);
     size_t lds_m = (size_t)wpb * nq * a.K * sizeof(chip_topk_entry);
     size_t lds = lds_q > lds_m ? lds_q : lds_m;
-    if (lds < 2048) lds = 2048;  // merge scratch + ticket flag
-    if (lds > 160 * 1024 || grid > c->scan_block) return CHIP_ERR_UNSUPPORTED;  // the last block holds one list per thread
+    if (lds > 160 * 1024 || grid > 512) return CHIP_ERR_UNSUPPORTED;  // K2 holds one partial list per thread
     switch (nq) {
         case 1: return launch_scan_q<1>(c, s, a, grid, lds);
         case 2: return launch_scan_q<2>(c, s, a, grid, lds);
@@ -323,11 +412,12 @@ int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid)
 }
 
 // ------------------------------------------------------------------------------------------------ K2
-// Stand-alone merge (+ decision) of per-GPU lists after the RCCL all-gather: one workgroup of 512 threads.
+// Merge (+ decision) of the per-workgroup lists of a scan, or of the per-GPU lists after the RCCL all-gather: one
+// workgroup of 512 threads.
 template <int NQ>
 __global__ __launch_bounds__(512) void topk_merge(MergeArgs a)
 {
-    __shared__ __attribute__((aligned(16))) char smem[2048];
+    __shared__ __attribute__((aligned(16))) char smem[kMergeSmem];
     merge_sorted_lists<NQ>(a.in, a.n_lists, a.K, a.out, a.result, a.l, a.locality, a.thresh, smem);
 }
 

@@ -71,8 +71,11 @@ int chip_last_hip_error(const chip_ctx *ctx, const char **text);
 #define CHIP_RING_ROWS 4096
 int  chip_create(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device, int32_t shard_rank, int32_t shard_count);
 void chip_destroy(chip_ctx *ctx);
-/* Run all work of this ctx on an externally owned hipStream_t (e.g. torch's current stream). NULL -> own stream. */
+/* Make an externally owned hipStream_t (e.g. the stream torch.distributed synchronises its collectives with) the
+ * ctx stream: synchronous queries, merges and the stream-ordering promises of chip_scan_local refer to it.  The value
+ * is taken literally: NULL is HIP's null stream.  chip_reset_stream returns to the ctx's private stream. */
 int  chip_set_stream(chip_ctx *ctx, void *hip_stream);
+int  chip_reset_stream(chip_ctx *ctx);
 int  chip_synchronize(chip_ctx *ctx);
 
 /* ------------------------------------------------------------------------------------------ DB append
@@ -135,7 +138,8 @@ typedef struct {
 
 /* Synchronous tick (single-GPU ctx, shard_count == 1). */
 int chip_loop_tick(chip_ctx *ctx, int64_t l, const chip_dot_params *p, chip_tick_result *out);
-/* Pipelined form: enqueue up to CHIP_MAX_INFLIGHT ticks without host synchronisation, collect later. */
+/* Pipelined form: enqueue up to CHIP_MAX_INFLIGHT - 1 ticks without host synchronisation, collect later.  Scans run
+ * back to back on an internal stream; the one-workgroup merge of tick i (ctx stream) overlaps the scan of tick i+1. */
 #define CHIP_MAX_INFLIGHT 64
 int chip_loop_tick_enqueue(chip_ctx *ctx, int64_t l, const chip_dot_params *p, int32_t slot);
 int chip_loop_tick_collect(chip_ctx *ctx, int32_t slot, chip_tick_result *out);
@@ -145,14 +149,20 @@ void chip_loop_reset(chip_ctx *ctx);
 /* Sharded tick, three phases (host does the exchange between 1 and 2):
  *  1. chip_scan_local: scan this rank's share of rows [0,k), k = l - lag, for the three queries l-1,l-2,l-3 and
  *     leave its 3 x topk list (chip_topk_entry, global indices) in DEVICE memory at dev_out (caller-owned,
- *     3*topk*sizeof(chip_topk_entry) bytes), stream-ordered on the ctx stream.  *status gets CHIP_TICK_*;
- *     when it is not CHIP_TICK_SCANNED nothing was enqueued and phases 2-3 are skipped by every rank alike.
- *  2. host: all-gather dev_out of every rank -> gathered[G][3][topk].
- *  3. chip_merge_decide: merge the G lists per query, apply the :1056 criterion, return the result.     */
+ *     3*topk*sizeof(chip_topk_entry) bytes).  *status gets CHIP_TICK_*; when it is not CHIP_TICK_SCANNED nothing was
+ *     enqueued and phases 2-3 are skipped by every rank alike.
+ *     Stream semantics: the list is written by a small merge kernel on the ctx stream (chip_set_stream), so work
+ *     enqueued there afterwards (the all-gather) sees it and dev_out / gathered buffers may be reused every tick.
+ *     The scan itself runs on an internal stream: the next tick's scan overlaps this tick's merge + all-gather.
+ *  2. host: all-gather dev_out of every rank -> gathered[G][3][topk] (on the ctx stream).
+ *  3. chip_merge_decide (synchronous) or chip_merge_decide_enqueue + chip_loop_tick_collect (pipelined):
+ *     merge the G lists per query, apply the :1056 criterion, return the result.                          */
 typedef struct { double score; int64_t idx; } chip_topk_entry;
 int chip_scan_local(chip_ctx *ctx, int64_t l, const chip_dot_params *p, int32_t topk, void *dev_out, int32_t *status);
 int chip_merge_decide(chip_ctx *ctx, int64_t l, const chip_dot_params *p, const void *dev_gathered, int32_t n_lists,
                       int32_t topk, chip_tick_result *out);
+int chip_merge_decide_enqueue(chip_ctx *ctx, int64_t l, const chip_dot_params *p, const void *dev_gathered, int32_t n_lists,
+                              int32_t topk, int32_t slot);
 
 /* ------------------------------------------------------------------------------------------ PnP-RANSAC
  * Replaces the body of StaticTheiaPoseCompute::PNP (src/DlsPnpWithRansac.cpp:192-240): theia::Ransac over
@@ -211,8 +221,10 @@ int chip_get_info(const chip_ctx *ctx, chip_info *info);
 /* Per-kernel timing on the ctx stream (hipEvents bracketing every scan launch). */
 int chip_profile_enable(chip_ctx *ctx, int32_t on);
 int chip_profile_reset(chip_ctx *ctx);
-/* after chip_synchronize: total ms and launch count of the dominant kernel (db_scan_topk) since reset */
-int chip_profile_scan(chip_ctx *ctx, double *total_ms, int64_t *n_launches, double *bytes_per_launch_last);
+/* Sum of the per-launch durations (ms) and launch count of the dominant kernel (db_scan_topk) since reset, plus the
+ * busy span first-start -> last-stop; total_ms / span_ms (the
+ * measured concurrency) stays ~1: scans are serialised on one internal stream. */
+int chip_profile_scan(chip_ctx *ctx, double *total_ms, int64_t *n_launches, double *bytes_per_launch_last, double *span_ms);
 
 #ifdef __cplusplus
 }

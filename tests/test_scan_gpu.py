@@ -296,6 +296,18 @@ def test_sharded_tick_over_rccl_world1():
                 assert g.status == o["status"]
                 if o["status"] == 2:
                     same_tick(g, o)
-            chip.set_stream(None)
+            # pipelined form: scans on the internal lanes overlap the all-gather + merge on torch's stream
+            orc2 = oracle_lib.LoopOracle(db)
+            chip.loop_reset()
+            sched = scenarios.default_schedule(N)
+            for base in range(0, len(sched), 20):
+                chunk = sched[base:base + 20]
+                sts = [det.tick_enqueue(l, s) for s, l in enumerate(chunk)]
+                for s, l in enumerate(chunk):
+                    o = orc2.tick(l)
+                    assert sts[s] == o["status"]
+                    if o["status"] == 2:
+                        same_tick(det.collect(s), o)
+            det.close()
     finally:
         dist.destroy_process_group()

@@ -73,6 +73,13 @@ class OracleShard:
             r.found, r.idx_curr, r.idx_prev, r.score = 1, l - 1, r.argmax[0], r.maxv[0]
         return r
 
+    def merge_decide_enqueue(self, l, gathered_ptr, n_lists, slot, topk, params=None):
+        self.slots = getattr(self, "slots", {})
+        self.slots[slot] = self.merge_decide(l, gathered_ptr, n_lists, topk, params)   # the stand-in is synchronous
+
+    def loop_tick_collect(self, slot):
+        return self.slots.pop(slot)
+
 
 def _worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -93,6 +100,19 @@ def _worker(rank, world, port, ret):
                 assert (g.found, g.idx_curr, g.idx_prev) == (o["found"], o["idx_curr"], o["idx_prev"])
                 n_found += g.found
         assert n_found >= len(loops)
+        # pipelined form (double-buffered lists): same records, collected in enqueue order
+        det2 = sharded.ShardedLoopDetector(OracleShard(db, rank, world), topk=8, device="cpu")
+        orc2 = oracle_lib.LoopOracle(db)
+        sched = scenarios.default_schedule(N)
+        for base in range(0, len(sched), 7):
+            chunk = sched[base:base + 7]
+            sts = [det2.tick_enqueue(l, s) for s, l in enumerate(chunk)]
+            for s, l in enumerate(chunk):
+                o = orc2.tick(l)
+                assert sts[s] == o["status"]
+                if o["status"] == 2:
+                    g = det2.collect(s)
+                    assert (g.found, g.idx_curr, g.idx_prev, list(g.argmax)) == (o["found"], o["idx_curr"], o["idx_prev"], o["argmax"])
         ret[rank] = n_found
     finally:
         dist.destroy_process_group()
