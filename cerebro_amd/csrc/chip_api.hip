@@ -157,7 +157,7 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
     CHIP_HIP(c, hipHostMalloc(&c->flags_host, sizeof(uint32_t), hipHostMallocDefault));
 
     c->scan_block = env_int("CHIP_SCAN_BLOCK", 512);
-    if (c->scan_block != 256 && c->scan_block != 512) c->scan_block = 512;
+    if (c->scan_block != 256 && c->scan_block != 512 && c->scan_block != 768 && c->scan_block != 1024) c->scan_block = 512;
     c->scan_blocks_per_cu = env_int("CHIP_SCAN_BPC", 2);
     if (c->scan_blocks_per_cu < 1) c->scan_blocks_per_cu = 1;
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);

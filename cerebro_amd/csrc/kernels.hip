@@ -202,7 +202,7 @@ __device__ __forceinline__ void merge_sorted_lists(const chip_topk_entry *in, in
 // The cross-workgroup merge (+ accept decision) is K2 on the ctx stream, behind an event, so that it overlaps the
 // NEXT tick's scan (a fused last-workgroup merge was measured to serialise ~28 us per tick).
 template <int NQ, int U, bool FULL, bool NT, int R>
-__global__ __launch_bounds__(512) void db_scan_topk(ScanArgs a)
+__global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *qs = reinterpret_cast<float *>(smem);  // [NQ][D]
@@ -320,11 +320,11 @@ __global__ __launch_bounds__(512) void db_scan_topk(ScanArgs a)
     }
     __syncthreads();
     for (int q = wave; q < NQ; q += wpb) {
-        const int ncand = wpb * K;  // <= 8*16 = 128 -> at most 2 per lane
-        double cs[2];
-        int64_t ci[2];
+        const int ncand = wpb * K;  // <= 16 waves * 16 = 256 -> at most 4 per lane
+        double cs[4];
+        int64_t ci[4];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < 4; h++) {
             const int c = lane + 64 * h;
             if (c < ncand) {
                 const chip_topk_entry t = cand[((c / K) * NQ + q) * K + (c % K)];
@@ -336,15 +336,18 @@ __global__ __launch_bounds__(512) void db_scan_topk(ScanArgs a)
         for (int j = 0; j < K; j++) {
             double bs = cs[0];
             int64_t bi = ci[0];
-            if (key_gt(cs[1], ci[1], bs, bi)) { bs = cs[1]; bi = ci[1]; }
+#pragma unroll
+            for (int h = 1; h < 4; h++)
+                if (key_gt(cs[h], ci[h], bs, bi)) { bs = cs[h]; bi = ci[h]; }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) {
                 const double os = __shfl_xor(bs, m, 64);
                 const int64_t oi = __shfl_xor(bi, m, 64);
                 if (key_gt(os, oi, bs, bi)) { bs = os; bi = oi; }
             }
-            if (ci[0] == bi && cs[0] == bs) { cs[0] = -INFINITY; ci[0] = -1; }
-            if (ci[1] == bi && cs[1] == bs) { cs[1] = -INFINITY; ci[1] = -1; }
+#pragma unroll
+            for (int h = 0; h < 4; h++)
+                if (ci[h] == bi && cs[h] == bs) { cs[h] = -INFINITY; ci[h] = -1; }
             if (lane == 0) { chip_topk_entry t; t.score = bs; t.idx = bi; outp[j] = t; }
         }
     }
