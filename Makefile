@@ -11,7 +11,7 @@ ORCFLAGS   ?= -O2 -ffp-contract=off -fopenmp -fPIC -Wall -Wextra
 
 LIBDIR     := cerebro_amd/lib
 CSRC       := cerebro_amd/csrc
-HIP_SRCS   := $(CSRC)/kernels.hip $(CSRC)/chip_api.hip $(CSRC)/pnp.hip
+HIP_SRCS   := $(CSRC)/kernels.hip $(CSRC)/chip_api.hip $(CSRC)/pnp.hip $(CSRC)/icp.hip
 HIP_OBJS   := $(HIP_SRCS:$(CSRC)/%.hip=$(LIBDIR)/%.o)
 ORC_SRCS   := $(wildcard oracle/*.c)
 
@@ -20,7 +20,7 @@ lib: $(LIBDIR)/libcerebro_hip.so
 oracle: oracle/_build/liboracle.so
 host: $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay
 
-$(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/chip_internal.h include/cerebro_hip.h
+$(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/chip_internal.h $(CSRC)/ransac_common.h include/cerebro_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -30,8 +30,8 @@ $(LIBDIR)/libcerebro_hip.so: $(HIP_OBJS)
 # ---- ROS-free C++ host side (mirror of the Cerebro / StaticTheiaPoseCompute::PNP surface) + replay harness ----
 HOSTDIR    := cerebro_amd/host
 CXX        ?= g++
-$(LIBDIR)/libcerebro_host.so: $(HOSTDIR)/cerebro_host.cc $(HOSTDIR)/cerebro_host.h include/cerebro_hip.h $(LIBDIR)/libcerebro_hip.so
-	$(CXX) -O2 -std=c++17 -fPIC -shared -Wall -Wextra $(HOSTDIR)/cerebro_host.cc -o $@ -L$(LIBDIR) -lcerebro_hip -Wl,-rpath,'$$ORIGIN' -lpthread
+$(LIBDIR)/libcerebro_host.so: $(HOSTDIR)/cerebro_host.cc $(HOSTDIR)/state_json.cc $(HOSTDIR)/cerebro_host.h $(HOSTDIR)/state_json.h include/cerebro_hip.h $(LIBDIR)/libcerebro_hip.so
+	$(CXX) -O2 -std=c++17 -fPIC -shared -Wall -Wextra $(HOSTDIR)/cerebro_host.cc $(HOSTDIR)/state_json.cc -o $@ -L$(LIBDIR) -lcerebro_hip -Wl,-rpath,'$$ORIGIN' -lpthread
 
 $(LIBDIR)/cerebro_replay: $(HOSTDIR)/cerebro_replay.cc $(LIBDIR)/libcerebro_host.so
 	$(CXX) -O2 -std=c++17 -Wall -Wextra $(HOSTDIR)/cerebro_replay.cc -o $@ -L$(LIBDIR) -lcerebro_host -lcerebro_hip -Wl,-rpath,'$$ORIGIN' -lpthread

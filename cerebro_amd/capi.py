@@ -110,6 +110,9 @@ _SIGS = {
     "chip_ransac_params_default": (None, [C.POINTER(RansacParams)]),
     "chip_pnp_ransac": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(RansacParams), _P, C.POINTER(C.c_float), _P,
                                   C.POINTER(RansacSummary)]),
+    "chip_icp_params_default": (None, [C.POINTER(RansacParams)]),
+    "chip_icp_ransac": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(RansacParams), _P, C.POINTER(C.c_float), _P,
+                                  C.POINTER(RansacSummary)]),
     "chip_get_info": (C.c_int, [_P, C.POINTER(Info)]),
     "chip_profile_enable": (C.c_int, [_P, C.c_int32]),
     "chip_profile_reset": (C.c_int, [_P]),
@@ -171,6 +174,12 @@ def default_dot_params() -> DotParams:
 def default_ransac_params() -> RansacParams:
     p = RansacParams()
     load_library().chip_ransac_params_default(C.byref(p))
+    return p
+
+
+def default_icp_params() -> RansacParams:
+    p = RansacParams()
+    load_library().chip_icp_params_default(C.byref(p))
     return p
 
 
@@ -337,6 +346,24 @@ class Chip:
                     summary=dict(n_iterations=summ.n_iterations, n_inliers=summ.n_inliers,
                                  best_hypothesis=summ.best_hypothesis, n_models=summ.n_models,
                                  best_cost=summ.best_cost))
+
+    def icp_ransac(self, A: np.ndarray, B: np.ndarray, params: RansacParams | None = None):
+        A = np.ascontiguousarray(A, dtype=np.float64).reshape(-1, 3)
+        B = np.ascontiguousarray(B, dtype=np.float64).reshape(-1, 3)
+        N = A.shape[0]
+        assert B.shape[0] == N
+        p = params or default_icp_params()
+        T = np.empty(16, dtype=np.float64)
+        conf = C.c_float()
+        mask = np.zeros(max(N, 1), dtype=np.uint8)
+        summ = RansacSummary()
+        st = self.lib.chip_icp_ransac(self.h, _ptr(A), _ptr(B), N, C.byref(p), _ptr(T), C.byref(conf), _ptr(mask), C.byref(summ))
+        if st == CHIP_ERR_TOO_FEW_POINTS:
+            return dict(status=st, confidence=-1.0, T=None, mask=None, summary=None)
+        self._chk(st, "chip_icp_ransac")
+        return dict(status=st, confidence=float(conf.value), T=T.reshape(4, 4).T.copy(), mask=mask[:N].copy(),
+                    summary=dict(n_iterations=summ.n_iterations, n_inliers=summ.n_inliers,
+                                 best_hypothesis=summ.best_hypothesis, n_models=summ.n_models, best_cost=summ.best_cost))
 
     # -- introspection / profiling
     def info(self) -> dict:

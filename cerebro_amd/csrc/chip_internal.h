@@ -120,6 +120,7 @@ struct Ctx {
 
     // --- pnp scratch (pnp.hip) ---
     void *pnp_state = nullptr;
+    void *icp_state = nullptr;   // icp.hip, created on first use
 
     mutable hipError_t last_hip = hipSuccess;
 };
@@ -148,6 +149,7 @@ inline float *row_ptr_host(const Ctx *c, int64_t local) {
 // pnp.hip
 int pnp_create(Ctx *c);
 void pnp_destroy(Ctx *c);
+void icp_destroy(Ctx *c);
 
 }  // namespace chip
 

@@ -1,0 +1,297 @@
+// icp.hip -- batched Umeyama-ICP-in-RANSAC on gfx950: replaces the RANSAC branch of
+// StaticTheiaPoseCompute::P3P_ICP (/root/reference/src/DlsPnpWithRansac.cpp:65-121), i.e. theia::Ransac over the
+// AlignPointCloudsUmeyamaWithRansac estimator (src/DlsPnpWithRansac.h:104-166).
+//
+//   icp_hyp_score : one wave per hypothesis.  Lane 0 draws the 10-point sample (same counter-based sampler as PnP);
+//                   the 3x3 Umeyama solve (means, covariance, fixed-sweep Jacobi SVD, S22 sign, scale) is ~600 flops
+//                   and is computed redundantly by every lane (wave-uniform registers, no LDS traffic, no divergence);
+//                   accept iff min(s, 1/s) > 0.9 (:137); then the L2 error of all N correspondences, MLE cost in the
+//                   fixed lane-strided + butterfly order, inlier words by __ballot.
+//   K7 on the host: ransac_common.h (shared with PnP).
+// fp64, -ffp-contract=off, same operation order as oracle/icp_ransac.c => bit-identical poses and masks.
+#include "ransac_common.h"
+#include <cstring>
+#include <new>
+
+namespace chip {
+
+struct IcpArgs {
+    const double *A;   // N x 3 (frame a)
+    const double *B;   // N x 3 (frame b)
+    int32_t N, S;
+    uint64_t seed;
+    double thresh;
+    int32_t use_mle;
+    int32_t mask_words;
+    double *T_out;     // [H][16]
+    double *cost;      // [H]
+    int32_t *nin;      // [H]
+    int32_t *valid;    // [H]
+    unsigned long long *mask;  // [H][mask_words]
+};
+
+constexpr int kJacobiSweeps = 8;
+
+#define JROT(p, q)                                                                             \
+    do {                                                                                       \
+        const double apq = Am[p][q];                                                           \
+        if (apq != 0.0) {                                                                      \
+            const double theta = (Am[q][q] - Am[p][p]) / (2.0 * apq);                          \
+            const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0)); \
+            const double cc = 1.0 / sqrt(tt * tt + 1.0), ss = tt * cc;                         \
+            for (int r = 0; r < 3; r++) {                                                      \
+                const double arp = Am[r][p], arq = Am[r][q];                                   \
+                Am[r][p] = cc * arp - ss * arq;                                                \
+                Am[r][q] = ss * arp + cc * arq;                                                \
+            }                                                                                  \
+            for (int r = 0; r < 3; r++) {                                                      \
+                const double apr = Am[p][r], aqr = Am[q][r];                                   \
+                Am[p][r] = cc * apr - ss * aqr;                                                \
+                Am[q][r] = ss * apr + cc * aqr;                                                \
+            }                                                                                  \
+            for (int r = 0; r < 3; r++) {                                                      \
+                const double vrp = V[r][p], vrq = V[r][q];                                     \
+                V[r][p] = cc * vrp - ss * vrq;                                                 \
+                V[r][q] = ss * vrp + cc * vrq;                                                 \
+            }                                                                                  \
+        }                                                                                      \
+    } while (0)
+
+#define COLSWAP(i, j)                                                                          \
+    do {                                                                                       \
+        const double tw = w[i]; w[i] = w[j]; w[j] = tw;                                        \
+        for (int r = 0; r < 3; r++) { const double tv = V[r][i]; V[r][i] = V[r][j]; V[r][j] = tv; } \
+    } while (0)
+
+__global__ __launch_bounds__(64) void icp_hyp_score(IcpArgs a)
+{
+    __shared__ int smp[kSampleMax], fy_key[2 * kSampleMax], fy_val[2 * kSampleMax];
+    __shared__ double sa[kSampleMax * 3], sb[kSampleMax * 3];
+    const int lane = threadIdx.x;
+    const int hyp = blockIdx.x;
+    const int n = a.S;
+    if (lane == 0) ransac_sample_sparse(a.seed, hyp, a.N, n, fy_key, fy_val, smp);
+    __syncthreads();
+    if (lane < n) {
+        const int s = smp[lane];
+        for (int k = 0; k < 3; k++) { sa[3 * lane + k] = a.A[3 * s + k]; sb[3 * lane + k] = a.B[3 * s + k]; }
+    }
+    __syncthreads();
+
+    // ---- Umeyama on the sample (every lane computes the same thing) ----
+    double ma[3] = {0.0, 0.0, 0.0}, mb[3] = {0.0, 0.0, 0.0};
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) { ma[k] = ma[k] + sa[3 * i + k]; mb[k] = mb[k] + sb[3 * i + k]; }
+    for (int k = 0; k < 3; k++) { ma[k] = ma[k] / (double)n; mb[k] = mb[k] / (double)n; }
+    double Sg[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}}, var_a = 0.0;
+    for (int i = 0; i < n; i++) {
+        double da[3], db[3];
+        for (int k = 0; k < 3; k++) { da[k] = sa[3 * i + k] - ma[k]; db[k] = sb[3 * i + k] - mb[k]; }
+        var_a = var_a + ((da[0] * da[0] + da[1] * da[1]) + da[2] * da[2]);
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) Sg[r][c] = Sg[r][c] + db[r] * da[c];
+    }
+    var_a = var_a / (double)n;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) Sg[r][c] = Sg[r][c] / (double)n;
+    double Am[3][3], V[3][3], w[3], sig[3], U[3][3];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            Am[r][c] = (Sg[0][r] * Sg[0][c] + Sg[1][r] * Sg[1][c]) + Sg[2][r] * Sg[2][c];
+            V[r][c] = (r == c) ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < kJacobiSweeps; sweep++) { JROT(0, 1); JROT(0, 2); JROT(1, 2); }
+    w[0] = Am[0][0]; w[1] = Am[1][1]; w[2] = Am[2][2];
+    // descending selection sort (ties keep the lower index first), same comparisons as the oracle
+    if (w[1] > w[0]) COLSWAP(0, 1);
+    if (w[2] > w[0]) COLSWAP(0, 2);
+    if (w[2] > w[1]) COLSWAP(1, 2);
+    {
+        const double det = V[0][0] * (V[1][1] * V[2][2] - V[1][2] * V[2][1]) - V[0][1] * (V[1][0] * V[2][2] - V[1][2] * V[2][0]) +
+                           V[0][2] * (V[1][0] * V[2][1] - V[1][1] * V[2][0]);
+        if (det < 0.0)
+            for (int r = 0; r < 3; r++) V[r][2] = -V[r][2];
+    }
+    for (int k = 0; k < 3; k++) sig[k] = sqrt(w[k] > 0.0 ? w[k] : 0.0);
+    bool ok = (sig[1] > 1e-6 * sig[0]) && (sig[0] > 0.0);
+    double R[9], t[3], scale = 0.0;
+    if (ok) {
+        for (int k = 0; k < 2; k++)
+            for (int r = 0; r < 3; r++) U[r][k] = ((Sg[r][0] * V[0][k] + Sg[r][1] * V[1][k]) + Sg[r][2] * V[2][k]) / sig[k];
+        double S22 = 1.0;
+        if (sig[2] > 1e-6 * sig[0]) {
+            for (int r = 0; r < 3; r++) U[r][2] = ((Sg[r][0] * V[0][2] + Sg[r][1] * V[1][2]) + Sg[r][2] * V[2][2]) / sig[2];
+            const double detU = U[0][0] * (U[1][1] * U[2][2] - U[1][2] * U[2][1]) - U[0][1] * (U[1][0] * U[2][2] - U[1][2] * U[2][0]) +
+                                U[0][2] * (U[1][0] * U[2][1] - U[1][1] * U[2][0]);
+            if (detU < 0.0) S22 = -1.0;
+        } else {
+            U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+            U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+            U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+        }
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) R[3 * r + c] = (U[r][0] * V[c][0] + U[r][1] * V[c][1]) + (S22 * U[r][2]) * V[c][2];
+        scale = ((sig[0] + sig[1]) + S22 * sig[2]) / var_a;
+        for (int r = 0; r < 3; r++) t[r] = mb[r] - scale * ((R[3 * r] * ma[0] + R[3 * r + 1] * ma[1]) + R[3 * r + 2] * ma[2]);
+        const double inv = 1.0 / scale;
+        ok = (scale < inv ? scale : inv) > 0.9;   // DlsPnpWithRansac.h:137
+    }
+    if (!ok) {
+        if (lane == 0) { a.valid[hyp] = 0; a.nin[hyp] = 0; a.cost[hyp] = INFINITY; }
+        return;
+    }
+    double T[16];
+    T[0] = R[0]; T[1] = R[3]; T[2] = R[6]; T[3] = 0.0;
+    T[4] = R[1]; T[5] = R[4]; T[6] = R[7]; T[7] = 0.0;
+    T[8] = R[2]; T[9] = R[5]; T[10] = R[8]; T[11] = 0.0;
+    T[12] = t[0]; T[13] = t[1]; T[14] = t[2]; T[15] = 1.0;
+    if (lane == 0)
+        for (int e = 0; e < 16; e++) a.T_out[hyp * 16 + e] = T[e];
+    // ---- Error (L2, DlsPnpWithRansac.h:152-164) over all N + MLE cost ----
+    double acc = 0.0;
+    int cnt = 0;
+    for (int base = 0; base < a.N; base += 64) {
+        const int i = base + lane;
+        bool in = false;
+        if (i < a.N) {
+            const double a0 = a.A[3 * i], a1 = a.A[3 * i + 1], a2 = a.A[3 * i + 2];
+            const double x = ((T[0] * a0 + T[4] * a1) + T[8] * a2) + T[12];
+            const double y = ((T[1] * a0 + T[5] * a1) + T[9] * a2) + T[13];
+            const double z = ((T[2] * a0 + T[6] * a1) + T[10] * a2) + T[14];
+            const double dx = x - a.B[3 * i], dy = y - a.B[3 * i + 1], dz = z - a.B[3 * i + 2];
+            const double rr = sqrt((dx * dx + dy * dy) + dz * dz);
+            in = rr < a.thresh;
+            acc = acc + (in ? rr : a.thresh);
+        }
+        const unsigned long long bw = __ballot(in);
+        cnt += __popcll(bw);
+        if (lane == 0) a.mask[(size_t)hyp * a.mask_words + (base >> 6)] = bw;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc = acc + __shfl_xor(acc, m, 64);
+    if (lane == 0) {
+        a.valid[hyp] = 1;
+        a.nin[hyp] = cnt;
+        a.cost[hyp] = a.use_mle ? acc : (double)(a.N - cnt);
+    }
+}
+
+struct IcpState {
+    double *A = nullptr, *B = nullptr, *T_out = nullptr, *cost = nullptr;
+    int32_t *nin = nullptr, *valid = nullptr;
+    unsigned long long *mask = nullptr;
+    int32_t cap_N = 0, cap_H = 0, cap_words = 0;
+    double *h_cost = nullptr, *h_T = nullptr;
+    int32_t *h_nin = nullptr, *h_valid = nullptr;
+    unsigned long long *h_mask = nullptr;
+};
+
+static void icp_free(IcpState *st)
+{
+    (void)hipFree(st->A); (void)hipFree(st->B); (void)hipFree(st->T_out); (void)hipFree(st->cost);
+    (void)hipFree(st->nin); (void)hipFree(st->valid); (void)hipFree(st->mask);
+    (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid); (void)hipHostFree(st->h_mask);
+    *st = IcpState();
+}
+
+void icp_destroy(Ctx *c)
+{
+    IcpState *st = static_cast<IcpState *>(c->icp_state);
+    if (!st) return;
+    icp_free(st);
+    delete st;
+    c->icp_state = nullptr;
+}
+
+static int icp_reserve(Ctx *c, IcpState *st, int N, int H)
+{
+    const int words = (N + 63) / 64;
+    if (N <= st->cap_N && H <= st->cap_H && words <= st->cap_words) return CHIP_OK;
+    const int nN = N > st->cap_N ? N : st->cap_N, nH = H > st->cap_H ? H : st->cap_H, nW = words > st->cap_words ? words : st->cap_words;
+    icp_free(st);
+    CHIP_HIP(c, hipMalloc(&st->A, sizeof(double) * 3 * (size_t)nN));
+    CHIP_HIP(c, hipMalloc(&st->B, sizeof(double) * 3 * (size_t)nN));
+    CHIP_HIP(c, hipMalloc(&st->T_out, sizeof(double) * 16 * (size_t)nH));
+    CHIP_HIP(c, hipMalloc(&st->cost, sizeof(double) * (size_t)nH));
+    CHIP_HIP(c, hipMalloc(&st->nin, sizeof(int32_t) * (size_t)nH));
+    CHIP_HIP(c, hipMalloc(&st->valid, sizeof(int32_t) * (size_t)nH));
+    CHIP_HIP(c, hipMalloc(&st->mask, sizeof(unsigned long long) * (size_t)nH * nW));
+    CHIP_HIP(c, hipHostMalloc(&st->h_cost, sizeof(double) * (size_t)nH, hipHostMallocDefault));
+    CHIP_HIP(c, hipHostMalloc(&st->h_T, sizeof(double) * 16, hipHostMallocDefault));
+    CHIP_HIP(c, hipHostMalloc(&st->h_nin, sizeof(int32_t) * (size_t)nH, hipHostMallocDefault));
+    CHIP_HIP(c, hipHostMalloc(&st->h_valid, sizeof(int32_t) * (size_t)nH, hipHostMallocDefault));
+    CHIP_HIP(c, hipHostMalloc(&st->h_mask, sizeof(unsigned long long) * (size_t)nW, hipHostMallocDefault));
+    st->cap_N = nN; st->cap_H = nH; st->cap_words = nW;
+    return CHIP_OK;
+}
+
+}  // namespace chip
+
+using namespace chip;
+
+extern "C" void chip_icp_params_default(chip_ransac_params *p)
+{
+    if (!p) return;
+    chip_ransac_params_default(p);
+    p->error_thresh = 0.1;  // DlsPnpWithRansac.cpp:89
+    p->sample_size = 10;    // DlsPnpWithRansac.h:118
+}
+
+extern "C" int chip_icp_ransac(chip_ctx *c, const double *A, const double *B, int32_t N, const chip_ransac_params *p,
+                               double T_colmajor[16], float *confidence, uint8_t *inlier_mask, chip_ransac_summary *summary)
+{
+    if (!c || !A || !B || !p || !T_colmajor || !confidence) return CHIP_ERR_INVALID_ARG;
+    if (N < 20) return CHIP_ERR_TOO_FEW_POINTS;  // DlsPnpWithRansac.cpp:19-22
+    const int32_t S = p->sample_size;
+    if (S < 3 || S > kSampleMax || S > N || p->n_hypotheses < 0 || p->max_iterations < 1) return CHIP_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lk(c->pnp_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    if (!c->icp_state) {
+        c->icp_state = new (std::nothrow) IcpState();
+        if (!c->icp_state) return CHIP_ERR_OOM;
+    }
+    IcpState *st = static_cast<IcpState *>(c->icp_state);
+    const int H = ransac_initial_iterations(p);
+    int rc = icp_reserve(c, st, N, H);
+    if (rc != CHIP_OK) return rc;
+    const int words = (N + 63) / 64;
+    hipStream_t s = c->s_pnp;
+    CHIP_HIP(c, hipMemcpyAsync(st->A, A, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, s));
+    CHIP_HIP(c, hipMemcpyAsync(st->B, B, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, s));
+    IcpArgs a;
+    a.A = st->A; a.B = st->B; a.N = N; a.S = S; a.seed = p->seed; a.thresh = p->error_thresh; a.use_mle = p->use_mle;
+    a.mask_words = words; a.T_out = st->T_out; a.cost = st->cost; a.nin = st->nin; a.valid = st->valid; a.mask = st->mask;
+    hipLaunchKernelGGL(icp_hyp_score, dim3(H), dim3(64), 0, s, a);
+    CHIP_HIP(c, hipGetLastError());
+    CHIP_HIP(c, hipMemcpyAsync(st->h_cost, st->cost, sizeof(double) * (size_t)H, hipMemcpyDeviceToHost, s));
+    CHIP_HIP(c, hipMemcpyAsync(st->h_nin, st->nin, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, s));
+    CHIP_HIP(c, hipMemcpyAsync(st->h_valid, st->valid, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, s));
+    CHIP_HIP(c, hipStreamSynchronize(s));
+    double best_cost = DBL_MAX;
+    int32_t n_models = 0, num_it = 0;
+    const int32_t best_h = ransac_select(p, N, H, st->h_valid, st->h_cost, st->h_nin, &num_it, &n_models, &best_cost);
+    int32_t nin = 0;
+    if (best_h >= 0) {
+        CHIP_HIP(c, hipMemcpyAsync(st->h_T, st->T_out + 16 * (size_t)best_h, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
+        CHIP_HIP(c, hipMemcpyAsync(st->h_mask, st->mask + (size_t)best_h * words, sizeof(unsigned long long) * (size_t)words, hipMemcpyDeviceToHost, s));
+        CHIP_HIP(c, hipStreamSynchronize(s));
+        std::memcpy(T_colmajor, st->h_T, sizeof(double) * 16);
+        nin = st->h_nin[best_h];
+        if (inlier_mask)
+            for (int i = 0; i < N; i++) inlier_mask[i] = (uint8_t)((st->h_mask[i >> 6] >> (i & 63)) & 1ull);
+        const double ratio = (double)nin / (double)N;
+        *confidence = (float)(1.0 - std::pow(1.0 - std::pow(ratio, (double)S), (double)num_it));  // summary.confidence (:121)
+    } else {
+        for (int i = 0; i < 16; i++) T_colmajor[i] = NAN;
+        if (inlier_mask) std::memset(inlier_mask, 0, (size_t)N);
+        *confidence = 0.0f;
+    }
+    if (summary) {
+        summary->n_iterations = num_it;
+        summary->n_inliers = nin;
+        summary->best_hypothesis = best_h;
+        summary->n_models = n_models;
+        summary->best_cost = best_h >= 0 ? best_cost : INFINITY;
+    }
+    return CHIP_OK;
+}

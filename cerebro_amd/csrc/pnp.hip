@@ -17,7 +17,7 @@
 // order as the CPU oracle), lanes only parallelise over independent outputs, so poses and inlier masks are
 // reproducible bit for bit.  Neither HBM nor MFMA bound: ~1.3 MFLOP and ~100 KB of LDS-resident state per
 // hypothesis, latency bound.
-#include "chip_internal.h"
+#include "ransac_common.h"
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -100,19 +100,6 @@ static void build_tables(PnpTables &t)
 }
 
 // ------------------------------------------------------------------------------------------------ device helpers
-__device__ __forceinline__ uint64_t splitmix64_d(uint64_t x)
-{
-    x += 0x9E3779B97F4A7C15ULL;
-    uint64_t z = x;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
-}
-__device__ __forceinline__ uint64_t rng_draw(uint64_t seed, uint32_t hyp, uint32_t draw)
-{
-    return splitmix64_d(seed ^ ((uint64_t)hyp << 32) ^ (uint64_t)draw);
-}
-
 // wave-wide max of a NON-NEGATIVE double (or NaN-free |x|) with DPP row ops; result broadcast via readlane(63).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_max_step(double v)
@@ -139,7 +126,6 @@ __device__ __forceinline__ double wave_max_nonneg(double v)
 }
 
 // ------------------------------------------------------------------------------------------------ K4 + K5a
-constexpr int kSampleMax = 16;   // DlsPnpWithRansac.h:45 uses 15
 constexpr int kLD = 121;         // padded row stride of E (doubles): column walks hit 32 distinct banks
 constexpr int kNR = 93, kNC = 120;
 
@@ -192,24 +178,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
 
     // ---- sampler: partial Fisher-Yates over a virtual identity permutation (theia::RandomSampler restated) ----
     if (tid == 0) {
-        int used = 0;
-        for (int i = 0; i < n; i++) {
-            const uint64_t x = rng_draw(a.seed, (uint32_t)hyp, (uint32_t)i);
-            const int j = i + (int)(x % (uint64_t)(a.N - i));
-            int vi = i, vj = j, pi = -1, pj = -1;
-            for (int e = 0; e < used; e++) {
-                if (fy_key[e] == i) { vi = fy_val[e]; pi = e; }
-                if (fy_key[e] == j) { vj = fy_val[e]; pj = e; }
-            }
-            // idx[i] <- vj ; idx[j] <- vi
-            if (pi < 0) { pi = used++; fy_key[pi] = i; }
-            fy_val[pi] = vj;
-            if (j != i) {
-                if (pj < 0) { pj = used++; fy_key[pj] = j; }
-                fy_val[pj] = vi;
-            }
-            smp[i] = vj;
-        }
+        ransac_sample_sparse(a.seed, hyp, a.N, n, fy_key, fy_val, smp);
         for (int j = 0; j < 4; j++) {   // random linear form f0 (Theia: 100 * Vector4d::Random())
             const uint64_t x = rng_draw(a.seed, (uint32_t)hyp, (uint32_t)(64 + j));
             const double f = (double)(x >> 11) * (1.0 / 9007199254740992.0);
@@ -882,18 +851,6 @@ static int pnp_reserve(Ctx *c, PnpState *st, int N, int H)
     return CHIP_OK;
 }
 
-// theia::SampleConsensusEstimator::ComputeMaxIterations
-static int32_t ransac_max_iterations(int32_t S, double ratio, double log_fail, int32_t min_it, int32_t max_it)
-{
-    if (ratio == 1.0) return min_it;
-    const double log_prob = std::log(1.0 - std::pow(ratio, (double)S)) - DBL_EPSILON;
-    const double itf = std::floor(log_fail / log_prob) + 1.0;
-    int32_t it = (itf > 2.0e9) ? 2000000000 : (int32_t)itf;
-    if (it < min_it) it = min_it;
-    if (it > max_it) it = max_it;
-    return it;
-}
-
 }  // namespace chip
 
 using namespace chip;
@@ -910,15 +867,7 @@ extern "C" int chip_pnp_ransac(chip_ctx *c, const double *X, const double *uv, i
     PnpState *st = static_cast<PnpState *>(c->pnp_state);
     if (!st) return CHIP_ERR_INVALID_ARG;
 
-    const bool bench = p->n_hypotheses > 0;
-    const double log_fail = std::log(p->failure_probability);
-    int32_t max_it;
-    if (bench) max_it = p->n_hypotheses;
-    else {
-        max_it = p->max_iterations;
-        if (p->min_inlier_ratio > 0) max_it = ransac_max_iterations(S, p->min_inlier_ratio, log_fail, p->min_iterations, p->max_iterations);
-    }
-    const int H = max_it;
+    const int H = ransac_initial_iterations(p);
     int rc = pnp_reserve(c, st, N, H);
     if (rc != CHIP_OK) return rc;
     const int words = (N + 63) / 64;
@@ -947,21 +896,8 @@ extern "C" int chip_pnp_ransac(chip_ctx *c, const double *X, const double *uv, i
 
     // K7: theia::Ransac::Estimate's sequential rule replayed over the per-hypothesis results
     double best_cost = DBL_MAX;
-    int32_t best_h = -1, n_models = 0, num_it = 0;
-    for (num_it = 0; num_it < max_it; num_it++) {
-        if (!st->h_valid[num_it]) continue;   // EstimateModel returned false
-        n_models++;
-        const double cost = st->h_cost[num_it];
-        if (cost < best_cost) {               // strict: first best wins
-            best_cost = cost; best_h = num_it;
-            if (!bench) {
-                const double ratio = (double)st->h_nin[num_it] / (double)N;
-                if (ratio < (double)S / (double)N) continue;
-                const int32_t mi = ransac_max_iterations(S, ratio, log_fail, p->min_iterations, p->max_iterations);
-                if (mi < max_it) max_it = mi;
-            }
-        }
-    }
+    int32_t n_models = 0, num_it = 0;
+    const int32_t best_h = ransac_select(p, N, H, st->h_valid, st->h_cost, st->h_nin, &num_it, &n_models, &best_cost);
     int32_t nin = 0;
     if (best_h >= 0) {
         CHIP_HIP(c, hipMemcpyAsync(st->h_T, st->T_out + 16 * (size_t)best_h, sizeof(double) * 16, hipMemcpyDeviceToHost, s));

@@ -1,0 +1,99 @@
+// ransac_common.h -- pieces shared by the batched RANSAC legs (pnp.hip, icp.hip): the counter-based RNG + sampler
+// (device) and theia::Ransac's sequential selection rule replayed on the host (K7).
+#pragma once
+#include "chip_internal.h"
+#include <cfloat>
+#include <cmath>
+
+namespace chip {
+
+constexpr int kSampleMax = 16;   // DlsPnpWithRansac.h:45 uses 15, :118 uses 10
+
+__device__ __forceinline__ uint64_t splitmix64_d(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t rng_draw(uint64_t seed, uint32_t hyp, uint32_t draw)
+{
+    return splitmix64_d(seed ^ ((uint64_t)hyp << 32) ^ (uint64_t)draw);
+}
+
+// theia::RandomSampler restated: partial Fisher-Yates over a VIRTUAL identity permutation of N (only the <= 2S touched
+// positions are materialised in fy_key/fy_val, LDS arrays of >= 2*kSampleMax ints).  Called by ONE lane.
+__device__ __forceinline__ void ransac_sample_sparse(uint64_t seed, int hyp, int N, int S, int *fy_key, int *fy_val, int *smp)
+{
+    int used = 0;
+    for (int i = 0; i < S; i++) {
+        const uint64_t x = rng_draw(seed, (uint32_t)hyp, (uint32_t)i);
+        const int j = i + (int)(x % (uint64_t)(N - i));
+        int vi = i, vj = j, pi = -1, pj = -1;
+        for (int e = 0; e < used; e++) {
+            if (fy_key[e] == i) { vi = fy_val[e]; pi = e; }
+            if (fy_key[e] == j) { vj = fy_val[e]; pj = e; }
+        }
+        if (pi < 0) { pi = used++; fy_key[pi] = i; }   // idx[i] <- vj ; idx[j] <- vi
+        fy_val[pi] = vj;
+        if (j != i) {
+            if (pj < 0) { pj = used++; fy_key[pj] = j; }
+            fy_val[pj] = vi;
+        }
+        smp[i] = vj;
+    }
+}
+
+// theia::SampleConsensusEstimator::ComputeMaxIterations
+inline int32_t ransac_max_iterations(int32_t S, double ratio, double log_fail, int32_t min_it, int32_t max_it)
+{
+    if (ratio == 1.0) return min_it;
+    const double log_prob = std::log(1.0 - std::pow(ratio, (double)S)) - DBL_EPSILON;
+    const double itf = std::floor(log_fail / log_prob) + 1.0;
+    int32_t it = (itf > 2.0e9) ? 2000000000 : (int32_t)itf;
+    if (it < min_it) it = min_it;
+    if (it > max_it) it = max_it;
+    return it;
+}
+
+inline int32_t ransac_initial_iterations(const chip_ransac_params *p)
+{
+    if (p->n_hypotheses > 0) return p->n_hypotheses;
+    int32_t max_it = p->max_iterations;
+    if (p->min_inlier_ratio > 0)
+        max_it = ransac_max_iterations(p->sample_size, p->min_inlier_ratio, std::log(p->failure_probability), p->min_iterations, p->max_iterations);
+    return max_it;
+}
+
+// K7: theia::Ransac::Estimate's sequential rule (strict '<': first best wins; early termination unless benchmark mode)
+// replayed over per-hypothesis results.  Returns the winner (-1: none); *num_it = iterations the reference would run.
+inline int32_t ransac_select(const chip_ransac_params *p, int32_t N, int32_t H, const int32_t *valid, const double *cost,
+                             const int32_t *nin, int32_t *num_it_out, int32_t *n_models_out, double *best_cost_out)
+{
+    const bool bench = p->n_hypotheses > 0;
+    const int32_t S = p->sample_size;
+    const double log_fail = std::log(p->failure_probability);
+    double best_cost = DBL_MAX;
+    int32_t best_h = -1, n_models = 0, num_it = 0, max_it = H;
+    for (num_it = 0; num_it < max_it; num_it++) {
+        if (!valid[num_it]) continue;   // EstimateModel returned false
+        n_models++;
+        if (cost[num_it] < best_cost) {
+            best_cost = cost[num_it];
+            best_h = num_it;
+            if (!bench) {
+                const double ratio = (double)nin[num_it] / (double)N;
+                if (ratio < (double)S / (double)N) continue;
+                const int32_t mi = ransac_max_iterations(S, ratio, log_fail, p->min_iterations, p->max_iterations);
+                if (mi < max_it) max_it = mi;
+            }
+        }
+    }
+    *num_it_out = num_it;
+    *n_models_out = n_models;
+    *best_cost_out = best_cost;
+    return best_h;
+}
+
+}  // namespace chip

@@ -1,5 +1,6 @@
 // cerebro_host.cc -- see cerebro_host.h.  Host bookkeeping only; all arithmetic of the hot path is behind the C ABI.
 #include "cerebro_host.h"
+#include "state_json.h"
 
 #include <chrono>
 #include <cmath>
@@ -31,6 +32,26 @@ bool Cerebro::descriptor_available(const Time &stamp, const double *desc, int n)
     std::lock_guard<std::mutex> lk(m_wholeImageComputedList);  // Cerebro.cpp:321-326
     wholeImageComputedList.push_back(stamp);
     return (int64_t)wholeImageComputedList.size() == first + 1;
+}
+
+int64_t Cerebro::loadStateFromDisk(const std::string &path)
+{
+    if (!ctx_) return -1;
+    StateDescriptors sd;
+    if (!load_state_json(path, sd)) { error_ = sd.error; status_ = CHIP_ERR_INVALID_ARG; return -1; }
+    if (sd.stampNSec.empty()) return 0;
+    if (sd.D != D_) { error_ = "descriptor size in state.json differs from descriptor_size"; status_ = CHIP_ERR_INVALID_ARG; return -1; }
+    int64_t first = -1;
+    status_ = chip_db_append_f64(ctx_, sd.desc.data(), (int64_t)sd.stampNSec.size(), CHIP_APPEND_ALLOW_ROUNDING, &first);
+    if (status_ != CHIP_OK) { error_ = chip_strerror(status_); return -1; }
+    std::lock_guard<std::mutex> lk(m_wholeImageComputedList);
+    for (uint64_t ns : sd.stampNSec) {
+        Time t;
+        t.sec = (uint32_t)(ns / 1000000000ull);   // ros::Time().fromNSec
+        t.nsec = (uint32_t)(ns % 1000000000ull);
+        wholeImageComputedList.push_back(t);
+    }
+    return (int64_t)sd.stampNSec.size();
 }
 
 int Cerebro::wholeImageComputedList_size() const

@@ -50,6 +50,14 @@ public:
     // ---- producer side (desc_th): Cerebro.cpp:268-275 = setWholeImageDescriptor + wholeImageComputedList_pushback
     bool descriptor_available(const Time &stamp, const double *desc, int n);
 
+    // Cold start from a checkpoint written by DataManager::saveStateToDisk: every node that carries a descriptor is
+    // appended in file (= time-stamp) order, as Cerebro rebuilds wholeImageComputedList after loadStateFromDisk
+    // (Cerebro.cpp:133-161).  Eigen's FullPrecision text keeps 15 significant digits, so a float32-valued descriptor
+    // comes back perturbed at ~1e-16 relative; the append therefore rounds to the nearest float32, which recovers
+    // the original value exactly.  Returns the number of descriptors loaded, or -1 (see last_status()/last_error()).
+    int64_t loadStateFromDisk(const std::string &state_json_path);
+    const std::string &last_error() const { return error_; }
+
     // ---- thread-safe accessors (Cerebro.h:105-106)
     int wholeImageComputedList_size() const;
     Time wholeImageComputedList_at(int k) const;
@@ -77,6 +85,7 @@ private:
     chip_ctx *ctx_ = nullptr;
     int status_ = 0;
     int D_ = 0;
+    std::string error_;
     mutable std::mutex m_wholeImageComputedList;
     std::vector<Time> wholeImageComputedList;
     mutable std::mutex m_foundLoops;

@@ -203,6 +203,18 @@ int chip_pnp_ransac(chip_ctx *ctx, const double *X, const double *uv, int32_t N,
                     double T_colmajor[16], float *confidence, uint8_t *inlier_mask /* N bytes, may be NULL */,
                     chip_ransac_summary *summary /* may be NULL */);
 
+/* ------------------------------------------------------------------------------------------ Umeyama-ICP-RANSAC
+ * Replaces the RANSAC branch of StaticTheiaPoseCompute::P3P_ICP (src/DlsPnpWithRansac.cpp:65-121): theia::Ransac over
+ * AlignPointCloudsUmeyamaWithRansac (src/DlsPnpWithRansac.h:104-166): 10-point sample -> AlignPointCloudsUmeyama ->
+ * accept iff min(s, 1/s) > 0.9 (:137) -> b_T_a = [R t] -> L2 error (:152-164), threshold 0.1, MLE score.
+ *   A, B : N x 3 row-major, the same 3-D points expressed in frames a and b (uv_X, uvd_Y, :15-16)
+ * Status / T / confidence / mask / summary conventions are those of chip_pnp_ransac (N < 20 -> CHIP_ERR_TOO_FEW_POINTS,
+ * :19-22).  chip_icp_params_default = chip_ransac_params_default with error_thresh 0.1 (:89) and sample_size 10 (.h:118). */
+void chip_icp_params_default(chip_ransac_params *p);
+int chip_icp_ransac(chip_ctx *ctx, const double *A, const double *B, int32_t N, const chip_ransac_params *p,
+                    double T_colmajor[16], float *confidence, uint8_t *inlier_mask /* N bytes, may be NULL */,
+                    chip_ransac_summary *summary /* may be NULL */);
+
 /* ------------------------------------------------------------------------------------------ introspection */
 typedef struct {
     int32_t abi_version;

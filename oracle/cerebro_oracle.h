@@ -127,6 +127,16 @@ int32_t orc_ransac_max_iterations(int32_t S, double ratio, double log_fail, int3
 int    orc_pnp_ransac(const double *X, const double *uv, int32_t N, const orc_ransac_params *p,
                       double T[16], float *confidence, uint8_t *mask, orc_ransac_summary *summary);
 
+/* ================================================================== Umeyama-ICP / RANSAC (icp_ransac.c) */
+int    orc_umeyama(const double *a, const double *b, int32_t n, double R[9], double t[3], double *scale);
+double orc_icp_error(const double *T_colmajor, const double *a, const double *b);
+void   orc_icp_score_model(const double *T_colmajor, const double *A, const double *B, int32_t N, double thresh, int32_t use_mle,
+                           double *cost, int32_t *n_inliers, uint8_t *mask);
+int    orc_icp_hypothesis(const double *A, const double *B, int32_t N, uint64_t seed, int32_t hyp, int32_t S, double T[16], double *scale_out);
+void   orc_icp_params_default(orc_ransac_params *p);
+int    orc_icp_ransac(const double *A, const double *B, int32_t N, const orc_ransac_params *p,
+                      double T[16], float *confidence, uint8_t *mask, orc_ransac_summary *summary);
+
 #ifdef __cplusplus
 }
 #endif

@@ -266,3 +266,55 @@ def pnp_ransac(X, uv, params: OrcRansacParams | None = None):
     return dict(status=rc, confidence=float(conf.value), T=T.reshape(4, 4).T.copy(), mask=mask[:X.shape[0]].copy(),
                 summary=dict(n_iterations=s.n_iterations, n_inliers=s.n_inliers, best_hypothesis=s.best_hypothesis,
                              n_models=s.n_models, best_cost=s.best_cost))
+
+
+# ================================================================== Umeyama-ICP oracle bindings
+def _bind_icp():
+    lib = _bind_pnp()
+    if getattr(lib, "_icp_bound", False):
+        return lib
+    V = C.c_void_p
+    lib.orc_umeyama.restype = C.c_int
+    lib.orc_umeyama.argtypes = [V, V, C.c_int32, V, V, C.POINTER(C.c_double)]
+    lib.orc_icp_error.restype = C.c_double
+    lib.orc_icp_error.argtypes = [V, V, V]
+    lib.orc_icp_hypothesis.restype = C.c_int
+    lib.orc_icp_hypothesis.argtypes = [V, V, C.c_int32, C.c_uint64, C.c_int32, C.c_int32, V, C.POINTER(C.c_double)]
+    lib.orc_icp_params_default.argtypes = [C.POINTER(OrcRansacParams)]
+    lib.orc_icp_ransac.restype = C.c_int
+    lib.orc_icp_ransac.argtypes = [V, V, C.c_int32, C.POINTER(OrcRansacParams), V, C.POINTER(C.c_float), V, C.POINTER(OrcRansacSummary)]
+    lib._icp_bound = True
+    return lib
+
+
+def icp_params(**kw) -> OrcRansacParams:
+    p = OrcRansacParams()
+    _bind_icp().orc_icp_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def umeyama(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+    R = np.empty(9); t = np.empty(3); s = C.c_double()
+    rc = _bind_icp().orc_umeyama(_p(a), _p(b), a.shape[0], _p(R), _p(t), C.byref(s))
+    return rc, R.reshape(3, 3), t, s.value
+
+
+def icp_hypothesis(A, B, seed, hyp, S=10):
+    A = np.ascontiguousarray(A, dtype=np.float64); B = np.ascontiguousarray(B, dtype=np.float64)
+    T = np.empty(16); s = C.c_double()
+    ok = _bind_icp().orc_icp_hypothesis(_p(A), _p(B), A.shape[0], seed, hyp, S, _p(T), C.byref(s))
+    return ok, T.reshape(4, 4).T.copy(), s.value
+
+
+def icp_ransac(A, B, params: OrcRansacParams | None = None):
+    A = np.ascontiguousarray(A, dtype=np.float64).reshape(-1, 3)
+    B = np.ascontiguousarray(B, dtype=np.float64).reshape(-1, 3)
+    p = params or icp_params()
+    T = np.empty(16); conf = C.c_float(); mask = np.zeros(max(1, A.shape[0]), dtype=np.uint8); s = OrcRansacSummary()
+    rc = _bind_icp().orc_icp_ransac(_p(A), _p(B), A.shape[0], C.byref(p), _p(T), C.byref(conf), _p(mask), C.byref(s))
+    return dict(status=rc, confidence=float(conf.value), T=T.reshape(4, 4).T.copy(), mask=mask[:A.shape[0]].copy(),
+                summary=dict(n_iterations=s.n_iterations, n_inliers=s.n_inliers, best_hypothesis=s.best_hypothesis,
+                             n_models=s.n_models, best_cost=s.best_cost))

@@ -72,3 +72,72 @@ def test_replay_matches_oracle(tmp_path):
         for k, v in w.items():
             assert g[k] == v, (k, g, w)            # score round-trips exactly through %.17g
         assert g["time_double_a"] == pytest.approx(w["time_sec_a"] + 1e-9 * w["time_nsec_a"])
+
+
+# ------------------------------------------------------------------ N1: state.json cold start
+def write_state_json(path, db, stamps_nsec, has_desc=None, digits=15):
+    """Same structure as DataManager::saveStateToDisk (DataManager.cpp:1098-1215): nlohmann dump(4); descriptor text is
+    Eigen IOFormat(FullPrecision, DontAlignCols, ", ", "\\n") = one value per line with 15 significant digits."""
+    nodes = []
+    for i, ns in enumerate(stamps_nsec):
+        node = {"stampNSec": int(ns), "stamp_relative": i * 0.05, "seq": i, "isKeyFrame": True,
+                "getNumberOfSuccessfullyTrackedFeatures": 77, "isPoseAvailable": True,
+                "w_T_c": {"rows": 4, "cols": 4, "stampNSec": int(ns), "data": "1, 0, 0, 0\n0, 1, 0, 0\n0, 0, 1, 0\n0, 0, 0, 1",
+                          "data_pretty": ":YPR(deg)=(0,0,0)  \"quoted\" \\ back"}}
+        avail = has_desc is None or has_desc[i]
+        if avail:
+            node["wholeImageDescriptor"] = {"rows": db.shape[1], "cols": 1,
+                                            "data": "\n".join(f"{float(v):.{digits}g}" for v in db[i])}
+        node["isWholeImageDescriptorAvailable"] = bool(avail)
+        nodes.append(node)
+    doc = {"DataNodes": nodes, "ImageDataManager": {"stash": [{"a": [1, 2, {"b": None}]}], "n": 3}}
+    Path(path).write_text(json.dumps(doc, indent=4))
+    return doc
+
+
+def test_state_json_parser_matches_python(tmp_path):
+    D, N = 64, 40
+    db = scenarios.build_db(3, N, D, [])
+    stamps = [1403636579_000000000 + i * 50_000_000 for i in range(N)]
+    has = [i % 5 != 2 for i in range(N)]                               # some nodes are not keyframes / have no descriptor
+    doc = write_state_json(tmp_path / "state.json", db, stamps, has)
+    r = subprocess.run([str(LIB / "cerebro_replay"), "--parse-only", str(tmp_path / "state.json"), str(tmp_path / "o.bin")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = (tmp_path / "o.bin").read_bytes()
+    Dg, n = struct.unpack_from("<IQ", raw, 0)
+    assert Dg == D and n == sum(has)
+    got_stamps = np.frombuffer(raw, dtype=np.uint64, count=n, offset=12)
+    got = np.frombuffer(raw, dtype=np.float64, count=n * D, offset=12 + 8 * n).reshape(n, D)
+    want_stamps = [s for s, h in zip(stamps, has) if h]
+    want = np.array([[float(x) for x in nd["wholeImageDescriptor"]["data"].split("\n")] for nd in doc["DataNodes"] if "wholeImageDescriptor" in nd])
+    assert list(got_stamps) == want_stamps
+    assert got.tobytes() == want.tobytes()                              # strtod == Python float(): both correctly rounded
+    # 15 significant digits do not round-trip a double, but rounding to float32 recovers the original descriptor
+    orig = db[[i for i in range(N) if has[i]]]
+    assert not np.array_equal(got, orig.astype(np.float64))
+    assert np.array_equal(got.astype(np.float32), orig)
+    # malformed input is an error, not a crash
+    (tmp_path / "bad.json").write_text('{"DataNodes": [ {"stampNSec": 5, "wholeImageDescriptor": {"rows": 3, "cols": 1, "data": "1\\n2"}} ]}')
+    r = subprocess.run([str(LIB / "cerebro_replay"), "--parse-only", str(tmp_path / "bad.json"), str(tmp_path / "o2.bin")], capture_output=True, text=True)
+    assert r.returncode == 6 and "rows*cols" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cold_start_from_state_json_matches_oracle(tmp_path):
+    D, N = 1024, 700
+    plants, loops, ties = scenarios.loop_plants(N, 4, seed=8)
+    db = scenarios.build_db(19, N, D, plants)
+    stamps = [1403636579_000000000 + i * 50_000_000 for i in range(N)]
+    write_state_json(tmp_path / "state.json", db, stamps)
+    r = subprocess.run([str(LIB / "cerebro_replay"), "--state", str(tmp_path / "state.json"), str(tmp_path / "o.json")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = json.loads((tmp_path / "o.json").read_text())
+    orc = oracle_lib.LoopOracle(db)                                     # the float32 descriptors the checkpoint was made from
+    want = []
+    for l in range(56, N + 1, 3):
+        o = orc.tick(l)
+        if o["found"]:
+            want.append((o["idx_curr"], o["idx_prev"], o["score"]))
+    assert [(g["global_a"], g["global_b"], g["score"]) for g in got] == want and len(want) >= len(loops)
+    assert got[0]["time_sec_a"] == stamps[want[0][0]] // 10**9 and got[0]["time_nsec_a"] == stamps[want[0][0]] % 10**9
