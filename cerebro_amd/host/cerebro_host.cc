@@ -158,6 +158,125 @@ float StaticTheiaPoseCompute::PNP(chip_ctx *ctx, const std::vector<std::array<do
     return confidence;  // summary.confidence (:240)
 }
 
+float StaticTheiaPoseComputeICP::P3P_ICP(chip_ctx *ctx, const std::vector<std::array<double, 3>> &uv_X, const std::vector<std::array<double, 3>> &uvd_Y,
+                                         double uvd_T_uv[16], std::string &p3p__msg, const chip_ransac_params *params)
+{
+    if (uv_X.size() < 20) return -1;  // DlsPnpWithRansac.cpp:19-22
+    p3p__msg = "";
+    if (!ctx || uv_X.size() != uvd_Y.size()) return -1;
+    chip_ransac_params p;
+    if (params) p = *params; else chip_icp_params_default(&p);  // :88-93
+    float confidence = 0.f;
+    chip_ransac_summary s;
+    const int st = chip_icp_ransac(ctx, &uv_X[0][0], &uvd_Y[0][0], (int32_t)uv_X.size(), &p, uvd_T_uv, &confidence, nullptr, &s);
+    if (st != CHIP_OK) { p3p__msg = std::string("chip_icp_ransac: ") + chip_strerror(st); return -1; }
+    p3p__msg += "ICP Ransac;     #iterations=" + std::to_string(s.n_iterations) + "    confidence=" + std::to_string(confidence);  // :115-118
+    return confidence;  // :121
+}
+
+void matrix4_inverse_rigid(const double T[16], double I[16])
+{
+    // [R t; 0 1]^-1 = [R^T  -R^T t; 0 1]   (the reference calls Eigen's general Matrix4d::inverse(); identical up to rounding
+    // for the proper rigid transforms that reach this code)
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) I[4 * c + r] = T[4 * r + c];
+    for (int r = 0; r < 3; r++) I[12 + r] = -(I[r] * T[12] + I[4 + r] * T[13] + I[8 + r] * T[14]);
+    I[3] = I[7] = I[11] = 0.0;
+    I[15] = 1.0;
+}
+
+void matrix4_mul(const double A[16], const double B[16], double C[16])
+{
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += A[4 * k + r] * B[4 * c + k];
+            C[4 * c + r] = s;
+        }
+}
+
+void matrix4_to_rawyprt(const double T[16], double ypr[3], double t[3])
+{
+    // n, o, a = columns 0, 1, 2 of R (PoseManipUtils.cpp:150-157)
+    const double n0 = T[0], n1 = T[1], n2 = T[2], o0 = T[4], o1 = T[5], a0 = T[8], a1 = T[9];
+    const double y = std::atan2(n1, n0);
+    const double p = std::atan2(-n2, n0 * std::cos(y) + n1 * std::sin(y));
+    const double r = std::atan2(a0 * std::sin(y) - a1 * std::cos(y), -o0 * std::sin(y) + o1 * std::cos(y));
+    ypr[0] = y / M_PI * 180.0; ypr[1] = p / M_PI * 180.0; ypr[2] = r / M_PI * 180.0;  // :162
+    t[0] = T[12]; t[1] = T[13]; t[2] = T[14];
+}
+
+bool ProcessedLoopCandidate::makeLoopEdgeMsg(LoopEdgePOD &msg) const
+{
+    if (!isSet_3d2d__2T1) return false;  // ProcessedLoopCandidate.cpp:18-23
+    msg = make_loop_edge(t_node_1, t_node_2, _3d2d__2T1.data(), _3d2d__2T1__ransac_confidence, idx_from_datamanager_1, idx_from_datamanager_2);
+    return true;
+}
+
+static double inf_norm3(const double v[3])
+{
+    double m = std::fabs(v[0]);
+    if (std::fabs(v[1]) > m) m = std::fabs(v[1]);
+    if (std::fabs(v[2]) > m) m = std::fabs(v[2]);
+    return m;
+}
+
+bool ProcessedLoopCandidate::makeLoopEdgeMsgWithConsistencyCheck(LoopEdgePOD &msg)
+{
+    if (opX_b_T_a.size() != 3) return false;  // :42-46
+    // ros::Duration diff = node_1->getT() - node_2->getT(); if( abs(diff.sec) < 10 ) return false;  (:49-56)
+    // ros::Duration is normalised to sec = floor(seconds), 0 <= nsec < 1e9
+    int64_t dns = ((int64_t)t_node_1.sec - (int64_t)t_node_2.sec) * 1000000000ll + ((int64_t)t_node_1.nsec - (int64_t)t_node_2.nsec);
+    int64_t dsec = dns / 1000000000ll;
+    if (dns % 1000000000ll < 0) dsec -= 1;
+    if ((dsec < 0 ? -dsec : dsec) < 10) return false;
+
+    const double *op1 = opX_b_T_a[0].data(), *op2 = opX_b_T_a[1].data(), *icp = opX_b_T_a[2].data();
+    double op1_inv[16], op2_inv[16], d12[16], d1i[16], d2i[16];
+    matrix4_inverse_rigid(op1, op1_inv);
+    matrix4_inverse_rigid(op2, op2_inv);
+    matrix4_mul(op1_inv, op2, d12);   // op1_m_op2 (:64)
+    matrix4_mul(op1_inv, icp, d1i);   // op1_m_icp (:65)
+    matrix4_mul(op2_inv, icp, d2i);   // op2_m_icp (:66)
+    double y12[3], t12[3], y1i[3], t1i[3], y2i[3], t2i[3];
+    matrix4_to_rawyprt(d12, y12, t12);
+    matrix4_to_rawyprt(d1i, y1i, t1i);
+    matrix4_to_rawyprt(d2i, y2i, t2i);
+    const bool is_consistent_ypr = inf_norm3(y12) < 5.0 && inf_norm3(y1i) < 5.0 && inf_norm3(y2i) < 5.0;  // :75-79
+    const bool is_consistent_tr = inf_norm3(t1i) < .2 && inf_norm3(t1i) < .2 && inf_norm3(t2i) < .2;       // :81-85 (sic: op1_m_icp twice)
+    if (pf_matches > 800 && (is_consistent_ypr && is_consistent_tr)) {  // :112
+        _3d2d__2T1 = opX_b_T_a[0];
+        isSet_3d2d__2T1 = true;
+        float g = opX_goodness[0];
+        if (opX_goodness[1] > g) g = opX_goodness[1];
+        if (opX_goodness[2] > g) g = opX_goodness[2];
+        _3d2d__2T1__ransac_confidence = g;  // :116
+        return makeLoopEdgeMsg(msg);
+    }
+    return false;
+}
+
+bool compute_three_way_pose(chip_ctx *ctx, const PosePairInput &in, ProcessedLoopCandidate &pc, uint64_t seed)
+{
+    chip_ransac_params pp, pi;
+    chip_ransac_params_default(&pp);
+    chip_icp_params_default(&pi);
+    if (seed) { pp.seed = seed; pi.seed = seed ^ 0x9E3779B97F4A7C15ull; }
+    std::array<double, 16> op1{}, op2_a_T_b{}, op2{}, icp{};
+    std::string m1, m2, m3;
+    const float g1 = StaticTheiaPoseCompute::PNP(ctx, in.world_point_uv, in.feature_position_uv_d, op1.data(), m1, &pp);          // Cerebro.cpp:1518
+    pp.seed += 1;
+    const float g2 = StaticTheiaPoseCompute::PNP(ctx, in.world_point_uv_d, in.feature_position_uv, op2_a_T_b.data(), m2, &pp);   // :1572
+    matrix4_inverse_rigid(op2_a_T_b.data(), op2.data());                                                                          // :1582
+    const float g3 = StaticTheiaPoseComputeICP::P3P_ICP(ctx, in.uv_X, in.uvd_Y, icp.data(), m3, &pi);                               // :1629
+    for (int i = 0; i < 16; i++)  // :1678  op != op  <=> any NaN
+        if (op1[i] != op1[i] || op2[i] != op2[i] || icp[i] != icp[i]) return false;
+    if (g1 < 0 || g2 < 0 || g3 < 0) return false;  // a too-small set leaves the pose untouched in the reference; treat as no pose
+    pc.opX_b_T_a = {op1, op2, icp};       // :1706-1719
+    pc.opX_goodness = {g1, g2, g3};
+    return true;
+}
+
 void matrix4_to_pose(const double T[16], double position[3], double q[4])
 {
     position[0] = T[12]; position[1] = T[13]; position[2] = T[14];

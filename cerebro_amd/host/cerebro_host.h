@@ -101,6 +101,52 @@ struct StaticTheiaPoseCompute {
                      const chip_ransac_params *params = nullptr, std::vector<uint8_t> *inliers = nullptr);
 };
 
+struct StaticTheiaPoseComputeICP {
+    // float P3P_ICP(uv_X, uvd_Y, uvd_T_uv, p3p__msg)  (DlsPnpWithRansac.cpp:16-122, RANSAC branch).  Same conventions as PNP.
+    static float P3P_ICP(chip_ctx *ctx, const std::vector<std::array<double, 3>> &uv_X, const std::vector<std::array<double, 3>> &uvd_Y,
+                         double uvd_T_uv[16], std::string &p3p__msg, const chip_ransac_params *params = nullptr);
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row N3: what happens right after the path -- the three-way consistency gate and the LoopEdge message.
+// Mirrors ProcessedLoopCandidate (src/ProcessedLoopCandidate.{h,cpp}) and the pose part of
+// Cerebro::process_loop_candidate_imagepair_consistent_pose_compute (src/Cerebro.cpp:1512-1719).
+struct ProcessedLoopCandidate {
+    Time t_node_1, t_node_2;                       // node_1->getT(), node_2->getT()
+    int idx_from_datamanager_1 = -1, idx_from_datamanager_2 = -1;
+    int pf_matches = 0;                            // number of GMS point-feature matches (Cerebro.cpp:1505)
+    std::vector<std::array<double, 16>> opX_b_T_a; // op1__b_T_a, op2__b_T_a, icp_b_T_a (column-major)
+    std::vector<float> opX_goodness;
+    // results of the gate
+    bool isSet_3d2d__2T1 = false;
+    std::array<double, 16> _3d2d__2T1{};
+    float _3d2d__2T1__ransac_confidence = 0.f;
+
+    // ProcessedLoopCandidate.cpp:16-36
+    bool makeLoopEdgeMsg(LoopEdgePOD &msg) const;
+    // ProcessedLoopCandidate.cpp:40-125: 3 candidates; |dt| >= 10 s; pairwise |ypr|_inf < 5 deg and |t|_inf < 0.2 m
+    // (the reference tests op1_m_icp_tr twice instead of op1_m_op2_tr -- kept); pf_matches > 800.
+    bool makeLoopEdgeMsgWithConsistencyCheck(LoopEdgePOD &msg);
+};
+
+// 3-D/2-D and 3-D/3-D correspondence sets of an image pair, in the layout StaticPointFeatureMatching produces
+// (src/utils/PointFeatureMatching.cpp:95-195): points of frame a with their normalized projections in b, and vice versa.
+struct PosePairInput {
+    std::vector<std::array<double, 3>> world_point_uv;       // a_X       (Cerebro.cpp:1512)
+    std::vector<std::array<double, 2>> feature_position_uv_d; // uv in b
+    std::vector<std::array<double, 3>> world_point_uv_d;     // b_X       (Cerebro.cpp:1566)
+    std::vector<std::array<double, 2>> feature_position_uv;   // uv in a
+    std::vector<std::array<double, 3>> uv_X, uvd_Y;          // 3d-3d     (Cerebro.cpp:1629)
+};
+// PNP(a->b) (:1518), PNP(b->a) inverted (:1572,:1582), P3P_ICP (:1629), NaN gate (:1678), push of the 3 poses (:1706-1719).
+// Returns false when one of the three poses has NaN/Inf (the candidate is skipped).
+bool compute_three_way_pose(chip_ctx *ctx, const PosePairInput &in, ProcessedLoopCandidate &proc_candi, uint64_t seed = 0);
+
+// PoseManipUtils::R2ypr (src/utils/PoseManipUtils.cpp:148-163), degrees, from a column-major 4x4
+void matrix4_to_rawyprt(const double T_colmajor[16], double ypr_deg[3], double t[3]);
+void matrix4_inverse_rigid(const double T[16], double Tinv[16]);
+void matrix4_mul(const double A[16], const double B[16], double C[16]);
+
 // geometry_msgs::Pose from a column-major 4x4 (PoseManipUtils::eigenmat_to_geometry_msgs_Pose,
 // src/utils/PoseManipUtils.cpp:31-45: position = T(0..2,3), orientation = Quaterniond(T.topLeftCorner<3,3>()))
 void matrix4_to_pose(const double T_colmajor[16], double position[3], double orientation_xyzw[4]);

@@ -53,8 +53,89 @@ static int from_state(const char *in, const char *outp, int device)
     return 0;
 }
 
+// --gate <in.txt> : no GPU.  One candidate per line: sec1 nsec1 sec2 nsec2 idx1 idx2 pf_matches g1 g2 g3 then 3 x 16 doubles
+// (column-major op1, op2, icp).  Prints one JSON object per line with the gate decision and the LoopEdge fields.
+static int gate(const char *in)
+{
+    FILE *f = std::fopen(in, "r");
+    if (!f) { std::perror(in); return 2; }
+    for (;;) {
+        cerebro_hip::ProcessedLoopCandidate pc;
+        unsigned s1, n1, s2, n2;
+        float g[3];
+        if (std::fscanf(f, "%u %u %u %u %d %d %d %f %f %f", &s1, &n1, &s2, &n2, &pc.idx_from_datamanager_1, &pc.idx_from_datamanager_2,
+                        &pc.pf_matches, &g[0], &g[1], &g[2]) != 10) break;
+        pc.t_node_1.sec = s1; pc.t_node_1.nsec = n1; pc.t_node_2.sec = s2; pc.t_node_2.nsec = n2;
+        for (int k = 0; k < 3; k++) {
+            std::array<double, 16> T;
+            for (int e = 0; e < 16; e++)
+                if (std::fscanf(f, "%lf", &T[e]) != 1) { std::fprintf(stderr, "bad matrix\n"); return 2; }
+            pc.opX_b_T_a.push_back(T);
+            pc.opX_goodness.push_back(g[k]);
+        }
+        cerebro_hip::LoopEdgePOD e;
+        const bool ok = pc.makeLoopEdgeMsgWithConsistencyCheck(e);
+        if (!ok) { std::printf("{\"ok\": false}\n"); continue; }
+        std::printf("{\"ok\": true, \"sec0\": %u, \"nsec0\": %u, \"sec1\": %u, \"nsec1\": %u, \"position\": [%.17g, %.17g, %.17g], "
+                    "\"orientation_xyzw\": [%.17g, %.17g, %.17g, %.17g], \"weight\": %.9g, \"description\": \"%s\"}\n",
+                    e.timestamp0.sec, e.timestamp0.nsec, e.timestamp1.sec, e.timestamp1.nsec, e.position[0], e.position[1], e.position[2],
+                    e.orientation_xyzw[0], e.orientation_xyzw[1], e.orientation_xyzw[2], e.orientation_xyzw[3], (double)e.weight, e.description.c_str());
+    }
+    std::fclose(f);
+    return 0;
+}
+
+// --threeway <in.bin> [device] : GPU.  in.bin: u32 N, u32 pf_matches, u64 seed, then N x {3,2,3,2,3,3} f64 arrays
+// (world_point_uv, feature_position_uv_d, world_point_uv_d, feature_position_uv, uv_X, uvd_Y).  Runs the three estimators
+// and the consistency gate exactly as the loop-candidate consumer does and prints the result as JSON.
+static int threeway(const char *in, int device)
+{
+    FILE *f = std::fopen(in, "rb");
+    if (!f) { std::perror(in); return 2; }
+    uint32_t N = 0, pf = 0;
+    uint64_t seed = 0;
+    if (std::fread(&N, 4, 1, f) != 1 || std::fread(&pf, 4, 1, f) != 1 || std::fread(&seed, 8, 1, f) != 1) return 2;
+    cerebro_hip::PosePairInput inp;
+    inp.world_point_uv.resize(N); inp.feature_position_uv_d.resize(N); inp.world_point_uv_d.resize(N);
+    inp.feature_position_uv.resize(N); inp.uv_X.resize(N); inp.uvd_Y.resize(N);
+    bool ok = std::fread(inp.world_point_uv.data(), 24, N, f) == N && std::fread(inp.feature_position_uv_d.data(), 16, N, f) == N &&
+              std::fread(inp.world_point_uv_d.data(), 24, N, f) == N && std::fread(inp.feature_position_uv.data(), 16, N, f) == N &&
+              std::fread(inp.uv_X.data(), 24, N, f) == N && std::fread(inp.uvd_Y.data(), 24, N, f) == N;
+    std::fclose(f);
+    if (!ok) { std::fprintf(stderr, "truncated input\n"); return 2; }
+    chip_ctx *ctx = nullptr;
+    const int st = chip_create(&ctx, 64, 0, device, 0, 1);
+    if (st != CHIP_OK) { std::fprintf(stderr, "chip_create failed: %s\n", chip_strerror(st)); return 3; }
+    cerebro_hip::ProcessedLoopCandidate pc;
+    pc.t_node_1.sec = 1403636700; pc.t_node_2.sec = 1403636600;
+    pc.idx_from_datamanager_1 = 2100; pc.idx_from_datamanager_2 = 100;
+    pc.pf_matches = (int)pf;
+    const bool have = cerebro_hip::compute_three_way_pose(ctx, inp, pc, seed);
+    std::printf("{\"have_poses\": %s", have ? "true" : "false");
+    if (have) {
+        std::printf(", \"goodness\": [%.9g, %.9g, %.9g], \"poses\": [", (double)pc.opX_goodness[0], (double)pc.opX_goodness[1], (double)pc.opX_goodness[2]);
+        for (int k = 0; k < 3; k++) {
+            std::printf("%s[", k ? ", " : "");
+            for (int e = 0; e < 16; e++) std::printf("%s%.17g", e ? ", " : "", pc.opX_b_T_a[k][e]);
+            std::printf("]");
+        }
+        cerebro_hip::LoopEdgePOD e;
+        const bool pub = pc.makeLoopEdgeMsgWithConsistencyCheck(e);
+        std::printf("], \"publish\": %s", pub ? "true" : "false");
+        if (pub)
+            std::printf(", \"position\": [%.17g, %.17g, %.17g], \"orientation_xyzw\": [%.17g, %.17g, %.17g, %.17g], \"weight\": %.9g, \"description\": \"%s\"",
+                        e.position[0], e.position[1], e.position[2], e.orientation_xyzw[0], e.orientation_xyzw[1], e.orientation_xyzw[2],
+                        e.orientation_xyzw[3], (double)e.weight, e.description.c_str());
+    }
+    std::printf("}\n");
+    chip_destroy(ctx);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 3 && std::strcmp(argv[1], "--gate") == 0) return gate(argv[2]);
+    if (argc >= 3 && std::strcmp(argv[1], "--threeway") == 0) return threeway(argv[2], argc > 3 ? std::atoi(argv[3]) : 0);
     if (argc >= 4 && std::strcmp(argv[1], "--parse-only") == 0) return parse_only(argv[2], argv[3]);
     if (argc >= 4 && std::strcmp(argv[1], "--state") == 0) return from_state(argv[2], argv[3], argc > 4 ? std::atoi(argv[4]) : 0);
     if (argc < 3) { std::fprintf(stderr, "usage: %s <stream.bin> <out.json> [device] | --state <state.json> <out.json> [device] | --parse-only <state.json> <out.bin>\n", argv[0]); return 2; }

@@ -1,0 +1,139 @@
+"""Row N3: three-way consistency gate + LoopEdge packaging (ProcessedLoopCandidate.cpp:16-125, PoseManipUtils.cpp:31-45,
+:148-163) -- C++ host mirror vs a numpy restatement; plus the GPU end-to-end three-estimator run."""
+import json
+import math
+import struct
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import np_mirror_pnp as M
+
+ROOT = Path(__file__).resolve().parent.parent
+REPLAY = ROOT / "cerebro_amd" / "lib" / "cerebro_replay"
+
+
+def r2ypr_deg(R):
+    n, o, a = R[:, 0], R[:, 1], R[:, 2]
+    y = math.atan2(n[1], n[0])
+    p = math.atan2(-n[2], n[0] * math.cos(y) + n[1] * math.sin(y))
+    r = math.atan2(a[0] * math.sin(y) - a[1] * math.cos(y), -o[0] * math.sin(y) + o[1] * math.cos(y))
+    return np.array([y, p, r]) / math.pi * 180.0
+
+
+def quat_xyzw(R):
+    """Eigen::Quaterniond(Matrix3d)"""
+    t = np.trace(R)
+    if t > 0:
+        t = math.sqrt(t + 1.0); w = 0.5 * t; t = 0.5 / t
+        return np.array([(R[2, 1] - R[1, 2]) * t, (R[0, 2] - R[2, 0]) * t, (R[1, 0] - R[0, 1]) * t, w])
+    i = 0
+    if R[1, 1] > R[0, 0]: i = 1
+    if R[2, 2] > R[i, i]: i = 2
+    j, k = (i + 1) % 3, (i + 2) % 3
+    t = math.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+    v = np.zeros(3); v[i] = 0.5 * t; t = 0.5 / t
+    w = (R[k, j] - R[j, k]) * t; v[j] = (R[j, i] + R[i, j]) * t; v[k] = (R[k, i] + R[i, k]) * t
+    return np.array([v[0], v[1], v[2], w])
+
+
+def gate(t1, t2, idx1, idx2, pf, g, T):
+    """ProcessedLoopCandidate::makeLoopEdgeMsgWithConsistencyCheck"""
+    dns = (t1[0] - t2[0]) * 10**9 + (t1[1] - t2[1])
+    dsec = dns // 10**9                                   # ros::Duration: sec = floor
+    if abs(dsec) < 10:
+        return None
+    op1, op2, icp = T
+    d12, d1i, d2i = np.linalg.inv(op1) @ op2, np.linalg.inv(op1) @ icp, np.linalg.inv(op2) @ icp
+    ok_ypr = all(np.abs(r2ypr_deg(d[:3, :3])).max() < 5.0 for d in (d12, d1i, d2i))
+    ok_tr = np.abs(d1i[:3, 3]).max() < .2 and np.abs(d1i[:3, 3]).max() < .2 and np.abs(d2i[:3, 3]).max() < .2   # sic
+    if pf > 800 and ok_ypr and ok_tr:
+        return dict(position=op1[:3, 3], orientation_xyzw=quat_xyzw(op1[:3, :3]), weight=np.float32(max(g)),
+                    description=f"{idx1}<=>{idx2}    this pose is: {idx2}_T_{idx1}")
+    return None
+
+
+def rand_pose(rng, ang_deg, tr):
+    s = np.tan(np.deg2rad(ang_deg) / 2) * rng.standard_normal(3) / np.sqrt(3)
+    T = np.eye(4); T[:3, :3] = M.quat_R(s); T[:3, 3] = rng.uniform(-tr, tr, 3)
+    return T
+
+
+def test_gate_matches_numpy_restatement(tmp_path):
+    rng = np.random.default_rng(0)
+    cases = []
+    for i in range(400):
+        base = rand_pose(rng, 40, 2.0)
+        lvl = [0.5, 3.0, 4.9, 5.1, 8.0][i % 5]
+        T = [base] + [base @ rand_pose(rng, lvl, [0.05, 0.19, 0.21, 0.5][i % 4]) for _ in range(2)]
+        dt = [100.0, 10.0, 9.999, -9.5, -10.0, -10.5, 0.3][i % 7]
+        t2 = (1403636600, 500_000_000)
+        ns1 = t2[0] * 10**9 + t2[1] + int(round(dt * 1e9))
+        t1 = (ns1 // 10**9, ns1 % 10**9)
+        pf = [801, 800, 5000, 150][i % 4]
+        g = rng.uniform(0, 1, 3).astype(np.float32)
+        cases.append((t1, t2, 1000 + i, 10 + i, pf, g, T))
+    with open(tmp_path / "in.txt", "w") as f:
+        for t1, t2, i1, i2, pf, g, T in cases:
+            f.write(f"{t1[0]} {t1[1]} {t2[0]} {t2[1]} {i1} {i2} {pf} {g[0]:.9g} {g[1]:.9g} {g[2]:.9g}")
+            for Tm in T:
+                f.write(" " + " ".join(f"{x:.17g}" for x in Tm.T.reshape(16)))
+            f.write("\n")
+    r = subprocess.run([str(REPLAY), "--gate", str(tmp_path / "in.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(x) for x in r.stdout.strip().splitlines()]
+    assert len(lines) == len(cases)
+    n_ok = 0
+    for c, got in zip(cases, lines):
+        want = gate(*c)
+        assert got["ok"] == (want is not None), (c[:5], got)
+        if want is not None:
+            n_ok += 1
+            assert (got["sec0"], got["nsec0"], got["sec1"], got["nsec1"]) == (*c[0], *c[1])
+            assert np.allclose(got["position"], want["position"], atol=1e-15, rtol=0)
+            assert np.allclose(got["orientation_xyzw"], want["orientation_xyzw"], atol=1e-14, rtol=0)
+            assert np.float32(got["weight"]) == want["weight"] and got["description"] == want["description"]
+    assert 10 < n_ok < len(cases) - 10
+
+
+def make_pair_input(N, seed, noise_px=0.3, depth_noise=0.01):
+    X, uv_b, T, inl = M.make_scene(N=N, outlier_frac=0.1, noise_px=noise_px, seed=seed)
+    rng = np.random.default_rng(seed + 5)
+    Xb = (X @ T[:3, :3].T + T[:3, 3] + rng.standard_normal((N, 3)) * depth_noise).astype(np.float32).astype(np.float64)
+    uv_a = X[:, :2] / X[:, 2:3] + rng.standard_normal((N, 2)) * (noise_px / 458.0)
+    return X, uv_b, Xb, uv_a, T
+
+
+@pytest.mark.gpu
+def test_three_way_pose_and_loopedge_end_to_end(tmp_path):
+    from cerebro_amd import capi
+    N, seed, pf = 900, 31, 1200
+    X, uv_b, Xb, uv_a, T = make_pair_input(N, seed)
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(struct.pack("<IIQ", N, pf, 777))
+        for arr in (X, uv_b, Xb, uv_a, X, Xb):
+            f.write(np.ascontiguousarray(arr, dtype=np.float64).tobytes())
+    r = subprocess.run([str(REPLAY), "--threeway", str(tmp_path / "in.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout)
+    assert got["have_poses"]
+    poses = [np.array(p).reshape(4, 4).T for p in got["poses"]]
+    # the same three estimator calls through the Python binding (same seeds as compute_three_way_pose)
+    with capi.Chip(64) as chip:
+        p = capi.default_ransac_params(); p.seed = 777
+        r1 = chip.pnp_ransac(X, uv_b, p)
+        p.seed = 778
+        r2 = chip.pnp_ransac(Xb, uv_a, p)
+        pi = capi.default_icp_params(); pi.seed = 777 ^ 0x9E3779B97F4A7C15
+        r3 = chip.icp_ransac(X, Xb, pi)
+    assert np.array_equal(poses[0], r1["T"]) and np.array_equal(poses[2], r3["T"])
+    assert np.allclose(poses[1], np.linalg.inv(r2["T"]), atol=1e-12)            # op2__b_T_a = op2__a_T_b.inverse() (Cerebro.cpp:1582)
+    assert np.allclose(got["goodness"], [r1["confidence"], r2["confidence"], r3["confidence"]])
+    for P in poses:
+        assert np.abs(P[:3, :3] - T[:3, :3]).max() < 0.03 and np.abs(P[:3, 3] - T[:3, 3]).max() < 0.15
+    want = gate((1403636700, 0), (1403636600, 0), 2100, 100, pf, np.array(got["goodness"], dtype=np.float32), poses)
+    assert got["publish"] == (want is not None) and got["publish"]
+    assert np.allclose(got["position"], want["position"]) and np.allclose(got["orientation_xyzw"], want["orientation_xyzw"], atol=1e-12)
+    assert got["description"] == "2100<=>100    this pose is: 100_T_2100"
