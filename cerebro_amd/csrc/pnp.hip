@@ -20,6 +20,7 @@
 #include "ransac_common.h"
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -399,6 +400,7 @@ struct EigArgs {
     int32_t *valid;         // [H]  1 = exactly one DLS solution
     int32_t *nsol;          // [H]  number of cheirality-valid real solutions (diagnostics)
     unsigned long long *mask;  // [H][mask_words]
+    int32_t debug_stop;     // tuning only (CHIP_PNP_DEBUG_STOP)
 };
 
 #define HH(i, j) Hs[(i) * EN + (j)]
@@ -426,6 +428,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     }
     __syncthreads();
 
+    if (a.debug_stop == 1) return;
     // ================= Householder reduction to Hessenberg form (orthes) =================
     for (int m = low + 1; m <= high - 1; m++) {
         double scale = 0.0;
@@ -491,6 +494,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     }
     __syncthreads();
 
+    if (a.debug_stop == 2) return;
     // ================= Francis double-shift QR with accumulation (hqr2) =================
     double norm = 0.0;
     for (int i = 0; i < nn; i++)
@@ -500,12 +504,19 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     int iter = 0;
     bool failed = false;
     while (n >= low) {
-        int l = n;
-        while (l > low) {
-            s = fabs(HH(l - 1, l - 1)) + fabs(HH(l, l));
-            if (s == 0.0) s = norm;
-            if (fabs(HH(l, l - 1)) < eps * s) break;
-            l--;
+        // l = largest index in (low, n] whose sub-diagonal element is negligible (else low).  The reference scans
+        // l = n, n-1, ... sequentially; every index is independent, so lane l tests its own and a ballot picks the
+        // same l (exact reformulation: same arithmetic per index, same selection).
+        int l;
+        {
+            bool small = false;
+            if (lane > low && lane <= n) {
+                double ss = fabs(HH(lane - 1, lane - 1)) + fabs(HH(lane, lane));
+                if (ss == 0.0) ss = norm;
+                small = fabs(HH(lane, lane - 1)) < eps * ss;
+            }
+            const unsigned long long bm = __ballot(small);
+            l = bm ? 63 - __builtin_clzll(bm) : low;
         }
         if (l == n) {  // one root
             const double v = HH(n, n) + exshift;
@@ -588,19 +599,29 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             }
             iter++;
             if (iter > 60) { failed = true; break; }
-            int m = n - 2;
-            while (m >= l) {  // two consecutive small sub-diagonal elements
-                z = HH(m, m);
-                r = x - z; s = y - z;
-                p = (r * s - w) / HH(m + 1, m) + HH(m, m + 1);
-                q = HH(m + 1, m + 1) - z - r - s;
-                r = HH(m + 2, m + 1);
-                s = fabs(p) + fabs(q) + fabs(r);
-                p = p / s; q = q / s; r = r / s;
-                if (m == l) break;
-                if (fabs(HH(m, m - 1)) * (fabs(q) + fabs(r)) <
-                    eps * (fabs(p) * (fabs(HH(m - 1, m - 1)) + fabs(z) + fabs(HH(m + 1, m + 1))))) break;
-                m--;
+            // two consecutive small sub-diagonal elements: the reference scans m = n-2, n-3, ..., l and stops at the first
+            // m that passes the test (or at m == l).  Lane m evaluates its own candidate (p,q,r normalised as in the
+            // reference); the ballot selects the largest passing m; p,q,r come from that lane.  Exact reformulation.
+            int m;
+            {
+                double pm = 0.0, qm = 0.0, rm = 0.0;
+                bool pass = false;
+                if (lane >= l && lane <= n - 2) {
+                    const int mm = lane;
+                    const double zz = HH(mm, mm);
+                    double rr = x - zz, ss = y - zz;
+                    pm = (rr * ss - w) / HH(mm + 1, mm) + HH(mm, mm + 1);
+                    qm = HH(mm + 1, mm + 1) - zz - rr - ss;
+                    rm = HH(mm + 2, mm + 1);
+                    ss = fabs(pm) + fabs(qm) + fabs(rm);
+                    pm = pm / ss; qm = qm / ss; rm = rm / ss;
+                    if (mm == l) pass = true;
+                    else pass = fabs(HH(mm, mm - 1)) * (fabs(qm) + fabs(rm)) <
+                                eps * (fabs(pm) * (fabs(HH(mm - 1, mm - 1)) + fabs(zz) + fabs(HH(mm + 1, mm + 1))));
+                }
+                const unsigned long long bm = __ballot(pass);
+                m = 63 - __builtin_clzll(bm);   // lane l always passes and l <= n-2 in this branch
+                p = __shfl(pm, m, 64); q = __shfl(qm, m, 64); r = __shfl(rm, m, 64);
             }
             __syncthreads();
             if (lane >= m + 2 && lane <= n) { HH(lane, lane - 2) = 0.0; if (lane > m + 2) HH(lane, lane - 3) = 0.0; }
@@ -653,6 +674,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     }
     __syncthreads();
 
+    if (a.debug_stop == 3) return;
     // ================= back-substitution (real eigenvalues only), one lane per eigenvector =================
     int my_valid = 0;
     double R[9], t3[3];
@@ -714,6 +736,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             }
         }
     }
+    if (a.debug_stop == 4) return;
     const unsigned long long vb = __ballot(my_valid);
     const int nsol = __popcll(vb);
     if (lane == 0) a.nsol[hyp] = failed ? -2 : nsol;
@@ -885,6 +908,7 @@ extern "C" int chip_pnp_ransac(chip_ctx *c, const double *X, const double *uv, i
     EigArgs ea;
     ea.X = st->X; ea.uv = st->uv; ea.N = N; ea.S = S; ea.thresh = p->error_thresh; ea.use_mle = p->use_mle;
     ea.Sg = st->Sg; ea.Tg = st->Tg; ea.sample = st->sample; ea.ok = st->ok; ea.mask_words = words;
+    { const char *dv = std::getenv("CHIP_PNP_DEBUG_STOP"); ea.debug_stop = dv ? std::atoi(dv) : 0; }
     ea.T_out = st->T_out; ea.cost = st->cost; ea.nin = st->nin; ea.valid = st->valid; ea.nsol = st->nsol; ea.mask = st->mask;
     hipLaunchKernelGGL(pnp_eig_score, dim3(H), dim3(64), 0, s, ea);
     CHIP_HIP(c, hipGetLastError());
