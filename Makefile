@@ -7,11 +7,12 @@ ARCH       ?= gfx950
 # the scan kernel uses explicit fma() where the product is exact.
 HIPFLAGS   ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -Wall -Wno-unused-function
 CC         ?= gcc
-ORCFLAGS   ?= -O2 -ffp-contract=off -fopenmp -fPIC -Wall -Wextra
+# -mfma only makes __builtin_fmaf a single vfmadd (exact either way); -ffp-contract=off forbids any other fusion
+ORCFLAGS   ?= -O2 -mfma -ffp-contract=off -fopenmp -fPIC -Wall -Wextra
 
 LIBDIR     := cerebro_amd/lib
 CSRC       := cerebro_amd/csrc
-HIP_SRCS   := $(CSRC)/kernels.hip $(CSRC)/chip_api.hip $(CSRC)/pnp.hip $(CSRC)/icp.hip
+HIP_SRCS   := $(CSRC)/kernels.hip $(CSRC)/chip_api.hip $(CSRC)/pnp.hip $(CSRC)/icp.hip $(CSRC)/batch.hip
 HIP_OBJS   := $(HIP_SRCS:$(CSRC)/%.hip=$(LIBDIR)/%.o)
 ORC_SRCS   := $(wildcard oracle/*.c)
 
@@ -20,7 +21,7 @@ lib: $(LIBDIR)/libcerebro_hip.so
 oracle: oracle/_build/liboracle.so
 host: $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay
 
-$(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/chip_internal.h $(CSRC)/ransac_common.h include/cerebro_hip.h
+$(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/chip_internal.h $(CSRC)/ransac_common.h $(CSRC)/topk_merge.h include/cerebro_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -98,6 +98,7 @@ _SIGS = {
     "chip_db_append_synthetic": (C.c_int, [_P, C.c_int64, C.c_uint64, _P, _P, _P, C.c_int64]),
     "chip_query_rows": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
     "chip_query_vectors_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
+    "chip_query_batch_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
     "chip_dot_params_default": (None, [C.POINTER(DotParams)]),
     "chip_loop_tick": (C.c_int, [_P, C.c_int64, C.POINTER(DotParams), C.POINTER(TickResult)]),
     "chip_loop_tick_enqueue": (C.c_int, [_P, C.c_int64, C.POINTER(DotParams), C.c_int32]),
@@ -281,6 +282,15 @@ class Chip:
         ix = np.empty((nq, topk), dtype=np.int64)
         self._chk(self.lib.chip_query_vectors_f32(self.h, k, _ptr(q), nq, topk, _ptr(sc), _ptr(ix)),
                   "chip_query_vectors_f32")
+        return sc, ix
+
+    def query_batch(self, k: int, q: np.ndarray, topk: int = CHIP_DEFAULT_TOPK):
+        """many-query fp32 MFMA mode: returns (scores float32 [Q, topk], idx int64 [Q, topk])"""
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, self.D)
+        Q = q.shape[0]
+        sc = np.empty((Q, topk), dtype=np.float32)
+        ix = np.empty((Q, topk), dtype=np.int64)
+        self._chk(self.lib.chip_query_batch_f32(self.h, k, _ptr(q), Q, topk, _ptr(sc), _ptr(ix)), "chip_query_batch_f32")
         return sc, ix
 
     # -- tick

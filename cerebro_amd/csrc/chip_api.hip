@@ -101,6 +101,7 @@ static void destroy_ctx(chip_ctx *c)
     (void)hipDeviceSynchronize();
     pnp_destroy(c);
     icp_destroy(c);
+    batch_destroy(c);
     for (float *p : c->segs) (void)hipFree(p);
     if (c->seg_table_dev) (void)hipFree(c->seg_table_dev);
     if (c->ring_dev) (void)hipFree(c->ring_dev);

@@ -121,6 +121,7 @@ struct Ctx {
     // --- pnp scratch (pnp.hip) ---
     void *pnp_state = nullptr;
     void *icp_state = nullptr;   // icp.hip, created on first use
+    void *batch_state = nullptr; // batch.hip, created on first use
 
     mutable hipError_t last_hip = hipSuccess;
 };
@@ -150,6 +151,7 @@ inline float *row_ptr_host(const Ctx *c, int64_t local) {
 int pnp_create(Ctx *c);
 void pnp_destroy(Ctx *c);
 void icp_destroy(Ctx *c);
+void batch_destroy(Ctx *c);
 
 }  // namespace chip
 

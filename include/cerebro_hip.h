@@ -109,6 +109,15 @@ int chip_query_rows(chip_ctx *ctx, int64_t k, const int64_t *query_rows, int32_t
 int chip_query_vectors_f32(chip_ctx *ctx, int64_t k, const float *queries, int32_t nq, int32_t topk,
                            double *scores, int64_t *idx);
 
+/* Many-query batched mode: Q query descriptors (host, Q x D fp32) against rows [0,k) in ONE pass of
+ * the DB as an fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32) with a fused exact top-k.  Semantics are those of
+ * the reference's compiled-out faiss variants (IndexFlatIP on float descriptors, src/Cerebro.cpp:390,422,455-472):
+ * score = fp32 inner product, here defined as ONE k-ordered fmaf chain (bit-reproducible; differs from the fp64 scores
+ * of chip_query_* by fp32 round-off, ~1e-7).  Ordering (score desc, index desc); unused slots -inf / -1.
+ * Requires D % 32 == 0.  Worth it from Q ~ 40 upwards (arithmetic intensity Q/2 flop/B vs the 19.7 flop/B ridge). */
+int chip_query_batch_f32(chip_ctx *ctx, int64_t k, const float *queries, int32_t Q, int32_t topk,
+                         float *scores /* Q x topk */, int64_t *idx /* Q x topk */);
+
 /* ------------------------------------------------------------------------------------------ the tick
  * One pass of the while-loop body of Cerebro::descrip_N__dot__descrip_0_N (src/Cerebro.cpp:956-1100) for
  * l = wholeImageComputedList_size().  Defaults (chip_dot_params_default): LOCALITY_THRESH 12 (:912),

@@ -48,6 +48,11 @@ double   orc_dot_seq_f64(const double *q, const double *col, int32_t D);
 void     orc_scan_topk_f32(const float *db, int64_t k, int32_t D,
                            const float *queries, int32_t nq, int32_t K,
                            double *out_scores, int64_t *out_idx);
+/* Batched many-query mode (row N4): fp32 k-ordered fmaf chain per (query, row); scores returned as doubles
+ * (exactly the float values); same ordering rule.  OpenMP over queries. */
+float    orc_dot_fmaf_f32(const float *q, const float *row, int32_t D);
+void     orc_scan_topk_fmaf_f32(const float *db, int64_t k, int32_t D, const float *queries, int32_t nq, int32_t K,
+                                double *out_scores, int64_t *out_idx);
 /* Same, rows produced on the fly by the synthetic generator (for 100k/1M checks without 16 GB of RAM).
  * plant_dst/src/kind describe planted rows (sorted by dst, may be NULL).  nthreads<=0 -> 1. */
 void     orc_scan_topk_synth(uint64_t seed, int64_t k, int32_t D,

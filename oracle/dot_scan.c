@@ -82,6 +82,16 @@ double orc_dot_seq_f64(const double *q, const double *col, int32_t D)
     return s;
 }
 
+/* fp32 dot product as ONE k-ordered fmaf chain: acc = fmaf(q[e], row[e], acc), e ascending.  This is what the batched
+ * many-query mode computes (v_mfma_f32_32x32x2_f32 is bit-for-bit such a chain), and what the compiled-out faiss variants
+ * of the reference compute up to summation order (IndexFlatIP on X.cast<float>(), Cerebro.cpp:390,422,455). */
+float orc_dot_fmaf_f32(const float *q, const float *row, int32_t D)
+{
+    float acc = 0.0f;
+    for (int32_t e = 0; e < D; e++) acc = __builtin_fmaf(q[e], row[e], acc);
+    return acc;
+}
+
 /* ---------------------------------------------------------------- top-K with (score desc, idx desc) */
 static inline int key_gt(double s, int64_t i, double s2, int64_t i2) { return s > s2 || (s == s2 && i > i2); }
 
@@ -106,6 +116,18 @@ void orc_scan_topk_f32(const float *db, int64_t k, int32_t D, const float *queri
         for (int32_t q = 0; q < nq; q++)
             topk_push(out_scores + (size_t)q * K, out_idx + (size_t)q * K, K,
                       orc_dot_tree_f32(queries + (size_t)q * D, db + (size_t)i * D, D), i);
+}
+
+void orc_scan_topk_fmaf_f32(const float *db, int64_t k, int32_t D, const float *queries, int32_t nq, int32_t K,
+                            double *out_scores, int64_t *out_idx)
+{
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int32_t q = 0; q < nq; q++) {
+        double *sc = out_scores + (size_t)q * K;
+        int64_t *ix = out_idx + (size_t)q * K;
+        topk_init(sc, ix, K);
+        for (int64_t i = 0; i < k; i++) topk_push(sc, ix, K, (double)orc_dot_fmaf_f32(queries + (size_t)q * D, db + (size_t)i * D, D), i);
+    }
 }
 
 void orc_scan_topk_synth(uint64_t seed, int64_t k, int32_t D,

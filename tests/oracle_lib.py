@@ -62,6 +62,10 @@ def load():
     lib.orc_dot_seq_f64.argtypes = [V, V, C.c_int32]
     lib.orc_scan_topk_f32.restype = None
     lib.orc_scan_topk_f32.argtypes = [V, C.c_int64, C.c_int32, V, C.c_int32, C.c_int32, V, V]
+    lib.orc_dot_fmaf_f32.restype = C.c_float
+    lib.orc_dot_fmaf_f32.argtypes = [V, V, C.c_int32]
+    lib.orc_scan_topk_fmaf_f32.restype = None
+    lib.orc_scan_topk_fmaf_f32.argtypes = [V, C.c_int64, C.c_int32, V, C.c_int32, C.c_int32, V, V]
     lib.orc_scan_topk_synth.restype = None
     lib.orc_scan_topk_synth.argtypes = [C.c_uint64, C.c_int64, C.c_int32, V, V, V, C.c_int64, V, C.c_int32, C.c_int32,
                                         V, V, C.c_int32]
@@ -102,6 +106,17 @@ def scan_topk(db: np.ndarray, k: int, queries: np.ndarray, K: int):
     sc = np.empty((nq, K), dtype=np.float64)
     ix = np.empty((nq, K), dtype=np.int64)
     load().orc_scan_topk_f32(_p(db), k, db.shape[1], _p(queries), nq, K, _p(sc), _p(ix))
+    return sc, ix
+
+
+def scan_topk_fmaf(db: np.ndarray, k: int, queries: np.ndarray, K: int):
+    """batched mode oracle: fp32 fmaf chain"""
+    db = np.ascontiguousarray(db, dtype=np.float32)
+    queries = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, db.shape[1])
+    nq = queries.shape[0]
+    sc = np.empty((nq, K), dtype=np.float64)
+    ix = np.empty((nq, K), dtype=np.int64)
+    load().orc_scan_topk_fmaf_f32(_p(db), k, db.shape[1], _p(queries), nq, K, _p(sc), _p(ix))
     return sc, ix
 
 

@@ -1,0 +1,66 @@
+"""Row N4: many-query batched mode (fp32 MFMA GEMM + fused exact top-k) vs the fp32 fmaf-chain oracle, bit for bit."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import scenarios
+from cerebro_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def check(chip, db, k, q, K):
+    want_s, want_i = oracle_lib.scan_topk_fmaf(db, k, q, K)
+    got_s, got_i = chip.query_batch(k, q, K)
+    assert np.array_equal(got_i, want_i), (got_i[:2], want_i[:2])
+    assert np.array_equal(got_s.view(np.uint32), want_s.astype(np.float32).view(np.uint32))     # bit-exact fp32 scores
+
+
+@pytest.mark.parametrize("D,N,Q", [(32, 300, 5), (512, 1500, 64), (1024, 3000, 200), (4096, 2000, 130)])
+def test_batch_parity(D, N, Q):
+    plants, loops, ties = scenarios.loop_plants(N, 4, seed=D + Q)
+    db = scenarios.build_db(7 * D, N, D, plants)
+    rng = np.random.default_rng(Q)
+    q = np.concatenate([db[rng.choice(N, Q - 2, replace=False)], oracle_lib.synth_rows(99, [1, 2], D)])
+    q[0] = db[loops[0][1]]
+    with capi.Chip(D) as chip:
+        chip.append_f32(db)
+        for K in (1, 8, 16):
+            for k in (0, 1, 127, 128, 129, N - 50, N):
+                check(chip, db, k, q, K)
+        if ties:
+            s, t1, t2 = ties[0]
+            sc, ix = chip.query_batch(N, db[[s]], 3)
+            assert list(ix[0]) == [t2, t1, s] and sc[0][0] == sc[0][1] == sc[0][2]           # index-descending tie rule
+        # fp32 MFMA scores agree with the fp64 scan of the tick path to fp32 round-off, and select the same best match
+        s64, i64 = chip.query_rows(N - 50, [loops[0][1]], 1)
+        s32, i32 = chip.query_batch(N - 50, db[[loops[0][1]]], 1)
+        assert i32[0, 0] == i64[0, 0] and abs(float(s32[0, 0]) - s64[0, 0]) < 1e-5
+
+
+def test_batch_errors():
+    with capi.Chip(36) as chip:                      # D % 32 != 0
+        chip.append_f32(np.zeros((4, 36), dtype=np.float32))
+        with pytest.raises(capi.ChipError) as e:
+            chip.query_batch(4, np.zeros((2, 36), dtype=np.float32), 4)
+        assert e.value.status == capi.CHIP_ERR_UNSUPPORTED
+    with capi.Chip(64) as chip:
+        chip.append_f32(np.zeros((4, 64), dtype=np.float32))
+        with pytest.raises(capi.ChipError) as e:
+            chip.query_batch(5, np.zeros((2, 64), dtype=np.float32), 4)
+        assert e.value.status == capi.CHIP_ERR_RANGE
+
+
+def test_batch_sharded_lists_are_consistent():
+    D, N, Q, G = 256, 1100, 70, 3
+    db = scenarios.build_db(5, N, D, [])
+    q = db[:Q]
+    want_s, want_i = oracle_lib.scan_topk_fmaf(db, N, q, 8)
+    parts = []
+    for r in range(G):
+        with capi.Chip(D, shard_rank=r, shard_count=G) as chip:
+            chip.append_f32(db)
+            parts.append(chip.query_batch(N, q, 8))
+    for qi in range(Q):
+        cand = sorted(((float(s), int(i)) for ps, pi in parts for s, i in zip(ps[qi], pi[qi]) if i >= 0), key=lambda t: (-t[0], -t[1]))[:8]
+        assert [c[1] for c in cand] == list(want_i[qi])
