@@ -119,6 +119,30 @@ def pnp_leg(chip, cpu_budget_s: float):
     return out
 
 
+def batch_leg(chip, rows: int, Q: int = 256):
+    """Row N4: Q queries against the resident DB prefix in one pass -- fp32 GEMM on v_mfma_f32_32x32x2_f32 + fused top-k.
+    MFMA-bound (arithmetic intensity Q/2 flop/B): priced against the 157.3 TFLOP/s dense fp32 matrix peak."""
+    q = chip.read_rows((np.arange(Q, dtype=np.int64) * 7919) % rows)
+    chip.query_batch(rows, q, TOPK)
+    chip.profile_enable(True)
+    chip.profile_reset()
+    n = 3
+    t0 = time.perf_counter()
+    for _ in range(n):
+        sc, ix = chip.query_batch(rows, q, TOPK)
+    dt = (time.perf_counter() - t0) / n
+    ms, cnt, _, _ = chip.profile_scan()
+    chip.profile_enable(False)
+    assert (ix[:, 0] == (np.arange(Q) * 7919) % rows).all()      # every query finds itself
+    k_s = ms / 1e3 / cnt
+    flops = 2.0 * Q * rows * D
+    return {"metric": "batched queries/sec (Q x DB fp32 GEMM on MFMA + fused top-k)", "value": Q / dt, "unit": "queries/s",
+            "Q": Q, "db_rows": rows, "ms_per_call": dt * 1e3, "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact k-ordered fmaf chain)",
+            "roofline": {"bound": "mfma", "achieved": flops / k_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": flops / k_s / 1e12 / 157.3, "kernel": "db_gemm_topk", "avg_kernel_ms": k_s * 1e3,
+                         "algorithmic_flops_per_launch": flops, "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +153,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20000, help="columns in the CPU baseline sample")
     ap.add_argument("--inflight", type=int, default=16)
     ap.add_argument("--no-pnp", action="store_true", help="skip the auxiliary PnP-RANSAC leg (config 3)")
+    ap.add_argument("--no-batch", action="store_true", help="skip the auxiliary many-query MFMA leg (row N4)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="testing aid: run the sharded code path (scan_local -> RCCL all-gather -> merge) even with 1 rank")
     args = ap.parse_args()
@@ -279,6 +304,8 @@ def main():
         }
         if world == 1 and not args.no_pnp:
             out["pnp"] = pnp_leg(chip, min(args.cpu_budget, 5.0))
+        if world == 1 and not args.no_batch:
+            out["batch"] = batch_leg(chip, args.rows)
         if world == 1 and args.cpu_budget > 0:
             cols_per_s, n, dt = cpu_baseline(args.cpu_sample, args.cpu_budget)
             out["cpu_baseline"] = {"value": cols_per_s / args.rows, "unit": "ticks/s", "cores": 1, "kind": "port",

@@ -25,7 +25,7 @@ namespace chip {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, KC = 32, LDT = KC + 1;
+constexpr int BM = 128, BN = 128;
 constexpr int CT_LD = BN + 1;   // transposed score half-tile [64][129]
 
 struct BatchArgs {
@@ -68,8 +68,13 @@ __device__ __forceinline__ void list_push(TopList &L, int K, float s, int32_t ro
     if (fkey_gt(s, row, L.s[0], L.r[0])) { L.s[0] = s; L.r[0] = row; }
 }
 
+template <int KC>
 __global__ __launch_bounds__(256) void db_gemm_topk(BatchArgs a)
 {
+    constexpr int LDT = KC + 1;          // padded LDS row stride (floats): conflict-free ds_read_b32 fragment reads
+    constexpr int LPR = KC / 4;          // lanes per row chunk (16 B each)
+    constexpr int RPP = 256 / LPR;       // rows per staging pass
+    constexpr int NPASS = BM / RPP;      // staging passes per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *As = reinterpret_cast<float *>(smem);        // [BM][LDT]
     float *Bs = As + BM * LDT;                           // [BN][LDT]
@@ -86,14 +91,22 @@ __global__ __launch_bounds__(256) void db_gemm_topk(BatchArgs a)
     list_init(L0);
     list_init(L1);
 
-    const int ld_row = tid >> 1, ld_half = tid & 1;      // staging: thread -> (tile row, 16-float half of the K chunk)
-    const float *arow = a.Q + (int64_t)(q0 + ld_row) * D + ld_half * 16;
+    // staging map: LPR consecutive lanes cover one row's K-chunk (KC*4 bytes: full-line, coalesced requests); NPASS passes
+    const int ld_c = (tid % LPR) * 4, ld_r = tid / LPR;
+    const float *arow[NPASS];
+#pragma unroll
+    for (int u = 0; u < NPASS; u++) arow[u] = a.Q + (int64_t)(q0 + ld_r + RPP * u) * D + ld_c;
 
     for (int64_t n0 = part_lo; n0 < part_hi; n0 += BN) {
-        const int64_t br = n0 + ld_row;
-        const bool bvalid = br < a.n_rows;
-        const int64_t brc = bvalid ? br : 0;
-        const float *brow = a.seg_table[brc >> a.seg_shift] + (brc & a.seg_mask) * (int64_t)D + ld_half * 16;
+        const float *brow[NPASS];
+        bool bvalid[NPASS];
+#pragma unroll
+        for (int u = 0; u < NPASS; u++) {
+            const int64_t br = n0 + ld_r + RPP * u;
+            bvalid[u] = br < a.n_rows;
+            const int64_t brc = bvalid[u] ? br : 0;
+            brow[u] = a.seg_table[brc >> a.seg_shift] + (brc & a.seg_mask) * (int64_t)D + ld_c;
+        }
         f32x16 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; i++)
@@ -102,21 +115,29 @@ __global__ __launch_bounds__(256) void db_gemm_topk(BatchArgs a)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
-        for (int kc = 0; kc < D; kc += KC) {
-            f32x4 av[4], bv[4];
+        // software pipeline: the global loads of chunk kc+KC are issued before the MFMA loop of chunk kc
+        f32x4 av[NPASS], bv[NPASS];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                av[u] = *reinterpret_cast<const f32x4 *>(arow + kc + 4 * u);
-                bv[u] = bvalid ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(brow + kc + 4 * u)) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int u = 0; u < NPASS; u++) {
+            av[u] = *reinterpret_cast<const f32x4 *>(arow[u]);
+            bv[u] = bvalid[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(brow[u])) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int kc = 0; kc < D; kc += KC) {
             __syncthreads();   // previous chunk's fragment reads are done
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < NPASS; u++)
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    As[ld_row * LDT + ld_half * 16 + 4 * u + c] = av[u][c];
-                    Bs[ld_row * LDT + ld_half * 16 + 4 * u + c] = bv[u][c];
+                    As[(ld_r + RPP * u) * LDT + ld_c + c] = av[u][c];
+                    Bs[(ld_r + RPP * u) * LDT + ld_c + c] = bv[u][c];
                 }
+            if (kc + KC < D) {
+#pragma unroll
+                for (int u = 0; u < NPASS; u++) {
+                    av[u] = *reinterpret_cast<const f32x4 *>(arow[u] + kc + KC);
+                    bv[u] = bvalid[u] ? __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(brow[u] + kc + KC)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
             __syncthreads();
             const int fr = lane & 31, fk = lane >> 5;
 #pragma unroll
@@ -222,7 +243,7 @@ using namespace chip;
 extern "C" int chip_query_batch_f32(chip_ctx *c, int64_t k, const float *queries, int32_t Q, int32_t topk, float *scores, int64_t *idx)
 {
     if (!c || !queries || Q < 1) return CHIP_ERR_INVALID_ARG;
-    if (topk < 1 || topk > CHIP_MAX_TOPK || c->D % KC != 0) return CHIP_ERR_UNSUPPORTED;
+    if (topk < 1 || topk > CHIP_MAX_TOPK || c->D % 32 != 0) return CHIP_ERR_UNSUPPORTED;
     int64_t n_global;
     {
         std::lock_guard<std::mutex> lk(c->mu);
@@ -275,7 +296,8 @@ extern "C" int chip_query_batch_f32(chip_ctx *c, int64_t k, const float *queries
     a.seg_table = c->seg_table_dev; a.seg_shift = c->seg_shift; a.seg_mask = c->seg_rows - 1;
     a.n_rows = n_rows; a.D = D; a.Q = st->Q; a.Qpad = Qpad; a.K = topk; a.rows_per_part = rows_per_part;
     a.idx_mul = c->nranks; a.idx_add = c->nranks == 1 ? 0 : c->rank; a.partial = st->partial;
-    const size_t lds_gemm = sizeof(float) * 2 * BM * LDT, lds_ct = sizeof(float) * 64 * CT_LD;
+    const int KCsel = 32;   // measured: KC=64 (66 KiB LDS) halves residency and drops 111 -> 88 TFLOP/s at Q=256
+    const size_t lds_gemm = sizeof(float) * 2 * BM * (KCsel + 1), lds_ct = sizeof(float) * 64 * CT_LD;
     const size_t lds = lds_gemm > lds_ct ? lds_gemm : lds_ct;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->prof_on) {
@@ -286,7 +308,12 @@ extern "C" int chip_query_batch_f32(chip_ctx *c, int64_t k, const float *queries
         c->prof_bytes_last = (double)n_rows * D * 4.0 * qtiles;
         CHIP_HIP(c, hipEventRecord(e0, s));
     }
-    hipLaunchKernelGGL(db_gemm_topk, dim3((unsigned)P, (unsigned)qtiles), dim3(256), lds, s, a);
+    if (KCsel == 64) {
+        if (lds > 65536) CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_gemm_topk<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(db_gemm_topk<64>, dim3((unsigned)P, (unsigned)qtiles), dim3(256), lds, s, a);
+    } else {
+        hipLaunchKernelGGL(db_gemm_topk<32>, dim3((unsigned)P, (unsigned)qtiles), dim3(256), lds, s, a);
+    }
     CHIP_HIP(c, hipGetLastError());
     if (e1) CHIP_HIP(c, hipEventRecord(e1, s));
     BatchMergeArgs m;
