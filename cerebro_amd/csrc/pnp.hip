@@ -2,9 +2,10 @@
 // /root/reference/src/DlsPnpWithRansac.cpp:192-240, i.e. theia::Ransac over the DlsPnpWithRansac estimator of
 // src/DlsPnpWithRansac.h:42-100).  All hypotheses of a call are generated and scored in parallel:
 //
-//   K4+K5a  pnp_build_solve   one 512-thread workgroup per hypothesis (LDS ~90 KB): counter-based sampler,
-//                             DLS cost matrix -> three Cayley cubics -> degree-7 Macaulay matrix [D|C] (93x120) in LDS
-//                             -> LU with partial pivoting (wave-0 DPP max + ballot pivot search, 2 barriers per step)
+//   K4+K5a  pnp_build_solve   one 512-thread workgroup per hypothesis (LDS ~45 KB, 2-3 per CU): counter-based sampler,
+//                             DLS cost matrix -> three Cayley cubics -> degree-7 Macaulay matrix [D|C] (93x120) held in
+//                             REGISTERS (24 rows x 1 column per thread) -> LU with partial pivoting (DPP wave max +
+//                             logical-position tie rule; only column k / pivot row / multipliers cross LDS)
 //                             -> 27x27 action matrix S = A - B D^-1 C.
 //   K5b+K6  pnp_eig_score     one WAVE per hypothesis: Householder Hessenberg + Francis double-shift QR with
 //                             accumulated transformations (matrices in LDS, lanes over independent rows/columns),
@@ -127,7 +128,6 @@ __device__ __forceinline__ double wave_max_nonneg(double v)
 }
 
 // ------------------------------------------------------------------------------------------------ K4 + K5a
-constexpr int kLD = 121;         // padded row stride of E (doubles): column walks hit 32 distinct banks
 constexpr int kNR = 93, kNC = 120;
 
 struct SolveArgs {
@@ -147,8 +147,7 @@ constexpr int kSolveThreads = 512;
 __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *E = reinterpret_cast<double *>(smem);                 // [93][kLD]
-    double *sm = E + kNR * kLD;
+    double *sm = reinterpret_cast<double *>(smem);
     double *sx = sm;            sm += kSampleMax * 3;             // sample points
     double *suv = sm;           sm += kSampleMax * 2;
     double *zb = sm;            sm += kSampleMax * 3;             // bearings
@@ -163,12 +162,17 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     double *fc = sm;            sm += 60;                         // f[3][20]
     double *uu = sm;            sm += 4;
     double *Xb = sm;            sm += 27 * 27;                    // X[66+t][c]
-    double *Lcol = sm;          sm += 96;                         // multipliers of the current elimination step
-    double *prow_buf = sm;      sm += 128;                        // copy of the pivot row (broadcast operand of the update)
+    double *Lcol = sm;          sm += 8 * 24;                     // multipliers of the current elimination step, per wave
+    double *prow_buf = sm;      sm += 128;                        // the pivot row (broadcast operand of the update)
+    double *colbuf = sm;        sm += 96;                         // column k of the not-yet-pivoted rows (by physical row)
+    double *Urows = sm;         sm += 27 * kNC;                   // pivot rows of steps 66..92 = rows of U needed by the back-substitution
     int *smp = reinterpret_cast<int *>(sm);                       // [16]
     int *fy_key = smp + 16;                                        // sparse Fisher-Yates map (<= 32 entries)
     int *fy_val = fy_key + 32;
-    int *flag = fy_val + 32;                                       // [2] : singular, spare
+    int *flag = fy_val + 32;                                       // [4] : singular, pivot physical row, spare
+    int *logpos = flag + 4;                                        // [96] logical position of each physical row (partial-pivoting swaps)
+    int *physof = logpos + 96;                                     // [96] inverse map
+    short *rdst = reinterpret_cast<short *>(physof + 96);          // [93][20] LDS copy of the Macaulay destination table
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -287,81 +291,115 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
         const int k = tid / 20, mth = tid % 20;
         fc[tid] = (double)tb.fmul[k][mth] * c4[tb.fsrc[k][mth]];
     }
-    // ---- Macaulay [D | C] ----
-    for (int e = tid; e < kNR * kLD; e += kSolveThreads) E[e] = 0.0;
+    // ---- Macaulay [D | C] (93 x 120) lives in REGISTERS: thread (tx = column, ty) holds rows ty, ty+4, ..., ty+92 of its
+    //      column in er[0..23] (static slot indices); only column k, the pivot row and the multipliers cross LDS. ----
+    const int tx = tid & 127, ty = tid >> 7;
+    for (int e = tid; e < kNR * 20; e += kSolveThreads) rdst[e] = tb.row_dst[e / 20][e % 20];
+    if (tid < 96) { logpos[tid] = tid; physof[tid] = tid; }
     __syncthreads();
-    for (int e = tid; e < kNR * 20; e += kSolveThreads) {
-        const int row = e / 20, term = e % 20;
-        E[row * kLD + tb.row_dst[row][term]] = fc[20 * tb.row_which[row] + term];
+    double er[24];
+    unsigned live = 0;   // bit s set <=> physical row ty + 4*s exists and has not been used as a pivot yet
+#pragma unroll
+    for (int sl = 0; sl < 24; sl++) {
+        const int row = ty + 4 * sl;
+        double v = 0.0;
+        if (row < kNR) {
+            live |= 1u << sl;
+            const int which = tb.row_which[row];
+            for (int term = 0; term < 20; term++)
+                if (rdst[row * 20 + term] == tx) v = fc[20 * which + term];
+        }
+        er[sl] = v;
+    }
+    // column 0 of the live rows -> colbuf
+    if (tx == 0) {
+#pragma unroll
+        for (int sl = 0; sl < 24; sl++)
+            if (live >> sl & 1u) colbuf[ty + 4 * sl] = er[sl];
     }
     __syncthreads();
 
-    // ---- LU with partial (row) pivoting.  Per step: wave 0 finds the pivot (DPP max + ballot = first row attaining the
-    //      max), swaps it into row k, copies it to prow_buf and writes the multipliers; then all threads update. ----
+    // ---- LU with partial (row) pivoting, no physical swaps: logpos[] tracks where the reference's swaps would have put
+    //      every row, so "first row attaining the max" (ties -> smallest logical index) is reproduced exactly. ----
+    bool singular = false;
+    double *Lw = Lcol;   // [8 waves][24]: multipliers of each wave's own row group (rows ty, ty+4, ...), wave-private
     for (int k = 0; k < kNR; k++) {
-        if (wave == 0) {
-            const int i0 = k + lane, i1 = k + 64 + lane;
-            const double e0 = i0 < kNR ? E[i0 * kLD + k] : 0.0, e1 = i1 < kNR ? E[i1 * kLD + k] : 0.0;
-            const double v0 = i0 < kNR ? fabs(e0) : -1.0, v1 = i1 < kNR ? fabs(e1) : -1.0;
-            double vm = v0 > v1 ? v0 : v1;
-            if (!(vm >= 0.0)) vm = 0.0;           // NaN / empty lanes do not take part (NaN never wins in the oracle either)
-            const double best = wave_max_nonneg(vm);
-            const unsigned long long b0 = __ballot(v0 == best), b1 = __ballot(v1 == best);
-            const bool singular = !(best > 0.0) || (b0 == 0 && b1 == 0);
-            if (singular) { if (lane == 0) flag[0] = 1; }
-            else {
-                const int prow = b0 ? k + __builtin_ctzll(b0) : k + 64 + __builtin_ctzll(b1);
-                const int src_lane = (prow - k) & 63;
-                const double piv = __shfl(prow - k >= 64 ? e1 : e0, src_lane, 64);   // E[prow][k]
-                const double ek = __shfl(e0, 0, 64);                                  // E[k][k] (moves to row prow)
-                // multipliers of rows i > k AFTER the swap (row prow then holds the old row k)
-                if (i0 > k && i0 < kNR) Lcol[i0] = (i0 == prow ? ek : e0) / piv;
-                if (i1 < kNR) Lcol[i1] = (i1 == prow ? ek : e1) / piv;
-                // swap rows k <-> prow on columns k..119 and publish the pivot row
-                for (int j = k + lane; j < kNC; j += 64) {
-                    const double aold = E[k * kLD + j], bnew = E[prow * kLD + j];
-                    prow_buf[j] = bnew;
-                    E[k * kLD + j] = bnew;
-                    E[prow * kLD + j] = aold;
-                }
-            }
+        // -- S1: EVERY wave finds the pivot itself (no cross-wave hand-off): max |column k| over the live rows and, among the
+        //    rows attaining it, the smallest LOGICAL index (the reference's "first row attaining the max")
+        const int i0 = lane, i1 = lane + 64;
+        const int lp0 = logpos[i0], lp1 = i1 < kNR ? logpos[i1] : -1;   // i0 < 64 < 93 always valid
+        const bool al0 = lp0 >= k, al1 = lp1 >= k;                      // pivots sit at logical positions < k
+        const double v0 = al0 ? fabs(colbuf[i0]) : -1.0, v1 = al1 ? fabs(colbuf[i1]) : -1.0;
+        double vm = v0 > 0.0 ? v0 : 0.0;                                // NaN never wins, as in the reference scan
+        if (v1 > vm) vm = v1;
+        const double best = wave_max_nonneg(vm);
+        const unsigned long long t0 = __ballot(al0 && v0 == best), t1 = __ballot(al1 && v1 == best);
+        int plog = 0x7fffffff;
+        if (__popcll(t0) + __popcll(t1) == 1) plog = t0 ? __builtin_amdgcn_readlane(lp0, __builtin_ctzll(t0)) : __builtin_amdgcn_readlane(lp1, __builtin_ctzll(t1 ? t1 : 1ull));
+        else if (t0 | t1) {                                              // exact ties are rare: butterfly min over logical indices
+            plog = (al0 && v0 == best) ? lp0 : 0x7fffffff;
+            if (al1 && v1 == best && lp1 < plog) plog = lp1;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(plog, m, 64); plog = o < plog ? o : plog; }
+        }
+        if (!(best > 0.0) || plog == 0x7fffffff) { singular = true; break; }   // same decision in every wave
+        const int prow = physof[plog];
+        const double piv = colbuf[prow];
+        if (lane < 24) {   // multipliers of this wave's row group
+            const int row = ty + 4 * lane;
+            double l = 0.0;
+            if (row < kNR && logpos[row] >= k && row != prow) l = colbuf[row] / piv;
+            Lw[wave * 24 + lane] = l;
+        }
+        if ((prow & 3) == ty && tx < kNC) {   // owners of the pivot row publish it: dynamic slot -> static select chain
+            const int ps = prow >> 2;
+            double u = er[0];
+#pragma unroll
+            for (int sl = 1; sl < 24; sl++) u = (ps == sl) ? er[sl] : u;
+            prow_buf[tx] = u;
+            if (k >= 66) Urows[(k - 66) * kNC + tx] = u;
+            live &= ~(1u << ps);
         }
         __syncthreads();
-        if (flag[0]) break;
+        // -- S2: rank-1 update of the live rows (registers), next pivot column -> colbuf, logical swap bookkeeping
+        if (tid == 0) {   // the reference swaps logical rows k and plog
+            const int rk = physof[k];
+            physof[k] = prow; physof[plog] = rk;
+            logpos[rk] = plog; logpos[prow] = k;
+        }
         {
-            const int tx = tid & 127, ty = tid >> 7;   // column lane, row phase (kSolveThreads / 128 phases)
-            const int j = k + 1 + tx;
-            if (j < kNC) {
-                constexpr int NTY = kSolveThreads / 128, UNR = 6;
-                const double ukj = prow_buf[j];
-                for (int ib = k + 1 + ty; ib < kNR; ib += NTY * UNR) {
-                    double ev[UNR], lv[UNR];
+            // all 24 multipliers of this wave's row group in one batch of independent LDS reads (dead rows and the pivot
+            // row carry l = 0); `live` is wave-uniform (same ty across a wave), so dead slots are skipped by scalar branches
+            double lv[24];
 #pragma unroll
-                    for (int u = 0; u < UNR; u++) {   // batched, mutually independent LDS loads
-                        const int i = ib + u * NTY;
-                        if (i < kNR) { ev[u] = E[i * kLD + j]; lv[u] = Lcol[i]; }
-                    }
+            for (int sl = 0; sl < 24; sl++) lv[sl] = Lw[wave * 24 + sl];
+            const double ukj = prow_buf[tx < kNC ? tx : 0];
+            const bool upd = tx > k && tx < kNC;
+            // branch-free: dead rows and the pivot row have l == 0 and keep their value (the reference skips l == 0 too)
 #pragma unroll
-                    for (int u = 0; u < UNR; u++) {
-                        const int i = ib + u * NTY;
-                        if (i < kNR && lv[u] != 0.0) E[i * kLD + j] = ev[u] - lv[u] * ukj;
-                    }
-                }
+            for (int sl = 0; sl < 24; sl++) {
+                const double nv = er[sl] - lv[sl] * ukj;
+                er[sl] = (upd && lv[sl] != 0.0) ? nv : er[sl];
+            }
+            if (tx == k + 1) {   // next pivot column (dead rows are written too, nobody reads them)
+#pragma unroll
+                for (int sl = 0; sl < 24; sl++) colbuf[ty + 4 * sl] = er[sl];
             }
         }
         __syncthreads();
     }
-    if (flag[0]) {
+    if (singular) {
         if (tid == 0) a.ok[hyp] = 0;
         return;
     }
-    // ---- back-substitution: only the last 27 unknowns (boundary monomials) are referenced by B ----
+    // ---- back-substitution: only the last 27 unknowns (boundary monomials) are referenced by B; Urows[i-66] = row i of U ----
     if (tid < 27) {
         const int c = tid;
         for (int i = kNR - 1; i >= kNR - 27; i--) {
-            double s = E[i * kLD + 93 + c];
-            for (int j = i + 1; j < kNR; j++) s = s - E[i * kLD + j] * Xb[(j - 66) * 27 + c];
-            Xb[(i - 66) * 27 + c] = s / E[i * kLD + i];
+            const double *Ui = Urows + (i - 66) * kNC;
+            double s = Ui[93 + c];
+            for (int j = i + 1; j < kNR; j++) s = s - Ui[j] * Xb[(j - 66) * 27 + c];
+            Xb[(i - 66) * 27 + c] = s / Ui[i];
         }
     }
     __syncthreads();
@@ -901,7 +939,7 @@ extern "C" int chip_pnp_ransac(chip_ctx *c, const double *X, const double *uv, i
     SolveArgs sa;
     sa.X = st->X; sa.uv = st->uv; sa.N = N; sa.S = S; sa.seed = p->seed; sa.tab = st->tab_dev;
     sa.Sg = st->Sg; sa.Tg = st->Tg; sa.sample = st->sample; sa.ok = st->ok;
-    const size_t lds = sizeof(double) * (kNR * kLD + kSampleMax * 8 + 9 + 9 + 27 + 27 + 81 + 90 + 100 + 36 + 60 + 4 + 27 * 27 + 96 + 128) + sizeof(int) * (16 + 32 + 32 + 2);
+    const size_t lds = sizeof(double) * (kSampleMax * 8 + 9 + 9 + 27 + 27 + 81 + 90 + 100 + 36 + 60 + 4 + 27 * 27 + 8 * 24 + 128 + 96 + 27 * kNC) + sizeof(int) * (16 + 32 + 32 + 4 + 96 + 96) + sizeof(short) * (kNR * 20) + 64;
     hipLaunchKernelGGL(pnp_build_solve, dim3(H), dim3(kSolveThreads), lds, s, sa);
     CHIP_HIP(c, hipGetLastError());
 

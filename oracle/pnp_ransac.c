@@ -328,6 +328,9 @@ int orc_dls_action_matrix(const double f[3][20], const double u[4], double S[27 
 
 /* ================================================================ 27x27 real eigenproblem (real eigenpairs only) */
 #define EN 27
+/* diagnostics (tests / tuning only): QR sweeps and k-steps of the last orc_eig27_real call on this thread */
+static __thread long dbg_sweeps, dbg_ksteps;
+void orc_eig27_last_stats(long *sweeps, long *ksteps) { *sweeps = dbg_sweeps; *ksteps = dbg_ksteps; }
 /* Householder reduction to upper Hessenberg form with accumulated transformations (orthes + ortran). */
 static void hessenberg(double H[EN][EN], double V[EN][EN])
 {
@@ -456,6 +459,7 @@ static int francis_qr(double H[EN][EN], double V[EN][EN], double wr[EN], double 
                 }
             }
             iter++;
+            dbg_sweeps++;
             if (iter > 60) return -1;
             int m = n - 2;
             while (m >= l) { /* two consecutive small sub-diagonal elements */
@@ -474,6 +478,7 @@ static int francis_qr(double H[EN][EN], double V[EN][EN], double wr[EN], double 
             for (int i = m + 2; i <= n; i++) { H[i][i - 2] = 0.0; if (i > m + 2) H[i][i - 3] = 0.0; }
             for (int k = m; k <= n - 1; k++) { /* double QR step on rows l..n, columns m..n */
                 int notlast = (k != n - 1);
+                dbg_ksteps++;
                 if (k != m) {
                     p = H[k][k - 1]; q = H[k + 1][k - 1]; r = notlast ? H[k + 2][k - 1] : 0.0;
                     x = fabs(p) + fabs(q) + fabs(r);
@@ -552,6 +557,7 @@ int orc_eig27_real(const double S[27 * 27], double lambda[27], double v4[27][4])
     for (int i = 0; i < EN; i++)
         for (int j = 0; j < EN; j++) H[i][j] = S[EN * i + j];
     memset(V, 0, sizeof V);
+    dbg_sweeps = dbg_ksteps = 0;
     hessenberg(H, V);
     if (francis_qr(H, V, wr, wi) != 0) return -1;
     int cnt = 0;
