@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <sstream>
 #include <thread>
 
@@ -79,6 +80,107 @@ bool Cerebro::descrip_N__dot__descrip_0_N_once(int64_t l, chip_tick_result *deta
     std::lock_guard<std::mutex> lk(m_foundLoops);                     // :1078-1081
     foundLoops.push_back(std::make_tuple(t_curr, t_prev, r.score));
     return true;
+}
+
+// index.search(1, X_raw, 5, distances, labels) for n_rows query rows against the index prefix [0, ntotal)
+bool Cerebro::index_search(int64_t ntotal, const int64_t *rows, int n_rows, float *distances, int64_t *labels)
+{
+    constexpr int K = 5;
+    for (int q0 = 0; q0 < n_rows; q0 += CHIP_MAX_NQ) {
+        const int nq = n_rows - q0 < CHIP_MAX_NQ ? n_rows - q0 : CHIP_MAX_NQ;   // one pass of the prefix serves up to 4 queries
+        double s[CHIP_MAX_NQ * K];
+        status_ = chip_query_rows(ctx_, ntotal, rows + q0, nq, K, s, labels + (size_t)q0 * K);
+        if (status_ != CHIP_OK) return false;
+        for (int i = 0; i < nq * K; i++) distances[(size_t)q0 * K + i] = (float)s[i];   // faiss distances are float
+    }
+    return true;
+}
+
+int Cerebro::faiss__naive_loopcandidate_generator_once(int64_t l)
+{
+    if (!ctx_) return 0;
+    constexpr int start_adding_descriptors_to_index_after = 150, LOCALITY_THRESH = 12;   // Cerebro.cpp:375-376
+    const float DOT_PROD_THRESH = 0.9f;                                                   // :377
+    if (l < 0) l = wholeImageComputedList_size();                                         // :401
+    status_ = CHIP_OK;
+    if (l - naive_last_l_ < 3) return 0;                                                  // :403-407
+    if (l > start_adding_descriptors_to_index_after)                                      // :415-433 (the rows are already on the device)
+        naive_l_last_added_to_index_ = l - start_adding_descriptors_to_index_after;
+    const int64_t ntotal = naive_l_last_added_to_index_;
+    std::vector<float> tmp_;
+    std::vector<int> tmp_i;
+    const int64_t n_new = l - naive_last_l_;
+    if (ntotal >= 5 && n_new == 3) {                       // :451; any other count can never satisfy _n == 3 (:476)
+        int64_t rows[3] = {naive_last_l_, naive_last_l_ + 1, naive_last_l_ + 2}, labels[15];
+        float distances[15];
+        if (!index_search(ntotal, rows, 3, distances, labels)) return 0;
+        for (int i = 0; i < 3; i++) { tmp_.push_back(distances[5 * i]); tmp_i.push_back((int)labels[5 * i]); }   // :471-472
+    }
+    int pushed = 0;
+    const int _n = (int)tmp_.size();
+    if (_n == 3 && tmp_[_n - 1] > DOT_PROD_THRESH && std::abs(tmp_i[0] - tmp_i[1]) < LOCALITY_THRESH &&
+        std::abs(tmp_i[0] - tmp_i[2]) < LOCALITY_THRESH) {                                // :476
+        const Time a = wholeImageComputedList_at((int)l - 1), b = wholeImageComputedList_at(tmp_i[2]);
+        std::lock_guard<std::mutex> lk(m_foundLoops);                                     // :483-484
+        foundLoops.push_back(std::make_tuple(a, b, (double)tmp_[2]));
+        pushed = 1;
+    }
+    naive_last_l_ = l;                                                                    // :488
+    return pushed;
+}
+
+int Cerebro::faiss_clique_loopcandidate_generator_once(int64_t l)
+{
+    if (!ctx_) return 0;
+    constexpr int start_adding_descriptors_to_index_after = 150, K_NEAREST_NEIGHBOURS = 5, LOCALITY = 7,
+                  reset_accumulation_every_n_frames = 4;                                  // Cerebro.cpp:515-519
+    const double DOT_PROD_THRESH = 0.85;
+    if (l < 0) l = wholeImageComputedList_size();                                         // :542
+    status_ = CHIP_OK;
+    if (l <= clique_last_l_) return 0;                                                    // :543-547
+    if (l > start_adding_descriptors_to_index_after)                                      // :558-582
+        clique_l_last_added_to_index_ = l - start_adding_descriptors_to_index_after;
+    const int64_t ntotal = clique_l_last_added_to_index_;
+    int pushed = 0;
+    if (ntotal >= K_NEAREST_NEIGHBOURS) {                                                 // :596 (ntotal is constant over the l_i loop)
+        // the searches of one iteration are independent of `retained`: run them first, up to 4 per pass of the prefix
+        const int n_new = (int)(l - clique_last_l_);
+        std::vector<int64_t> rows((size_t)n_new), labels((size_t)n_new * K_NEAREST_NEIGHBOURS);
+        std::vector<float> distances((size_t)n_new * K_NEAREST_NEIGHBOURS);
+        for (int i = 0; i < n_new; i++) rows[(size_t)i] = clique_last_l_ + i;
+        if (!index_search(ntotal, rows.data(), n_new, distances.data(), labels.data())) return 0;
+        const Time t_curr = wholeImageComputedList_at((int)l - 1);
+        for (int i = 0; i < n_new; i++) {
+            const int64_t l_i = rows[(size_t)i];
+            for (int g = 0; g < K_NEAREST_NEIGHBOURS; g++) {                              // :625-650
+                const float d = distances[(size_t)i * K_NEAREST_NEIGHBOURS + g];
+                const int64_t label = labels[(size_t)i * K_NEAREST_NEIGHBOURS + g];
+                if (d < DOT_PROD_THRESH) break;
+                int64_t duplicate = -1;
+                for (auto ity = retained_.begin(); ity != retained_.end(); ity++)
+                    if ((ity->first - label) < LOCALITY) { duplicate = ity->first; break; }   // :634 (signed, as upstream)
+                if (duplicate != -1) retained_[duplicate]++;
+                else retained_[label] = 1;
+            }
+            if (retained_.size() > 0 && l_i % reset_accumulation_every_n_frames == 0) {   // :653
+                auto push = [&](int64_t prev) {
+                    const Time b = wholeImageComputedList_at((int)prev);
+                    std::lock_guard<std::mutex> lk(m_foundLoops);
+                    foundLoops.push_back(std::make_tuple(t_curr, b, 0.9));                // :680-683 / :695-697
+                    pushed++;
+                };
+                if (retained_.size() == 1) push(retained_.begin()->first);                // :672
+                if (retained_.size() > 1) {                                               // :686
+                    const int percent = (int)(100. / retained_.size());
+                    for (auto ity = retained_.begin(); ity != retained_.end(); ity++)
+                        if ((rand_source ? rand_source() : std::rand()) % 100 < percent) push(ity->first);
+                }
+                retained_.clear();                                                        // :703
+            }
+        }
+    }
+    clique_last_l_ = l;                                                                   // :710
+    return pushed;
 }
 
 void Cerebro::run(double rate_hz)

@@ -12,6 +12,8 @@
 #include <array>
 #include <atomic>
 #include <cstdint>
+#include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <tuple>
@@ -72,6 +74,17 @@ public:
     void run_thread_enable() { b_run_thread = true; }
     void run_thread_disable() { b_run_thread = false; }
 
+    // ---- top-k candidate policies on a flat inner-product index (upstream: faiss::IndexFlatIP, HAVE_FAISS builds only).
+    // The "index" is the prefix [0, l-150) of the device DB; index.search(1, x, 5) is chip_query_rows(k, row, topk=5)
+    // with the fp64 score rounded to float.  One call = one iteration of the respective while-loop body.
+    //   faiss__naive_loopcandidate_generator   Cerebro.cpp:366-492: 3 consecutive top-1 labels within 12, last score > 0.9f
+    //   faiss_clique_loopcandidate_generator   Cerebro.cpp:506-722: neighbours > 0.85 accumulated in `retained` (LOCALITY 7),
+    //                                          flushed when l_i % 4 == 0, rand()-thinned when more than one key
+    // Return the number of candidates pushed to foundLoops.
+    int faiss__naive_loopcandidate_generator_once(int64_t l = -1);
+    int faiss_clique_loopcandidate_generator_once(int64_t l = -1);
+    std::function<int()> rand_source;  // rand() of Cerebro.cpp:692; defaults to std::rand
+
     // ---- foundLoops (Cerebro.h:152-158)
     int foundLoops_count() const;
     std::tuple<Time, Time, double> foundLoops_i(int i) const;
@@ -91,6 +104,11 @@ private:
     mutable std::mutex m_foundLoops;
     std::vector<std::tuple<Time, Time, double>> foundLoops;
     std::atomic<bool> b_run_thread{false};
+    // state of the two index policies (function-locals of the reference: Cerebro.cpp:393-394 / :535-539)
+    bool index_search(int64_t ntotal, const int64_t *rows, int n_rows, float *distances, int64_t *labels);
+    int64_t naive_last_l_ = 0, naive_l_last_added_to_index_ = 0;
+    int64_t clique_last_l_ = 0, clique_l_last_added_to_index_ = 0;
+    std::map<int64_t, int> retained_;
 };
 
 struct StaticTheiaPoseCompute {

@@ -132,13 +132,26 @@ static int threeway(const char *in, int device)
     return 0;
 }
 
+// --policy naive|clique <stream.bin> <out.json> [device] : same stream format, but each tick runs one iteration of
+// faiss__naive_loopcandidate_generator / faiss_clique_loopcandidate_generator instead of descrip_N__dot__descrip_0_N.
+// rand() of the clique policy is replaced by the ANSI C example generator seeded with 1 so replays are reproducible.
+static unsigned long g_rand_next = 1;
+static int replay_rand() { g_rand_next = g_rand_next * 1103515245ul + 12345ul; return (int)((g_rand_next / 65536ul) % 32768ul); }
+
 int main(int argc, char **argv)
 {
+    int policy = 0;
+    if (argc >= 5 && std::strcmp(argv[1], "--policy") == 0) {
+        policy = std::strcmp(argv[2], "naive") == 0 ? 1 : std::strcmp(argv[2], "clique") == 0 ? 2 : -1;
+        if (policy < 0) { std::fprintf(stderr, "unknown policy %s\n", argv[2]); return 2; }
+        argv += 2;
+        argc -= 2;
+    }
     if (argc >= 3 && std::strcmp(argv[1], "--gate") == 0) return gate(argv[2]);
     if (argc >= 3 && std::strcmp(argv[1], "--threeway") == 0) return threeway(argv[2], argc > 3 ? std::atoi(argv[3]) : 0);
     if (argc >= 4 && std::strcmp(argv[1], "--parse-only") == 0) return parse_only(argv[2], argv[3]);
     if (argc >= 4 && std::strcmp(argv[1], "--state") == 0) return from_state(argv[2], argv[3], argc > 4 ? std::atoi(argv[4]) : 0);
-    if (argc < 3) { std::fprintf(stderr, "usage: %s <stream.bin> <out.json> [device] | --state <state.json> <out.json> [device] | --parse-only <state.json> <out.bin>\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s [--policy naive|clique] <stream.bin> <out.json> [device] | --state <state.json> <out.json> [device] | --parse-only <state.json> <out.bin>\n", argv[0]); return 2; }
     FILE *f = std::fopen(argv[1], "rb");
     if (!f) { std::perror(argv[1]); return 2; }
     char magic[4];
@@ -160,6 +173,7 @@ int main(int argc, char **argv)
     std::fclose(f);
     cerebro_hip::Cerebro cer((int)D, argc > 3 ? std::atoi(argv[3]) : 0, (int64_t)N);
     if (!cer.ok()) { std::fprintf(stderr, "chip_create failed: %s\n", chip_strerror(cer.last_status())); return 3; }
+    cer.rand_source = replay_rand;
     int64_t appended = 0;
     for (uint64_t t = 0; t < T; t++) {
         const int64_t l = ticks[t];
@@ -168,7 +182,9 @@ int main(int argc, char **argv)
                 std::fprintf(stderr, "append failed at row %lld: %s\n", (long long)appended, chip_strerror(cer.last_status()));
                 return 4;
             }
-        cer.descrip_N__dot__descrip_0_N_once();
+        if (policy == 1) cer.faiss__naive_loopcandidate_generator_once();
+        else if (policy == 2) cer.faiss_clique_loopcandidate_generator_once();
+        else cer.descrip_N__dot__descrip_0_N_once();
         if (cer.last_status() != CHIP_OK) { std::fprintf(stderr, "tick failed: %s\n", chip_strerror(cer.last_status())); return 5; }
     }
     FILE *o = std::fopen(argv[2], "w");

@@ -142,6 +142,19 @@ void   orc_icp_params_default(orc_ransac_params *p);
 int    orc_icp_ransac(const double *A, const double *B, int32_t N, const orc_ransac_params *p,
                       double T[16], float *confidence, uint8_t *mask, orc_ransac_summary *summary);
 
+/* ================================================================== top-k candidate policies (policies.c, row N4) */
+typedef struct { int64_t idx_curr, idx_prev; double score; } orc_policy_loop;
+typedef struct { int64_t last_l, l_last_added; } orc_naive_state;                      /* zero-initialise */
+#define ORC_CLIQUE_MAX_RETAINED 64
+typedef struct { int64_t last_l, l_last_added; int32_t n_retained; int32_t pad_;
+                 int64_t key[ORC_CLIQUE_MAX_RETAINED]; int32_t cnt[ORC_CLIQUE_MAX_RETAINED]; } orc_clique_state;   /* zero-initialise */
+/* One iteration of Cerebro::faiss__naive_loopcandidate_generator (Cerebro.cpp:400-489); returns 0/1 loops written. */
+int32_t orc_faiss_naive_tick(const float *db, int32_t D, int64_t l, orc_naive_state *st, orc_policy_loop *out);
+/* One iteration of Cerebro::faiss_clique_loopcandidate_generator (Cerebro.cpp:541-711); rnd replaces rand() (:692).
+ * Returns the number of loops produced (written up to max_out). */
+int32_t orc_faiss_clique_tick(const float *db, int32_t D, int64_t l, orc_clique_state *st,
+                              int (*rnd)(void *), void *rnd_arg, orc_policy_loop *out, int32_t max_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,1 +1,3 @@
-(timeout 900 python -m pytest tests/test_batch_gpu.py -x -q 2>&1 | tail -15)
+#!/bin/bash
+mkdir -p gpurun_out
+python -m pytest tests -x -q -m gpu -k "policy or replay" 2>&1 | tail -8

@@ -333,3 +333,63 @@ def icp_ransac(A, B, params: OrcRansacParams | None = None):
     return dict(status=rc, confidence=float(conf.value), T=T.reshape(4, 4).T.copy(), mask=mask[:A.shape[0]].copy(),
                 summary=dict(n_iterations=s.n_iterations, n_inliers=s.n_inliers, best_hypothesis=s.best_hypothesis,
                              n_models=s.n_models, best_cost=s.best_cost))
+
+
+# ================================================================== top-k candidate policies (oracle/policies.c)
+class OrcPolicyLoop(C.Structure):
+    _fields_ = [("idx_curr", C.c_int64), ("idx_prev", C.c_int64), ("score", C.c_double)]
+
+
+class OrcNaiveState(C.Structure):
+    _fields_ = [("last_l", C.c_int64), ("l_last_added", C.c_int64)]
+
+
+class OrcCliqueState(C.Structure):
+    _fields_ = [("last_l", C.c_int64), ("l_last_added", C.c_int64), ("n_retained", C.c_int32), ("pad_", C.c_int32),
+                ("key", C.c_int64 * 64), ("cnt", C.c_int32 * 64)]
+
+
+RND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class AnsiRand:
+    """The ANSI C example rand() (seed 1) that cerebro_replay --policy installs as rand_source."""
+
+    def __init__(self, seed=1):
+        self.x = seed
+
+    def __call__(self, *_):
+        self.x = (self.x * 1103515245 + 12345) % (1 << 64)
+        return (self.x // 65536) % 32768
+
+
+class NaivePolicyOracle:
+    def __init__(self, db):
+        self.db = np.ascontiguousarray(db, dtype=np.float32)
+        self.st = OrcNaiveState(0, 0)
+        self.lib = load()
+        self.lib.orc_faiss_naive_tick.restype = C.c_int32
+        self.lib.orc_faiss_naive_tick.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(OrcNaiveState), C.POINTER(OrcPolicyLoop)]
+
+    def tick(self, l):
+        out = OrcPolicyLoop()
+        n = self.lib.orc_faiss_naive_tick(_p(self.db), self.db.shape[1], l, C.byref(self.st), C.byref(out))
+        return [(out.idx_curr, out.idx_prev, out.score)] if n else []
+
+
+class CliquePolicyOracle:
+    def __init__(self, db, rnd=None):
+        self.db = np.ascontiguousarray(db, dtype=np.float32)
+        self.st = OrcCliqueState()
+        self.rnd = rnd or AnsiRand()
+        self._cb = RND_FN(lambda _arg: self.rnd())
+        self.lib = load()
+        self.lib.orc_faiss_clique_tick.restype = C.c_int32
+        self.lib.orc_faiss_clique_tick.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(OrcCliqueState), RND_FN, C.c_void_p,
+                                                   C.POINTER(OrcPolicyLoop), C.c_int32]
+
+    def tick(self, l):
+        out = (OrcPolicyLoop * 32)()
+        n = self.lib.orc_faiss_clique_tick(_p(self.db), self.db.shape[1], l, C.byref(self.st), self._cb, None, out, 32)
+        assert n <= 32
+        return [(out[i].idx_curr, out[i].idx_prev, out[i].score) for i in range(n)]

@@ -141,3 +141,23 @@ def test_cold_start_from_state_json_matches_oracle(tmp_path):
             want.append((o["idx_curr"], o["idx_prev"], o["score"]))
     assert [(g["global_a"], g["global_b"], g["score"]) for g in got] == want and len(want) >= len(loops)
     assert got[0]["time_sec_a"] == stamps[want[0][0]] // 10**9 and got[0]["time_nsec_a"] == stamps[want[0][0]] % 10**9
+
+
+# ------------------------------------------------------------------ N4: top-k candidate policies over the C ABI
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy,step", [("naive", 3), ("clique", 1), ("clique", 3), ("clique", 5)])
+def test_policy_replay_matches_oracle(tmp_path, policy, step):
+    import test_oracle_policies as pol
+    db, plants = pol.policy_db(seed=9)
+    N = db.shape[0]
+    stamps = [(1403636579 + i // 20, (i % 20) * 50_000_000) for i in range(N)]
+    ticks = list(range(step, N + 1, step))
+    write_stream(tmp_path / "s.bin", db, stamps, ticks)
+    r = subprocess.run([str(LIB / "cerebro_replay"), "--policy", policy, str(tmp_path / "s.bin"), str(tmp_path / "o.json")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = json.loads((tmp_path / "o.json").read_text())
+    orc = oracle_lib.NaivePolicyOracle(db) if policy == "naive" else oracle_lib.CliquePolicyOracle(db, oracle_lib.AnsiRand())
+    want = [x for l in ticks for x in orc.tick(l)]
+    assert len(want) >= 3
+    assert [(g["global_a"], g["global_b"], g["score"]) for g in got] == want      # indices and float scores bit-exact
