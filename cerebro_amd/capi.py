@@ -111,6 +111,7 @@ _SIGS = {
     "chip_ransac_params_default": (None, [C.POINTER(RansacParams)]),
     "chip_pnp_ransac": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(RansacParams), _P, C.POINTER(C.c_float), _P,
                                   C.POINTER(RansacSummary)]),
+    "chip_pnp_ransac_batch": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.POINTER(RansacParams), _P, _P, _P, _P, _P]),
     "chip_icp_params_default": (None, [C.POINTER(RansacParams)]),
     "chip_icp_ransac": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(RansacParams), _P, C.POINTER(C.c_float), _P,
                                   C.POINTER(RansacSummary)]),
@@ -356,6 +357,30 @@ class Chip:
                     summary=dict(n_iterations=summ.n_iterations, n_inliers=summ.n_inliers,
                                  best_hypothesis=summ.best_hypothesis, n_models=summ.n_models,
                                  best_cost=summ.best_cost))
+
+    def pnp_ransac_batch(self, problems, params: RansacParams | None = None, seeds=None):
+        """problems: list of (X (N_i,3), uv (N_i,2)).  One pair of launches for the whole list; entry i equals
+        pnp_ransac(X_i, uv_i) run with seed seeds[i] (default: params.seed for all)."""
+        P = len(problems)
+        Xs = [np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 3) for X, _ in problems]
+        uvs = [np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2) for _, uv in problems]
+        Ns = np.array([x.shape[0] for x in Xs], dtype=np.int32)
+        p = params or default_ransac_params()
+        T = np.empty((P, 16), dtype=np.float64)
+        conf = np.zeros(P, dtype=np.float32)
+        masks = [np.zeros(max(int(n), 1), dtype=np.uint8) for n in Ns]
+        summ = (RansacSummary * max(P, 1))()
+        Xp = (C.c_void_p * max(P, 1))(*[x.ctypes.data for x in Xs])
+        uvp = (C.c_void_p * max(P, 1))(*[u.ctypes.data for u in uvs])
+        mp = (C.c_void_p * max(P, 1))(*[m.ctypes.data for m in masks])
+        sd = None if seeds is None else np.asarray(seeds, dtype=np.uint64)
+        st = self.lib.chip_pnp_ransac_batch(self.h, P, Xp, uvp, _ptr(Ns), C.byref(p), None if sd is None else _ptr(sd),
+                                            _ptr(T), _ptr(conf), mp, summ)
+        self._chk(st, "chip_pnp_ransac_batch")
+        return [dict(status=st, confidence=float(conf[i]), T=T[i].reshape(4, 4).T.copy(), mask=masks[i][:Ns[i]].copy(),
+                     summary=dict(n_iterations=summ[i].n_iterations, n_inliers=summ[i].n_inliers,
+                                  best_hypothesis=summ[i].best_hypothesis, n_models=summ[i].n_models,
+                                  best_cost=summ[i].best_cost)) for i in range(P)]
 
     def icp_ransac(self, A: np.ndarray, B: np.ndarray, params: RansacParams | None = None):
         A = np.ascontiguousarray(A, dtype=np.float64).reshape(-1, 3)

@@ -130,11 +130,21 @@ __device__ __forceinline__ double wave_max_nonneg(double v)
 // ------------------------------------------------------------------------------------------------ K4 + K5a
 constexpr int kNR = 93, kNC = 120;
 
-struct SolveArgs {
+// One RANSAC problem of a launch.  A launch covers up to kPnpMaxBatch independent problems (same parameters, own
+// correspondences and seed): workgroup b works on hypothesis b % H of problem b / H; all per-hypothesis arrays are
+// indexed by b.  A single wave per hypothesis leaves the SIMDs latency-bound at H = 1000, so co-scheduling the
+// independent estimations of a loop candidate (PNP a->b, PNP b->a: Cerebro.cpp:1518,1572) is nearly free.
+struct PnpProblem {
     const double *X;    // N x 3
     const double *uv;   // N x 2
-    int32_t N, S;
+    int32_t N, pad_;
     uint64_t seed;
+};
+constexpr int kPnpMaxBatch = 8;
+
+struct SolveArgs {
+    PnpProblem prob[kPnpMaxBatch];
+    int32_t H, S;
     const PnpTables *tab;
     double *Sg;         // [H][729]  action matrices
     double *Tg;         // [H][27]   translation factor (t = Tfac * vec(R))
@@ -177,15 +187,18 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int hyp = blockIdx.x;
+    const int slot = blockIdx.x;
+    const int pi = slot / a.H;
+    const int hyp = slot - pi * a.H;                               // hypothesis index within its problem (keys the RNG)
+    const PnpProblem pr = a.prob[pi];
     const int n = a.S;
     const PnpTables &tb = *a.tab;
 
     // ---- sampler: partial Fisher-Yates over a virtual identity permutation (theia::RandomSampler restated) ----
     if (tid == 0) {
-        ransac_sample_sparse(a.seed, hyp, a.N, n, fy_key, fy_val, smp);
+        ransac_sample_sparse(pr.seed, hyp, pr.N, n, fy_key, fy_val, smp);
         for (int j = 0; j < 4; j++) {   // random linear form f0 (Theia: 100 * Vector4d::Random())
-            const uint64_t x = rng_draw(a.seed, (uint32_t)hyp, (uint32_t)(64 + j));
+            const uint64_t x = rng_draw(pr.seed, (uint32_t)hyp, (uint32_t)(64 + j));
             const double f = (double)(x >> 11) * (1.0 / 9007199254740992.0);
             uu[j] = 100.0 * (2.0 * f - 1.0);
         }
@@ -194,9 +207,9 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     __syncthreads();
     if (tid < n) {
         const int s = smp[tid];
-        a.sample[hyp * kSampleMax + tid] = s;
-        const double X0 = a.X[3 * s], X1 = a.X[3 * s + 1], X2 = a.X[3 * s + 2];
-        const double u = a.uv[2 * s], v = a.uv[2 * s + 1];
+        a.sample[slot * kSampleMax + tid] = s;
+        const double X0 = pr.X[3 * s], X1 = pr.X[3 * s + 1], X2 = pr.X[3 * s + 2];
+        const double u = pr.uv[2 * s], v = pr.uv[2 * s + 1];
         sx[3 * tid] = X0; sx[3 * tid + 1] = X1; sx[3 * tid + 2] = X2;
         suv[2 * tid] = u; suv[2 * tid + 1] = v;
         const double nrm = sqrt((u * u + v * v) + 1.0);
@@ -243,7 +256,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
         Tf[tid] = (Hm[3 * aa] * W[j] + Hm[3 * aa + 1] * W[9 + j]) + Hm[3 * aa + 2] * W[18 + j];
     }
     __syncthreads();
-    if (tid < 27) a.Tg[hyp * 27 + tid] = Tf[tid];
+    if (tid < 27) a.Tg[slot * 27 + tid] = Tf[tid];
     // ---- M9 = sum (L+T)^T (I - z z^T) (L+T) ----
     if (tid < 81) {
         const int j = tid / 9, k = tid % 9;
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
         __syncthreads();
     }
     if (singular) {
-        if (tid == 0) a.ok[hyp] = 0;
+        if (tid == 0) a.ok[slot] = 0;
         return;
     }
     // ---- back-substitution: only the last 27 unknowns (boundary monomials) are referenced by B; Urows[i-66] = row i of U ----
@@ -413,18 +426,17 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
             const int col = tb.s_col[r][t];
             if (col >= 27) s = s - uu[t] * Xb[(col - 93) * 27 + j];
         }
-        a.Sg[(size_t)hyp * 729 + e] = s;
+        a.Sg[(size_t)slot * 729 + e] = s;
     }
-    if (tid == 0) a.ok[hyp] = 1;
+    if (tid == 0) a.ok[slot] = 1;
 }
 
 // ------------------------------------------------------------------------------------------------ K5b + K6
 constexpr int EN = 27;
 
 struct EigArgs {
-    const double *X;
-    const double *uv;
-    int32_t N, S;
+    PnpProblem prob[kPnpMaxBatch];
+    int32_t H, S;
     double thresh;
     int32_t use_mle;
     const double *Sg;       // [H][729]
@@ -450,7 +462,8 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     __shared__ double Hs[EN * EN], Vs[EN * EN], Xs[EN * EN];
     __shared__ double ort[EN], ortm[EN], wr[EN], wi[EN], Tf[27], sxs[kSampleMax * 3], model[16];
     const int lane = threadIdx.x;
-    const int hyp = blockIdx.x;
+    const int hyp = blockIdx.x;                                    // slot: hypothesis (hyp % H) of problem (hyp / H)
+    const PnpProblem pr = a.prob[hyp / a.H];
     const int low = 0, high = EN - 1, nn = EN;
     const double eps = DBL_EPSILON;
 
@@ -462,7 +475,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     if (lane < 27) Tf[lane] = a.Tg[hyp * 27 + lane];
     if (lane < a.S) {
         const int s = a.sample[hyp * kSampleMax + lane];
-        sxs[3 * lane] = a.X[3 * s]; sxs[3 * lane + 1] = a.X[3 * s + 1]; sxs[3 * lane + 2] = a.X[3 * s + 2];
+        sxs[3 * lane] = pr.X[3 * s]; sxs[3 * lane + 1] = pr.X[3 * s + 1]; sxs[3 * lane + 2] = pr.X[3 * s + 2];
     }
     __syncthreads();
 
@@ -796,16 +809,16 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     if (lane < 16) a.T_out[hyp * 16 + lane] = model[lane];
     double acc = 0.0;
     int cnt = 0;
-    for (int base = 0; base < a.N; base += 64) {
+    for (int base = 0; base < pr.N; base += 64) {
         const int i = base + lane;
         bool in = false;
-        if (i < a.N) {
-            const double X0 = a.X[3 * i], X1 = a.X[3 * i + 1], X2 = a.X[3 * i + 2];
+        if (i < pr.N) {
+            const double X0 = pr.X[3 * i], X1 = pr.X[3 * i + 1], X2 = pr.X[3 * i + 2];
             const double xx = ((T[0] * X0 + T[4] * X1) + T[8] * X2) + T[12];
             const double yy = ((T[1] * X0 + T[5] * X1) + T[9] * X2) + T[13];
             const double zz = ((T[2] * X0 + T[6] * X1) + T[10] * X2) + T[14];
             const double xn = xx / zz, yn = yy / zz;
-            const double rr = fabs(xn - a.uv[2 * i]) + fabs(yn - a.uv[2 * i + 1]);
+            const double rr = fabs(xn - pr.uv[2 * i]) + fabs(yn - pr.uv[2 * i + 1]);
             in = rr < a.thresh;
             acc = acc + (in ? rr : a.thresh);
         }
@@ -818,7 +831,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     if (lane == 0) {
         a.valid[hyp] = 1;
         a.nin[hyp] = cnt;
-        a.cost[hyp] = a.use_mle ? acc : (double)(a.N - cnt);
+        a.cost[hyp] = a.use_mle ? acc : (double)(pr.N - cnt);
     }
 }
 
@@ -836,7 +849,7 @@ struct PnpState {
     double *h_cost = nullptr, *h_T = nullptr;
     int32_t *h_nin = nullptr, *h_valid = nullptr, *h_nsol = nullptr;
     unsigned long long *h_mask = nullptr;
-    int32_t hcap_H = 0, hcap_words = 0;
+    int32_t hcap_P = 0, hcap_words = 0;
 };
 
 int pnp_create(Ctx *c)
@@ -873,9 +886,8 @@ void pnp_destroy(Ctx *c)
     c->pnp_state = nullptr;
 }
 
-static int pnp_reserve(Ctx *c, PnpState *st, int N, int H)
+static int pnp_reserve(Ctx *c, PnpState *st, int N, int H, int words, int P)
 {
-    const int words = (N + 63) / 64;
     if (N > st->cap_N) {
         (void)hipFree(st->X); (void)hipFree(st->uv);
         st->X = st->uv = nullptr; st->cap_N = 0;
@@ -888,8 +900,7 @@ static int pnp_reserve(Ctx *c, PnpState *st, int N, int H)
         (void)hipFree(st->Sg); (void)hipFree(st->Tg); (void)hipFree(st->T_out); (void)hipFree(st->cost);
         (void)hipFree(st->sample); (void)hipFree(st->ok); (void)hipFree(st->nin); (void)hipFree(st->valid); (void)hipFree(st->nsol);
         (void)hipFree(st->mask);
-        (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid);
-        (void)hipHostFree(st->h_nsol); (void)hipHostFree(st->h_mask);
+        (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid);
         st->cap_H = st->cap_words = 0;
         CHIP_HIP(c, hipMalloc(&st->Sg, sizeof(double) * 729 * (size_t)nh));
         CHIP_HIP(c, hipMalloc(&st->Tg, sizeof(double) * 27 * (size_t)nh));
@@ -902,12 +913,105 @@ static int pnp_reserve(Ctx *c, PnpState *st, int N, int H)
         CHIP_HIP(c, hipMalloc(&st->nsol, sizeof(int32_t) * (size_t)nh));
         CHIP_HIP(c, hipMalloc(&st->mask, sizeof(unsigned long long) * (size_t)nh * nw));
         CHIP_HIP(c, hipHostMalloc(&st->h_cost, sizeof(double) * (size_t)nh, hipHostMallocDefault));
-        CHIP_HIP(c, hipHostMalloc(&st->h_T, sizeof(double) * 16, hipHostMallocDefault));
         CHIP_HIP(c, hipHostMalloc(&st->h_nin, sizeof(int32_t) * (size_t)nh, hipHostMallocDefault));
         CHIP_HIP(c, hipHostMalloc(&st->h_valid, sizeof(int32_t) * (size_t)nh, hipHostMallocDefault));
-        CHIP_HIP(c, hipHostMalloc(&st->h_nsol, sizeof(int32_t) * (size_t)nh, hipHostMallocDefault));
-        CHIP_HIP(c, hipHostMalloc(&st->h_mask, sizeof(unsigned long long) * (size_t)nw, hipHostMallocDefault));
         st->cap_H = nh; st->cap_words = nw;
+    }
+    if (P > st->hcap_P || words > st->hcap_words) {
+        const int np = P > st->hcap_P ? P : st->hcap_P, nw = words > st->hcap_words ? words : st->hcap_words;
+        (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_mask);
+        st->hcap_P = st->hcap_words = 0;
+        CHIP_HIP(c, hipHostMalloc(&st->h_T, sizeof(double) * 16 * (size_t)np, hipHostMallocDefault));
+        CHIP_HIP(c, hipHostMalloc(&st->h_mask, sizeof(unsigned long long) * (size_t)nw * np, hipHostMallocDefault));
+        st->hcap_P = np; st->hcap_words = nw;
+    }
+    return CHIP_OK;
+}
+
+// Up to kPnpMaxBatch problems in one pair of launches; problem i's outputs are exactly those of a single-problem call.
+static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const double *const *uv, const int32_t *N,
+                   const chip_ransac_params *p, const uint64_t *seeds, double *T_colmajor, float *confidence,
+                   uint8_t *const *inlier_mask, chip_ransac_summary *summary)
+{
+    const int32_t S = p->sample_size;
+    const int H = ransac_initial_iterations(p);
+    int Ntot = 0, words = 0;
+    for (int i = 0; i < P; i++) { Ntot += N[i]; const int w = (N[i] + 63) / 64; words = w > words ? w : words; }
+    int rc = pnp_reserve(c, st, Ntot, P * H, words, P);
+    if (rc != CHIP_OK) return rc;
+    hipStream_t s = c->s_pnp;
+
+    SolveArgs sa;
+    EigArgs ea;
+    std::memset(&sa, 0, sizeof sa);
+    std::memset(&ea, 0, sizeof ea);
+    for (int i = 0, off = 0; i < P; off += N[i], i++) {
+        CHIP_HIP(c, hipMemcpyAsync(st->X + 3 * (size_t)off, X[i], sizeof(double) * 3 * (size_t)N[i], hipMemcpyHostToDevice, s));
+        CHIP_HIP(c, hipMemcpyAsync(st->uv + 2 * (size_t)off, uv[i], sizeof(double) * 2 * (size_t)N[i], hipMemcpyHostToDevice, s));
+        PnpProblem pr;
+        pr.X = st->X + 3 * (size_t)off; pr.uv = st->uv + 2 * (size_t)off; pr.N = N[i]; pr.pad_ = 0;
+        pr.seed = seeds ? seeds[i] : p->seed;
+        sa.prob[i] = pr;
+        ea.prob[i] = pr;
+    }
+    sa.H = H; sa.S = S; sa.tab = st->tab_dev;
+    sa.Sg = st->Sg; sa.Tg = st->Tg; sa.sample = st->sample; sa.ok = st->ok;
+    const size_t lds = sizeof(double) * (kSampleMax * 8 + 9 + 9 + 27 + 27 + 81 + 90 + 100 + 36 + 60 + 4 + 27 * 27 + 8 * 24 + 128 + 96 + 27 * kNC) + sizeof(int) * (16 + 32 + 32 + 4 + 96 + 96) + sizeof(short) * (kNR * 20) + 64;
+    hipLaunchKernelGGL(pnp_build_solve, dim3(P * H), dim3(kSolveThreads), lds, s, sa);
+    CHIP_HIP(c, hipGetLastError());
+
+    ea.H = H; ea.S = S; ea.thresh = p->error_thresh; ea.use_mle = p->use_mle;
+    ea.Sg = st->Sg; ea.Tg = st->Tg; ea.sample = st->sample; ea.ok = st->ok; ea.mask_words = words;
+    { const char *dv = std::getenv("CHIP_PNP_DEBUG_STOP"); ea.debug_stop = dv ? std::atoi(dv) : 0; }
+    ea.T_out = st->T_out; ea.cost = st->cost; ea.nin = st->nin; ea.valid = st->valid; ea.nsol = st->nsol; ea.mask = st->mask;
+    hipLaunchKernelGGL(pnp_eig_score, dim3(P * H), dim3(64), 0, s, ea);
+    CHIP_HIP(c, hipGetLastError());
+
+    const size_t HT = (size_t)P * H;
+    CHIP_HIP(c, hipMemcpyAsync(st->h_cost, st->cost, sizeof(double) * HT, hipMemcpyDeviceToHost, s));
+    CHIP_HIP(c, hipMemcpyAsync(st->h_nin, st->nin, sizeof(int32_t) * HT, hipMemcpyDeviceToHost, s));
+    CHIP_HIP(c, hipMemcpyAsync(st->h_valid, st->valid, sizeof(int32_t) * HT, hipMemcpyDeviceToHost, s));
+    CHIP_HIP(c, hipStreamSynchronize(s));
+
+    // K7: theia::Ransac::Estimate's sequential rule replayed over the per-hypothesis results (SURVEY.md A.1)
+    int32_t best_h[kPnpMaxBatch], num_it[kPnpMaxBatch], n_models[kPnpMaxBatch];
+    double best_cost[kPnpMaxBatch];
+    bool any = false;
+    for (int i = 0; i < P; i++) {
+        best_cost[i] = DBL_MAX; n_models[i] = 0; num_it[i] = 0;
+        const size_t o = (size_t)i * H;
+        best_h[i] = ransac_select(p, N[i], H, st->h_valid + o, st->h_cost + o, st->h_nin + o, &num_it[i], &n_models[i], &best_cost[i]);
+        if (best_h[i] >= 0) {
+            any = true;
+            CHIP_HIP(c, hipMemcpyAsync(st->h_T + 16 * (size_t)i, st->T_out + 16 * (o + best_h[i]), sizeof(double) * 16, hipMemcpyDeviceToHost, s));
+            CHIP_HIP(c, hipMemcpyAsync(st->h_mask + (size_t)i * words, st->mask + (o + best_h[i]) * words, sizeof(unsigned long long) * (size_t)words, hipMemcpyDeviceToHost, s));
+        }
+    }
+    if (any) CHIP_HIP(c, hipStreamSynchronize(s));
+    for (int i = 0; i < P; i++) {
+        double *T = T_colmajor + 16 * (size_t)i;
+        uint8_t *im = inlier_mask ? inlier_mask[i] : nullptr;
+        int32_t nin = 0;
+        if (best_h[i] >= 0) {
+            std::memcpy(T, st->h_T + 16 * (size_t)i, sizeof(double) * 16);
+            nin = st->h_nin[(size_t)i * H + best_h[i]];
+            const unsigned long long *hm = st->h_mask + (size_t)i * words;
+            if (im)
+                for (int k = 0; k < N[i]; k++) im[k] = (uint8_t)((hm[k >> 6] >> (k & 63)) & 1ull);
+            const double ratio = (double)nin / (double)N[i];
+            confidence[i] = (float)(1.0 - std::pow(1.0 - std::pow(ratio, (double)S), (double)num_it[i]));  // summary.confidence (:240)
+        } else {
+            for (int k = 0; k < 16; k++) T[k] = NAN;   // reference: uninitialised Matrix4d (:204); caller NaN-checks
+            if (im) std::memset(im, 0, (size_t)N[i]);
+            confidence[i] = 0.0f;
+        }
+        if (summary) {
+            summary[i].n_iterations = num_it[i];
+            summary[i].n_inliers = nin;
+            summary[i].best_hypothesis = best_h[i];
+            summary[i].n_models = n_models[i];
+            summary[i].best_cost = best_h[i] >= 0 ? best_cost[i] : INFINITY;
+        }
     }
     return CHIP_OK;
 }
@@ -916,72 +1020,35 @@ static int pnp_reserve(Ctx *c, PnpState *st, int N, int H)
 
 using namespace chip;
 
-extern "C" int chip_pnp_ransac(chip_ctx *c, const double *X, const double *uv, int32_t N, const chip_ransac_params *p,
-                               double T_colmajor[16], float *confidence, uint8_t *inlier_mask, chip_ransac_summary *summary)
+extern "C" int chip_pnp_ransac_batch(chip_ctx *c, int32_t P, const double *const *X, const double *const *uv, const int32_t *N,
+                                     const chip_ransac_params *p, const uint64_t *seeds, double *T_colmajor, float *confidence,
+                                     uint8_t *const *inlier_mask, chip_ransac_summary *summary)
 {
-    if (!c || !X || !uv || !p || !T_colmajor || !confidence) return CHIP_ERR_INVALID_ARG;
-    if (N < 20) return CHIP_ERR_TOO_FEW_POINTS;  // DlsPnpWithRansac.cpp:136-139
+    if (!c || P < 0 || (P > 0 && (!X || !uv || !N)) || !p || !T_colmajor || !confidence) return CHIP_ERR_INVALID_ARG;
     const int32_t S = p->sample_size;
-    if (S < 3 || S > kSampleMax || S > N || p->n_hypotheses < 0 || p->max_iterations < 1) return CHIP_ERR_UNSUPPORTED;
+    for (int i = 0; i < P; i++) {
+        if (!X[i] || !uv[i]) return CHIP_ERR_INVALID_ARG;
+        if (N[i] < 20) return CHIP_ERR_TOO_FEW_POINTS;  // DlsPnpWithRansac.cpp:136-139
+        if (S > N[i]) return CHIP_ERR_UNSUPPORTED;
+    }
+    if (S < 3 || S > kSampleMax || p->n_hypotheses < 0 || p->max_iterations < 1) return CHIP_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> lk(c->pnp_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
     PnpState *st = static_cast<PnpState *>(c->pnp_state);
     if (!st) return CHIP_ERR_INVALID_ARG;
-
-    const int H = ransac_initial_iterations(p);
-    int rc = pnp_reserve(c, st, N, H);
-    if (rc != CHIP_OK) return rc;
-    const int words = (N + 63) / 64;
-    hipStream_t s = c->s_pnp;
-    CHIP_HIP(c, hipMemcpyAsync(st->X, X, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, s));
-    CHIP_HIP(c, hipMemcpyAsync(st->uv, uv, sizeof(double) * 2 * (size_t)N, hipMemcpyHostToDevice, s));
-
-    SolveArgs sa;
-    sa.X = st->X; sa.uv = st->uv; sa.N = N; sa.S = S; sa.seed = p->seed; sa.tab = st->tab_dev;
-    sa.Sg = st->Sg; sa.Tg = st->Tg; sa.sample = st->sample; sa.ok = st->ok;
-    const size_t lds = sizeof(double) * (kSampleMax * 8 + 9 + 9 + 27 + 27 + 81 + 90 + 100 + 36 + 60 + 4 + 27 * 27 + 8 * 24 + 128 + 96 + 27 * kNC) + sizeof(int) * (16 + 32 + 32 + 4 + 96 + 96) + sizeof(short) * (kNR * 20) + 64;
-    hipLaunchKernelGGL(pnp_build_solve, dim3(H), dim3(kSolveThreads), lds, s, sa);
-    CHIP_HIP(c, hipGetLastError());
-
-    EigArgs ea;
-    ea.X = st->X; ea.uv = st->uv; ea.N = N; ea.S = S; ea.thresh = p->error_thresh; ea.use_mle = p->use_mle;
-    ea.Sg = st->Sg; ea.Tg = st->Tg; ea.sample = st->sample; ea.ok = st->ok; ea.mask_words = words;
-    { const char *dv = std::getenv("CHIP_PNP_DEBUG_STOP"); ea.debug_stop = dv ? std::atoi(dv) : 0; }
-    ea.T_out = st->T_out; ea.cost = st->cost; ea.nin = st->nin; ea.valid = st->valid; ea.nsol = st->nsol; ea.mask = st->mask;
-    hipLaunchKernelGGL(pnp_eig_score, dim3(H), dim3(64), 0, s, ea);
-    CHIP_HIP(c, hipGetLastError());
-
-    CHIP_HIP(c, hipMemcpyAsync(st->h_cost, st->cost, sizeof(double) * (size_t)H, hipMemcpyDeviceToHost, s));
-    CHIP_HIP(c, hipMemcpyAsync(st->h_nin, st->nin, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, s));
-    CHIP_HIP(c, hipMemcpyAsync(st->h_valid, st->valid, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, s));
-    CHIP_HIP(c, hipStreamSynchronize(s));
-
-    // K7: theia::Ransac::Estimate's sequential rule replayed over the per-hypothesis results (SURVEY.md A.1)
-    double best_cost = DBL_MAX;
-    int32_t n_models = 0, num_it = 0;
-    const int32_t best_h = ransac_select(p, N, H, st->h_valid, st->h_cost, st->h_nin, &num_it, &n_models, &best_cost);
-    int32_t nin = 0;
-    if (best_h >= 0) {
-        CHIP_HIP(c, hipMemcpyAsync(st->h_T, st->T_out + 16 * (size_t)best_h, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
-        CHIP_HIP(c, hipMemcpyAsync(st->h_mask, st->mask + (size_t)best_h * words, sizeof(unsigned long long) * (size_t)words, hipMemcpyDeviceToHost, s));
-        CHIP_HIP(c, hipStreamSynchronize(s));
-        std::memcpy(T_colmajor, st->h_T, sizeof(double) * 16);
-        nin = st->h_nin[best_h];
-        if (inlier_mask)
-            for (int i = 0; i < N; i++) inlier_mask[i] = (uint8_t)((st->h_mask[i >> 6] >> (i & 63)) & 1ull);
-        const double ratio = (double)nin / (double)N;
-        *confidence = (float)(1.0 - std::pow(1.0 - std::pow(ratio, (double)S), (double)num_it));  // summary.confidence (:240)
-    } else {
-        for (int i = 0; i < 16; i++) T_colmajor[i] = NAN;   // reference: uninitialised Matrix4d (:204); caller NaN-checks
-        if (inlier_mask) std::memset(inlier_mask, 0, (size_t)N);
-        *confidence = 0.0f;
-    }
-    if (summary) {
-        summary->n_iterations = num_it;
-        summary->n_inliers = nin;
-        summary->best_hypothesis = best_h;
-        summary->n_models = n_models;
-        summary->best_cost = best_h >= 0 ? best_cost : INFINITY;
+    for (int i0 = 0; i0 < P; i0 += kPnpMaxBatch) {
+        const int n = P - i0 < kPnpMaxBatch ? P - i0 : kPnpMaxBatch;
+        const int rc = pnp_run(c, st, n, X + i0, uv + i0, N + i0, p, seeds ? seeds + i0 : nullptr, T_colmajor + 16 * (size_t)i0,
+                               confidence + i0, inlier_mask ? inlier_mask + i0 : nullptr, summary ? summary + i0 : nullptr);
+        if (rc != CHIP_OK) return rc;
     }
     return CHIP_OK;
+}
+
+extern "C" int chip_pnp_ransac(chip_ctx *c, const double *X, const double *uv, int32_t N, const chip_ransac_params *p,
+                               double T_colmajor[16], float *confidence, uint8_t *inlier_mask, chip_ransac_summary *summary)
+{
+    if (!c || !X || !uv || !p || !T_colmajor || !confidence) return CHIP_ERR_INVALID_ARG;
+    uint8_t *masks[1] = {inlier_mask};
+    return chip_pnp_ransac_batch(c, 1, &X, &uv, &N, p, nullptr, T_colmajor, confidence, masks, summary);
 }

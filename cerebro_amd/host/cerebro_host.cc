@@ -365,10 +365,23 @@ bool compute_three_way_pose(chip_ctx *ctx, const PosePairInput &in, ProcessedLoo
     chip_icp_params_default(&pi);
     if (seed) { pp.seed = seed; pi.seed = seed ^ 0x9E3779B97F4A7C15ull; }
     std::array<double, 16> op1{}, op2_a_T_b{}, op2{}, icp{};
-    std::string m1, m2, m3;
-    const float g1 = StaticTheiaPoseCompute::PNP(ctx, in.world_point_uv, in.feature_position_uv_d, op1.data(), m1, &pp);          // Cerebro.cpp:1518
-    pp.seed += 1;
-    const float g2 = StaticTheiaPoseCompute::PNP(ctx, in.world_point_uv_d, in.feature_position_uv, op2_a_T_b.data(), m2, &pp);   // :1572
+    std::string m3;
+    // Cerebro.cpp:1518 PNP(a->b) and :1572 PNP(b->a) are independent: both go into one pair of launches (seeds seed, seed+1).
+    float g1 = -1.f, g2 = -1.f;
+    if (in.world_point_uv.size() >= 20 && in.world_point_uv_d.size() >= 20 && in.world_point_uv.size() == in.feature_position_uv_d.size() &&
+        in.world_point_uv_d.size() == in.feature_position_uv.size()) {   // the < 20 guard of PNP (DlsPnpWithRansac.cpp:136-139)
+        const double *Xs[2] = {&in.world_point_uv[0][0], &in.world_point_uv_d[0][0]};
+        const double *uvs[2] = {&in.feature_position_uv_d[0][0], &in.feature_position_uv[0][0]};
+        const int32_t Ns[2] = {(int32_t)in.world_point_uv.size(), (int32_t)in.world_point_uv_d.size()};
+        const uint64_t seeds[2] = {pp.seed, pp.seed + 1};
+        double T2[32];
+        float conf[2] = {0.f, 0.f};
+        if (chip_pnp_ransac_batch(ctx, 2, Xs, uvs, Ns, &pp, seeds, T2, conf, nullptr, nullptr) == CHIP_OK) {
+            for (int i = 0; i < 16; i++) { op1[i] = T2[i]; op2_a_T_b[i] = T2[16 + i]; }
+            g1 = conf[0];
+            g2 = conf[1];
+        }
+    }
     matrix4_inverse_rigid(op2_a_T_b.data(), op2.data());                                                                          // :1582
     const float g3 = StaticTheiaPoseComputeICP::P3P_ICP(ctx, in.uv_X, in.uvd_Y, icp.data(), m3, &pi);                               // :1629
     for (int i = 0; i < 16; i++)  // :1678  op != op  <=> any NaN

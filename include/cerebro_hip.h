@@ -212,6 +212,16 @@ int chip_pnp_ransac(chip_ctx *ctx, const double *X, const double *uv, int32_t N,
                     double T_colmajor[16], float *confidence, uint8_t *inlier_mask /* N bytes, may be NULL */,
                     chip_ransac_summary *summary /* may be NULL */);
 
+/* P independent estimations in one pair of launches -- e.g. the two role-swapped PNP calls the loop-candidate consumer
+ * makes per image pair (src/Cerebro.cpp:1518 and :1572).  One wave per hypothesis is latency-bound at H = 1000, so
+ * co-scheduled problems cost little more than one.  All problems share *p; problem i draws from seeds[i] (NULL: p->seed
+ * for every problem) and its outputs (T_colmajor + 16 i, confidence[i], inlier_mask[i] (N[i] bytes; the array or any
+ * entry may be NULL), summary[i]) are bit-identical to chip_pnp_ransac(X[i], uv[i], N[i]) with that seed.
+ * Any N[i] < 20 fails the whole call with CHIP_ERR_TOO_FEW_POINTS before anything runs.                         */
+int chip_pnp_ransac_batch(chip_ctx *ctx, int32_t P, const double *const *X, const double *const *uv, const int32_t *N,
+                          const chip_ransac_params *p, const uint64_t *seeds, double *T_colmajor /* P x 16 */,
+                          float *confidence /* P */, uint8_t *const *inlier_mask, chip_ransac_summary *summary /* P or NULL */);
+
 /* ------------------------------------------------------------------------------------------ Umeyama-ICP-RANSAC
  * Replaces the RANSAC branch of StaticTheiaPoseCompute::P3P_ICP (src/DlsPnpWithRansac.cpp:65-121): theia::Ransac over
  * AlignPointCloudsUmeyamaWithRansac (src/DlsPnpWithRansac.h:104-166): 10-point sample -> AlignPointCloudsUmeyama ->

@@ -1,2 +1,4 @@
-(timeout 900 python -m pytest tests/test_batch_gpu.py -x -q 2>&1 | tail -3)
-python scripts/gpu_batch_perf.py 2>&1 | grep "rows=1000000"
+#!/bin/bash
+mkdir -p gpurun_out
+python -m pytest tests -x -q -m gpu -k "pnp or threeway or gate or icp" 2>&1 | tail -8
+python scripts/gpu_pnp_batch_perf.py

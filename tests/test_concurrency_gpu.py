@@ -1,6 +1,7 @@
 """Thread-safety contract of the ctx (include/cerebro_hip.h): one appender thread (desc_th), one querier thread
 (dot_product_th) and one PnP caller (loopcandidate_consumer_th) share a chip_ctx, as in cerebro_node.cpp:487-509."""
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -23,12 +24,16 @@ def test_appender_querier_pnp_threads_share_a_ctx():
     db = scenarios.build_db(4, N, D, sorted(plants))
     X, uv, T, inl = make_scene(N=300, outlier_frac=0.2, noise_px=0.5, seed=5)
     want_pnp = oracle_lib.pnp_ransac(X, uv, oracle_lib.ransac_params(seed=9))
-    errors, found, pnp_runs = [], [], [0]
+    errors, found, pnp_runs, last_tick = [], [], [0], [0]
     stop = threading.Event()
     with capi.Chip(D, capacity_hint=64) as chip:          # tiny hint: the DB grows while being queried
         def appender():
             try:
                 for i in range(0, N, 3):
+                    # keyframes arrive slower than ticks in the live system: never run more than 6 rows ahead of the querier,
+                    # so consecutive ticks are <= 9 rows apart and every 12-row revisit is seen by at least one tick
+                    while i - last_tick[0] > 6 and not errors:
+                        time.sleep(0)
                     chip.append_f64(db[i:i + 3].astype(np.float64))
             except Exception as e:  # pragma: no cover
                 errors.append(e)
@@ -45,6 +50,7 @@ def test_appender_querier_pnp_threads_share_a_ctx():
                         r = chip.loop_tick(l)
                         if r.status != capi.CHIP_TICK_SKIPPED:
                             last = l
+                            last_tick[0] = l
                         if r.found:
                             found.append((r.idx_curr, r.idx_prev, r.score))
                         # whatever prefix this tick saw, its answer must equal the oracle's for that prefix

@@ -109,3 +109,32 @@ def test_edge_cases():
         st = chip.lib.chip_pnp_ransac(chip.h, X.ctypes.data, uv.ctypes.data, 64, p, np.empty(16).ctypes.data,
                                       capi.C.byref(capi.C.c_float()), None, None)
         assert st == capi.CHIP_ERR_UNSUPPORTED
+
+
+def same_result(a, b):
+    assert a["summary"] == b["summary"] or (np.isnan(a["summary"]["best_cost"]) and np.isnan(b["summary"]["best_cost"]))
+    assert np.array_equal(a["mask"], b["mask"]) and a["confidence"] == b["confidence"]
+    assert np.array_equal(a["T"].view(np.uint64), b["T"].view(np.uint64))
+
+
+@pytest.mark.parametrize("H", [0, 300])
+def test_batch_equals_individual_calls_and_oracle(H):
+    """chip_pnp_ransac_batch: ragged problem sizes, own seeds, more problems than one launch holds (8): entry i must be
+    bit-identical to the single call with seeds[i] (and hence to the oracle)."""
+    scenes = [M.make_scene(N=n, outlier_frac=o, noise_px=0.4, seed=s)[:2]
+              for n, o, s in [(64, 0.1, 1), (512, 0.3, 2), (20, 0.0, 3), (777, 0.5, 4), (130, 0.2, 5), (512, 0.3, 6), (65, 0.0, 7),
+                              (200, 0.6, 8), (333, 0.1, 9), (40, 0.0, 10), (512, 0.2, 11)]]
+    seeds = [1000 + 7 * i for i in range(len(scenes))]
+    with capi.Chip(256) as chip:
+        got = chip.pnp_ransac_batch(scenes, gparams(n_hypotheses=H), seeds=seeds)
+        for (X, uv), sd, g in zip(scenes, seeds, got):
+            same_result(g, chip.pnp_ransac(X, uv, gparams(n_hypotheses=H, seed=sd)))
+        for i in (1, 3, 10):
+            o = O.pnp_ransac(*scenes[i], O.ransac_params(n_hypotheses=H, seed=seeds[i]))
+            assert np.array_equal(got[i]["mask"], o["mask"]) and np.array_equal(got[i]["T"].view(np.uint64), o["T"].view(np.uint64))
+        # shared seed (seeds = NULL) and the empty batch
+        g2 = chip.pnp_ransac_batch(scenes[:2], gparams(n_hypotheses=50, seed=77))
+        same_result(g2[1], chip.pnp_ransac(*scenes[1], gparams(n_hypotheses=50, seed=77)))
+        assert chip.pnp_ransac_batch([], gparams()) == []
+        with pytest.raises(Exception):
+            chip.pnp_ransac_batch([scenes[0], (scenes[0][0][:19], scenes[0][1][:19])], gparams())    # a problem with < 20 points
