@@ -78,6 +78,40 @@ def cpu_baseline(sample_cols: int, budget_s: float):
     return cols_per_s, n, dt
 
 
+def usable_cpus() -> int:
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU boxes expose 256
+    logical CPUs behind a 16-CPU cpu.max; oversubscribing a CFS quota throttles instead of speeding up)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline_all_cores(sample_cols: int, budget_s: float):
+    """the same three GEMVs + maxCoeff + argmax with OpenMP over columns on every host core (what the
+    reference would get from Eigen's OpenMP GEMV, which it does not enable).  Reported next to `cpu_baseline`, never as it."""
+    import oracle_lib  # baseline only
+    nthreads = usable_cpus()
+    src = oracle_lib.synth_rows(SEED, range(2048), D).astype(np.float64)
+    M = oracle_lib.tile_columns_omp(sample_cols, src, nthreads)           # first touch by the scanning threads
+    v, vm, vmm = src[5].copy(), src[6].copy(), src[7].copy()
+    scratch = (np.empty(sample_cols), np.empty(sample_cols), np.empty(sample_cols))
+    oracle_lib.ref_scan_f64_colmajor_omp(M, sample_cols, v, vm, vmm, nthreads, scratch)
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        oracle_lib.ref_scan_f64_colmajor_omp(M, sample_cols, v, vm, vmm, nthreads, scratch)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s:
+            break
+    return n * sample_cols / dt, n, dt, nthreads
+
+
 def pnp_leg(chip, cpu_budget_s: float):
     """BASELINE config 3: 512 correspondences x 1000 hypotheses of 15 samples (DlsPnpWithRansac), whole call through
     chip_pnp_ransac (includes the 20 KB H2D of the correspondences and the host-side K7 selection)."""
@@ -101,9 +135,20 @@ def pnp_leg(chip, cpu_budget_s: float):
         p.seed = 99 + i
         chip.pnp_ransac(X, uv, p)
     dt_ref = time.perf_counter() - t1
+    # eight independent problems of the same shape per launch pair (chip_pnp_ransac_batch)
+    scenes = [make_scene(N=512, outlier_frac=0.3, noise_px=0.5, seed=4242 + i)[:2] for i in range(8)]
+    p.n_hypotheses = 1000
+    p.seed = 4242
+    chip.pnp_ransac_batch(scenes, p)
+    t3 = time.perf_counter()
+    breps = 10
+    for i in range(breps):
+        chip.pnp_ransac_batch(scenes, p, seeds=[4242 + 8 * i + j for j in range(8)])
+    dt_b = time.perf_counter() - t3
     out = {"metric": "PnP-RANSAC hypotheses/sec (512 correspondences, 1000 hypotheses of 15 samples, DLS + L1 reprojection scoring)",
            "value": reps * 1000 / dt, "unit": "hypotheses/s", "ms_per_call_1000_hyp": 1e3 * dt / reps,
            "reference_mode_ms_per_call": 1e3 * dt_ref / reps, "reference_mode": "<=50 iterations, theia early termination",
+           "batch8_hypotheses_per_s": breps * 8 * 1000 / dt_b, "batch8_ms_per_call": 1e3 * dt_b / breps,
            "dtype": "f64", "n_models_last": r["summary"]["n_models"],
            "roofline": {"bound": "latency (fp64 VALU + LDS); neither HBM nor MFMA", "flops_per_hypothesis_est": 1.3e6,
                         "achieved_gflops_est": reps * 1000 * 1.3e6 / dt / 1e9, "note": "see DESIGN.md 5"}}
@@ -328,6 +373,12 @@ def main():
                                    "sample": f"{n} ticks of 3 fp64 GEMVs over a {args.cpu_sample}-column x 4096 column-major M "
                                              f"({dt:.1f} s), scaled to {args.rows} columns; host has {os.cpu_count()} cores, "
                                              "reference path is single-threaded (Eigen without OpenMP)"}
+            ac_cols = max(args.cpu_sample, 200_000)      # 6.5 GB of fp64: large enough to defeat the host caches
+            cols_per_s, n, dt, nt = cpu_baseline_all_cores(ac_cols, min(args.cpu_budget, 6.0))
+            out["cpu_baseline_all_cores"] = {"value": cols_per_s / args.rows, "unit": "loop-queries/s", "cores": nt, "kind": "port",
+                                             "sample": f"{n} ticks over a {ac_cols}-column x 4096 fp64 M ({dt:.1f} s), OpenMP static "
+                                                       f"over columns, scaled to {args.rows} columns; {os.cpu_count()} logical CPUs visible, "
+                                                       f"{nt} usable under the affinity mask / cgroup quota"}
         print(json.dumps(out), flush=True)
 
     if 'det' in locals():

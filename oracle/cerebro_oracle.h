@@ -94,6 +94,12 @@ void orc_ref_scan_f64_colmajor(const double *M, int32_t D, int64_t k,
                                const double *v, const double *vm, const double *vmm,
                                double *u, double *um, double *umm,
                                double maxv[3], int64_t argmax[3]);
+/* OpenMP-over-columns variant of the same statements; bit-identical results. */
+void orc_ref_scan_f64_colmajor_omp(const double *M, int32_t D, int64_t k,
+                                   const double *v, const double *vm, const double *vmm,
+                                   double *u, double *um, double *umm,
+                                   double maxv[3], int64_t argmax[3], int32_t nthreads);
+void orc_tile_columns_omp(double *M, int32_t D, int64_t k, const double *src, int64_t src_cols, int32_t nthreads);
 
 
 /* ================================================================== PnP / RANSAC (pnp_ransac.c) */

@@ -245,3 +245,42 @@ void orc_ref_scan_f64_colmajor(const double *M, int32_t D, int64_t k,
     maxv[0] = a; maxv[1] = b; maxv[2] = c;
     argmax[0] = ia; argmax[1] = ib; argmax[2] = ic;
 }
+
+/* Same statements with the three products parallelised over columns (OpenMP static schedule, `nthreads` threads): what the
+ * reference would do had it enabled Eigen's OpenMP GEMV (it does not, CMakeLists.txt:42).  SURVEY.md 8d (ii).  Every u[i]
+ * is the same sequential dot product, so results equal the single-thread function bit for bit. */
+void orc_ref_scan_f64_colmajor_omp(const double *M, int32_t D, int64_t k,
+                                   const double *v, const double *vm, const double *vmm,
+                                   double *u, double *um, double *umm, double maxv[3], int64_t argmax[3], int32_t nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t i = 0; i < k; i++) u[i] = orc_dot_seq_f64(v, M + (size_t)i * D, D);
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t i = 0; i < k; i++) um[i] = orc_dot_seq_f64(vm, M + (size_t)i * D, D);
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t i = 0; i < k; i++) umm[i] = orc_dot_seq_f64(vmm, M + (size_t)i * D, D);
+    double a = u[0], b = um[0], c = umm[0];
+    for (int64_t i = 1; i < k; i++) { if (u[i] > a) a = u[i]; if (um[i] > b) b = um[i]; if (umm[i] > c) c = umm[i]; }
+    int64_t ia = -1, ib = -1, ic = -1;
+    for (int64_t ii = 0; ii < k; ii++) {
+        if (u[ii] == a) ia = ii;
+        if (um[ii] == b) ib = ii;
+        if (umm[ii] == c) ic = ii;
+    }
+    maxv[0] = a; maxv[1] = b; maxv[2] = c;
+    argmax[0] = ia; argmax[1] = ib; argmax[2] = ic;
+}
+
+/* First-touch helper for the multi-thread baseline: replicate a block of `src_cols` columns into M (k columns) in
+ * parallel with the same static schedule, so pages land on the NUMA node of the thread that will read them. */
+void orc_tile_columns_omp(double *M, int32_t D, int64_t k, const double *src, int64_t src_cols, int32_t nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t i = 0; i < k; i++) {
+        const double *s = src + (size_t)(i % src_cols) * D;
+        double *d = M + (size_t)i * D;
+        for (int32_t j = 0; j < D; j++) d[j] = s[j];
+    }
+}

@@ -163,6 +163,22 @@ def ref_scan_f64_colmajor(M: np.ndarray, k: int, v, vm, vmm):
     return maxv, arg, (u, um, umm)
 
 
+def ref_scan_f64_colmajor_omp(M: np.ndarray, k: int, v, vm, vmm, nthreads: int, scratch=None):
+    D = M.shape[1]
+    u, um, umm = scratch if scratch is not None else (np.empty(k), np.empty(k), np.empty(k))
+    maxv = np.empty(3); arg = np.empty(3, dtype=np.int64)
+    load().orc_ref_scan_f64_colmajor_omp(_p(M), D, C.c_int64(k), _p(v), _p(vm), _p(vmm), _p(u), _p(um), _p(umm), _p(maxv), _p(arg),
+                                         C.c_int32(nthreads))
+    return maxv, arg, (u, um, umm)
+
+
+def tile_columns_omp(k: int, src: np.ndarray, nthreads: int) -> np.ndarray:
+    """(k, D) float64 array made of repeated copies of `src`, first-touched by the threads that will scan it."""
+    M = np.empty((k, src.shape[1]), dtype=np.float64)
+    load().orc_tile_columns_omp(_p(M), src.shape[1], C.c_int64(k), _p(src), C.c_int64(src.shape[0]), C.c_int32(nthreads))
+    return M
+
+
 # ================================================================== PnP / RANSAC oracle bindings
 class OrcRansacParams(C.Structure):
     _fields_ = [("error_thresh", C.c_double), ("min_inlier_ratio", C.c_double), ("max_iterations", C.c_int32),

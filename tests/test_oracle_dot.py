@@ -185,3 +185,17 @@ def test_golden_fixture(oracle):
         sc, ix = oracle_lib.scan_topk(db, case["topk_k"], db[case["topk_rows"]], case["K"])
         assert ix.tolist() == case["topk_idx"]
         assert [[float(x).hex() for x in row] for row in sc] == case["topk_scores_hex"]
+
+
+def test_all_cores_baseline_equals_single_thread_reference_path():
+    """bench.py's cpu_baseline_all_cores (OpenMP over columns) computes the same u/um/umm, maxima and
+    last-index argmax as the literal single-thread statements."""
+    src = oracle_lib.synth_rows(3, range(40), 256).astype(np.float64)
+    M = oracle_lib.tile_columns_omp(1003, src, 4)                   # tiled copies -> exact ties, last index must win
+    assert np.array_equal(M[:40], src) and np.array_equal(M[1000], src[1000 % 40])
+    v, vm, vmm = src[5].copy(), src[6].copy(), src[7].copy()
+    a = oracle_lib.ref_scan_f64_colmajor_omp(M, 1003, v, vm, vmm, 4)
+    b = oracle_lib.ref_scan_f64_colmajor(M, 1003, v, vm, vmm)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
+    assert list(a[1]) == [965, 966, 967]                             # last tiled copies of rows 5, 6, 7
