@@ -78,6 +78,10 @@ def cpu_baseline(sample_cols: int, budget_s: float):
     return cols_per_s, n, dt
 
 
+def fmt_rows(n: int) -> str:
+    return f"{n // 10**6}M" if n % 10**6 == 0 else f"{n // 1000}k" if n % 1000 == 0 else str(n)
+
+
 def usable_cpus() -> int:
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU boxes expose 256
     logical CPUs behind a 16-CPU cpu.max; oversubscribing a CFS quota throttles instead of speeding up)."""
@@ -200,6 +204,7 @@ def main():
     ap.add_argument("--rows", type=int, default=1_000_000, help="DB rows scanned per tick (k)")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=20000, help="columns in the CPU baseline sample")
+    ap.add_argument("--dim", type=int, default=4096, help="descriptor size (BASELINE: 4096; the reference's default model emits 8192)")
     ap.add_argument("--inflight", type=int, default=16)
     ap.add_argument("--no-pnp", action="store_true", help="skip the auxiliary PnP-RANSAC leg (config 3)")
     ap.add_argument("--no-batch", action="store_true", help="skip the auxiliary many-query MFMA leg (row N4)")
@@ -236,6 +241,8 @@ def main():
         ls = [ls[i % TICK_WINDOW] for i in range(n_ticks)]
         expect = [expect[i % TICK_WINDOW] for i in range(n_ticks)]
 
+    global D
+    D = args.dim
     chip = capi.Chip(D, capacity_hint=total_rows, device=local_rank, shard_rank=rank, shard_count=world)
     info = chip.info()
     t_fill = time.perf_counter()
@@ -339,7 +346,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "loop-queries/sec (ticks of 3 descriptors vs 4096-D x 1M DB) [+ PnP-RANSAC hypotheses/sec in \"pnp\"]",
+            "metric": f"loop-queries/sec (ticks of 3 descriptors vs {D}-D x {fmt_rows(args.rows)} DB) [+ PnP-RANSAC hypotheses/sec in \"pnp\"]",
             "value": args.steps / elapsed,
             "unit": "loop-queries/s",
             "n_gpus": world,
@@ -351,7 +358,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (on-device integer-domain generator, seed 20190412, planted revisits)",
-            "config": {"workload": f"4096-D fp32 descriptors x {args.rows} keyframe DB, 3 queries/tick, top-{TOPK} + accept rule",
+            "config": {"workload": f"{D}-D fp32 descriptors x {args.rows} keyframe DB, 3 queries/tick, top-{TOPK} + accept rule",
                        "db_rows": args.rows, "D": D, "queries_per_tick": 3, "topk": TOPK, "storage": "fp32 rows (verified-lossless narrowing of the f64 wire type), fp64 accumulate",
                        "loop_query": "one tick of Cerebro::descrip_N__dot__descrip_0_N = 3 descriptor queries + top-k + accept rule",
                        "sharding": "single GPU" if world == 1 else f"row round-robin over {world} GPUs + RCCL all-gather of top-k",

@@ -158,8 +158,8 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
     CHIP_HIP(c, hipMalloc(&c->flags_dev, sizeof(uint32_t)));
     CHIP_HIP(c, hipHostMalloc(&c->flags_host, sizeof(uint32_t), hipHostMallocDefault));
 
-    c->scan_block = env_int("CHIP_SCAN_BLOCK", 512);
-    if (c->scan_block != 256 && c->scan_block != 512 && c->scan_block != 768 && c->scan_block != 1024) c->scan_block = 512;
+    c->scan_block = env_int("CHIP_SCAN_BLOCK", 0);   // 0 = chosen from D per launch (kernels.hip scan_shape)
+    if (c->scan_block != 256 && c->scan_block != 512 && c->scan_block != 768 && c->scan_block != 1024) c->scan_block = 0;
     c->scan_blocks_per_cu = env_int("CHIP_SCAN_BPC", 2);
     if (c->scan_blocks_per_cu < 1) c->scan_blocks_per_cu = 1;
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);

@@ -108,7 +108,7 @@ struct Ctx {
     int64_t last_l = 0;
 
     // --- scan tuning (resolved at create; CHIP_SCAN_* env overrides for A/B runs) ---
-    int32_t scan_block = 512;
+    int32_t scan_block = 0;       // 0 = auto
     int32_t scan_blocks_per_cu = 2;
     int32_t scan_variant = 0;
 

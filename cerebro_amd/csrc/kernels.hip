@@ -177,44 +177,66 @@ __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
 }
 
 template <int NQ, int U, bool FULL, bool NT, int R>
-static int launch_scan_k(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds)
+static int launch_scan_k(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds, int block)
 {
     if (lds > 65536) CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_scan_topk<NQ, U, FULL, NT, R>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((db_scan_topk<NQ, U, FULL, NT, R>), dim3(grid), dim3(c->scan_block), lds, s, a);
+    hipLaunchKernelGGL((db_scan_topk<NQ, U, FULL, NT, R>), dim3(grid), dim3(block), lds, s, a);
     CHIP_HIP(c, hipGetLastError());
     return CHIP_OK;
 }
 
 template <int NQ, int U, bool NT, int R>
-static int launch_scan_t(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds)
+static int launch_scan_t(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds, int block)
 {
-    return a.D % (256 * U) == 0 ? launch_scan_k<NQ, U, true, NT, R>(c, s, a, grid, lds) : launch_scan_k<NQ, U, false, NT, R>(c, s, a, grid, lds);
+    return a.D % (256 * U) == 0 ? launch_scan_k<NQ, U, true, NT, R>(c, s, a, grid, lds, block)
+                                : launch_scan_k<NQ, U, false, NT, R>(c, s, a, grid, lds, block);
 }
 
 // scan_variant (CHIP_SCAN_VARIANT, tuning/A-B only): 0 = production (U=8, non-temporal loads, 1 row in flight per wave)
 template <int NQ>
-static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds)
+static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds, int block)
 {
 #ifdef CHIP_SCAN_TUNING_VARIANTS
     switch (c->scan_variant) {
-        case 1: return launch_scan_t<NQ, 4, true, 1>(c, s, a, grid, lds);
-        case 2: return launch_scan_t<NQ, 16, true, 1>(c, s, a, grid, lds);
-        case 3: return launch_scan_t<NQ, 8, false, 1>(c, s, a, grid, lds);
-        case 4: return launch_scan_t<NQ, 4, true, 2>(c, s, a, grid, lds);
-        case 5: return launch_scan_t<NQ, 8, true, 2>(c, s, a, grid, lds);
-        case 6: return launch_scan_t<NQ, 4, false, 2>(c, s, a, grid, lds);
+        case 1: return launch_scan_t<NQ, 4, true, 1>(c, s, a, grid, lds, block);
+        case 2: return launch_scan_t<NQ, 16, true, 1>(c, s, a, grid, lds, block);
+        case 3: return launch_scan_t<NQ, 8, false, 1>(c, s, a, grid, lds, block);
+        case 4: return launch_scan_t<NQ, 4, true, 2>(c, s, a, grid, lds, block);
+        case 5: return launch_scan_t<NQ, 8, true, 2>(c, s, a, grid, lds, block);
+        case 6: return launch_scan_t<NQ, 4, false, 2>(c, s, a, grid, lds, block);
         default: break;
     }
 #endif
-    return launch_scan_t<NQ, 8, true, 1>(c, s, a, grid, lds);
+    return launch_scan_t<NQ, 8, true, 1>(c, s, a, grid, lds, block);
 }
 
-int scan_grid_for(const Ctx *c, int64_t n_rows, int /*nq*/)
+// Workgroup shape of K1.  The nq query descriptors sit in LDS (nq*D*4 bytes per workgroup), so the shape follows D:
+// 2 workgroups x 512 threads per CU while two copies fit in the 160 KiB (D = 4096: 48 KiB each), else 1 x 1024 threads
+// (D = 8192, the reference's default model: 96 KiB) -- the same 16 waves per CU either way (measured: 6.7 TB/s vs 5.5
+// with 512 x 1).  CHIP_SCAN_BLOCK / CHIP_SCAN_BPC override (tuning only).
+static size_t scan_lds_bytes(const Ctx *c, int nq, int K, int block)
 {
-    const int wpb = c->scan_block / 64;
+    const size_t lds_q = (size_t)nq * c->D * sizeof(float);
+    const size_t lds_m = (size_t)(block / 64) * nq * K * sizeof(chip_topk_entry);
+    return lds_q > lds_m ? lds_q : lds_m;
+}
+
+static void scan_shape(const Ctx *c, int nq, int *block, int *bpc)
+{
+    if (c->scan_block > 0) { *block = c->scan_block; *bpc = c->scan_blocks_per_cu; return; }
+    const bool two_fit = 2 * (scan_lds_bytes(c, nq, CHIP_MAX_TOPK, 512) + 1024) <= 160 * 1024;
+    *block = two_fit ? 512 : 1024;
+    *bpc = two_fit ? 2 : 1;
+}
+
+int scan_grid_for(const Ctx *c, int64_t n_rows, int nq)
+{
+    int block, bpc;
+    scan_shape(c, nq, &block, &bpc);
+    const int wpb = block / 64;
     int64_t want = (n_rows + wpb - 1) / wpb;
-    int64_t cap = (int64_t)c->n_cus * c->scan_blocks_per_cu;
+    int64_t cap = (int64_t)c->n_cus * bpc;
     if (cap > c->max_grid) cap = c->max_grid;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
@@ -223,16 +245,15 @@ int scan_grid_for(const Ctx *c, int64_t n_rows, int /*nq*/)
 
 int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid)
 {
-    const int wpb = c->scan_block / 64;
-    size_t lds_q = (size_t)nq * a.D * sizeof(float);
-    size_t lds_m = (size_t)wpb * nq * a.K * sizeof(chip_topk_entry);
-    size_t lds = lds_q > lds_m ? lds_q : lds_m;
+    int block, bpc;
+    scan_shape(c, nq, &block, &bpc);
+    const size_t lds = scan_lds_bytes(c, nq, a.K, block);
     if (lds > 160 * 1024 || grid > 512) return CHIP_ERR_UNSUPPORTED;  // K2 holds one partial list per thread
     switch (nq) {
-        case 1: return launch_scan_q<1>(c, s, a, grid, lds);
-        case 2: return launch_scan_q<2>(c, s, a, grid, lds);
-        case 3: return launch_scan_q<3>(c, s, a, grid, lds);
-        case 4: return launch_scan_q<4>(c, s, a, grid, lds);
+        case 1: return launch_scan_q<1>(c, s, a, grid, lds, block);
+        case 2: return launch_scan_q<2>(c, s, a, grid, lds, block);
+        case 3: return launch_scan_q<3>(c, s, a, grid, lds, block);
+        case 4: return launch_scan_q<4>(c, s, a, grid, lds, block);
     }
     return CHIP_ERR_UNSUPPORTED;
 }
