@@ -340,7 +340,8 @@ def main():
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         traffic = None
         pj = ROOT / "profiles" / "scan_traffic.json"
-        if pj.exists():
+        # the committed PMC measurement is of the headline launch (4096-D x 1M rows on one GPU); other shapes report null
+        if pj.exists() and D == 4096 and args.rows == 1_000_000 and world == 1:
             try:
                 traffic = json.loads(pj.read_text()).get("hbm_bytes_per_launch")
             except Exception:
