@@ -1,10 +1,13 @@
 // state_json.cc -- minimal, dependency-free JSON walk that materialises only what the descriptor DB needs.
 #include "state_json.h"
 
+#include <atomic>
 #include <cerrno>
+#include <charconv>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace cerebro_hip {
 namespace {
@@ -101,14 +104,77 @@ bool skip_value(Cur &c)
     }
 }
 
-// {"rows": D, "cols": 1, "data": "..."} -> appends rows*cols doubles parsed with strtod (== the reference's std::stod)
-bool parse_descriptor(Cur &c, std::vector<double> &vals, int64_t &rows, int64_t &cols)
+// The raw (still JSON-escaped) text of one descriptor's "data" string.  The structural walk only locates it; the numbers
+// are converted afterwards, many descriptors at a time (a checkpoint is ~80 KB of decimal text per 4096-D descriptor and
+// number conversion is >95 % of the load time).
+struct DataSpan {
+    const char *b = nullptr, *e = nullptr;  // between the quotes
+    bool plain = true;                      // only \n \t \r escapes inside (what nlohmann::json emits for Eigen's text)
+    int64_t rows = -1, cols = -1;
+    uint64_t stamp = 0;
+};
+
+// Finds the closing quote of the string starting at c.p (which must be '"') without materialising it.
+bool scan_string(Cur &c, DataSpan &sp)
+{
+    if (c.p >= c.end || *c.p != '"') return c.fail("expected string");
+    const char *q = c.p + 1;
+    sp.b = q;
+    sp.plain = true;
+    for (;;) {
+        const char *m = static_cast<const char *>(std::memchr(q, '"', (size_t)(c.end - q)));
+        if (!m) return c.fail("unterminated string");
+        // a quote preceded by an odd number of backslashes is escaped
+        const char *bs = m;
+        while (bs > q && bs[-1] == '\\') bs--;
+        if (((m - bs) & 1) == 0) { sp.e = m; break; }
+        q = m + 1;
+    }
+    for (const char *t = sp.b; t < sp.e; t++)
+        if (*t == '\\') {
+            if (t + 1 < sp.e && (t[1] == 'n' || t[1] == 't' || t[1] == 'r')) t++;
+            else { sp.plain = false; break; }
+        }
+    c.p = sp.e + 1;
+    return true;
+}
+
+// Text -> doubles with the semantics of the reference's std::stod (== strtod, "C" locale): std::from_chars is correctly
+// rounded like glibc's strtod and several times faster; anything it rejects (leading '+', hex floats ...) is retried with
+// strtod itself.  `escaped`: separators may also be the two-character sequences \n \t \r.
+bool convert_values(const char *q, const char *qe, bool escaped, double *dst, int64_t want, const char **err)
+{
+    int64_t n = 0;
+    while (q < qe) {
+        const char ch = *q;
+        if (ch == ' ' || ch == '\n' || ch == ',' || ch == '\t' || ch == '\r') { q++; continue; }
+        if (escaped && ch == '\\' && q + 1 < qe && (q[1] == 'n' || q[1] == 't' || q[1] == 'r')) { q += 2; continue; }
+        double v;
+        auto r = std::from_chars(q, qe, v);
+        const char *next = r.ptr;
+        // not a clean token end (e.g. the "0" of a hex float "0x1p-2"): let strtod decide
+        const bool clean = next >= qe || *next == ' ' || *next == '\n' || *next == ',' || *next == '\t' || *next == '\r' || *next == '\\';
+        if (r.ec != std::errc() || !clean) {
+            char *e = nullptr;
+            v = std::strtod(q, &e);   // the text is NUL-terminated past qe and strtod stops at the closing quote at the latest
+            if (e == q || e > qe) { *err = "wholeImageDescriptor.data: bad number"; return false; }
+            next = e;
+        }
+        if (n >= want) { *err = "wholeImageDescriptor.data: element count != rows*cols"; return false; }
+        dst[n++] = v;
+        q = next;
+    }
+    if (n != want) { *err = "wholeImageDescriptor.data: element count != rows*cols"; return false; }
+    return true;
+}
+
+// {"rows": D, "cols": 1, "data": "..."} -> locates the data text (converted later by convert_values)
+bool parse_descriptor(Cur &c, DataSpan &sp)
 {
     c.ws();
     if (c.p >= c.end || *c.p != '{') return c.fail("wholeImageDescriptor: expected object");
     c.p++;
-    rows = cols = -1;
-    std::string data;
+    sp.rows = sp.cols = -1;
     bool have_data = false;
     for (;;) {
         c.ws();
@@ -124,33 +190,19 @@ bool parse_descriptor(Cur &c, std::vector<double> &vals, int64_t &rows, int64_t 
             long long v = std::strtoll(c.p, &e, 10);
             if (e == c.p) return c.fail("bad rows/cols");
             c.p = e;
-            (key == "rows" ? rows : cols) = v;
+            (key == "rows" ? sp.rows : sp.cols) = v;
         } else if (key == "data") {
-            if (!parse_string(c, &data)) return false;
+            if (!scan_string(c, sp)) return false;
             have_data = true;
         } else if (!skip_value(c)) return false;
         c.ws();
         if (c.p < c.end && *c.p == ',') c.p++;
     }
-    if (!have_data || rows <= 0 || cols <= 0) return c.fail("wholeImageDescriptor: missing rows/cols/data");
-    const char *q = data.c_str(), *qe = q + data.size();
-    int64_t n = 0;
-    while (q < qe) {
-        while (q < qe && (*q == ' ' || *q == '\n' || *q == ',' || *q == '\t' || *q == '\r')) q++;
-        if (q >= qe) break;
-        char *e = nullptr;
-        errno = 0;
-        const double v = std::strtod(q, &e);
-        if (e == q) return c.fail("wholeImageDescriptor.data: bad number");
-        vals.push_back(v);
-        n++;
-        q = e;
-    }
-    if (n != rows * cols) return c.fail("wholeImageDescriptor.data: element count != rows*cols");
+    if (!have_data || sp.rows <= 0 || sp.cols <= 0) return c.fail("wholeImageDescriptor: missing rows/cols/data");
     return true;
 }
 
-bool parse_node(Cur &c, StateDescriptors &out)
+bool parse_node(Cur &c, StateDescriptors &out, std::vector<DataSpan> &spans)
 {
     c.ws();
     if (c.p >= c.end || *c.p != '{') return c.fail("DataNodes[]: expected object");
@@ -158,8 +210,7 @@ bool parse_node(Cur &c, StateDescriptors &out)
     uint64_t stamp = 0;
     bool have_stamp = false, have_desc = false;
     int available = -1;
-    std::vector<double> vals;
-    int64_t rows = 0, cols = 0;
+    DataSpan sp;
     for (;;) {
         c.ws();
         if (c.p < c.end && *c.p == '}') { c.p++; break; }
@@ -178,7 +229,7 @@ bool parse_node(Cur &c, StateDescriptors &out)
         } else if (key == "isWholeImageDescriptorAvailable") {
             if (c.lit("true")) available = 1; else if (c.lit("false")) available = 0; else return c.fail("bad bool");
         } else if (key == "wholeImageDescriptor") {
-            if (!parse_descriptor(c, vals, rows, cols)) return false;
+            if (!parse_descriptor(c, sp)) return false;
             have_desc = true;
         } else if (!skip_value(c)) return false;
         c.ws();
@@ -187,11 +238,12 @@ bool parse_node(Cur &c, StateDescriptors &out)
     out.n_nodes++;
     if (have_desc && available != 0) {   // DataManager::loadStateFromDisk only restores it when the flag is set
         if (!have_stamp) return c.fail("node with descriptor but no stampNSec");
-        const int D = (int)(rows * cols);
+        const int D = (int)(sp.rows * sp.cols);
         if (out.D == 0) out.D = D;
         if (D != out.D) return c.fail("descriptor size differs between nodes");
         out.stampNSec.push_back(stamp);
-        out.desc.insert(out.desc.end(), vals.begin(), vals.end());
+        sp.stamp = stamp;
+        spans.push_back(sp);
     }
     return true;
 }
@@ -206,6 +258,7 @@ bool parse_state_json(const std::string &text, StateDescriptors &out)
     if (c.p >= c.end || *c.p != '{') { out.error = "top level: expected object"; return false; }
     c.p++;
     bool seen = false;
+    std::vector<DataSpan> spans;
     for (;;) {
         c.ws();
         if (c.p < c.end && *c.p == '}') break;
@@ -223,7 +276,7 @@ bool parse_state_json(const std::string &text, StateDescriptors &out)
             if (c.p < c.end && *c.p == ']') c.p++;
             else
                 for (;;) {
-                    if (!parse_node(c, out)) break;
+                    if (!parse_node(c, out, spans)) break;
                     c.ws();
                     if (c.p < c.end && *c.p == ',') { c.p++; continue; }
                     if (c.p < c.end && *c.p == ']') { c.p++; break; }
@@ -236,6 +289,38 @@ bool parse_state_json(const std::string &text, StateDescriptors &out)
         if (c.p < c.end && *c.p == ',') c.p++;
     }
     if (c.err.empty() && !seen) c.err = "no DataNodes array";
+    if (c.err.empty() && !spans.empty()) {
+        // second pass: number conversion, descriptors split evenly over the threads
+        const size_t n = spans.size(), D = (size_t)out.D;
+        out.desc.resize(n * D);
+        unsigned nt = std::thread::hardware_concurrency();
+        if (nt > 32) nt = 32;
+        if (nt > n) nt = (unsigned)n;
+        if (nt < 1) nt = 1;
+        std::atomic<const char *> first_err{nullptr};
+        auto work = [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi && !first_err.load(std::memory_order_relaxed); i++) {
+                const DataSpan &sp = spans[i];
+                const char *err = nullptr;
+                bool ok;
+                if (sp.plain) ok = convert_values(sp.b, sp.e, true, &out.desc[i * D], (int64_t)D, &err);
+                else {  // unusual escapes (\uXXXX ...): decode the string first
+                    Cur d{sp.b - 1, c.end, {}};
+                    std::string data;
+                    ok = parse_string(d, &data);
+                    if (!ok) err = "wholeImageDescriptor.data: bad string";
+                    else ok = convert_values(data.c_str(), data.c_str() + data.size(), false, &out.desc[i * D], (int64_t)D, &err);
+                }
+                if (!ok) { const char *expect = nullptr; first_err.compare_exchange_strong(expect, err); }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+        work(0, n / nt);
+        for (std::thread &th : pool) th.join();
+        if (const char *e = first_err.load()) c.err = e;
+    }
+    if (!c.err.empty()) { out.stampNSec.clear(); out.desc.clear(); }
     out.error = c.err;
     return c.err.empty();
 }
@@ -245,6 +330,11 @@ bool load_state_json(const std::string &path, StateDescriptors &out)
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) { out = StateDescriptors(); out.error = "cannot open " + path; return false; }
     std::string text;
+    if (std::fseek(f, 0, SEEK_END) == 0) {
+        const long sz = std::ftell(f);
+        if (sz > 0) text.reserve((size_t)sz);
+        std::rewind(f);
+    }
     char buf[1 << 16];
     size_t n;
     while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);

@@ -123,6 +123,47 @@ def test_state_json_parser_matches_python(tmp_path):
     assert r.returncode == 6 and "rows*cols" in r.stderr
 
 
+def _parse_only(tmp_path, text):
+    (tmp_path / "t.json").write_text(text)
+    r = subprocess.run([str(LIB / "cerebro_replay"), "--parse-only", str(tmp_path / "t.json"), str(tmp_path / "t.bin")], capture_output=True, text=True)
+    if r.returncode != 0:
+        return r.returncode, r.stderr
+    raw = (tmp_path / "t.bin").read_bytes()
+    Dg, n = struct.unpack_from("<IQ", raw, 0)
+    return 0, np.frombuffer(raw, dtype=np.float64, count=n * Dg, offset=12 + 8 * n).reshape(n, Dg)
+
+
+def test_state_json_number_conversion_edge_cases(tmp_path):
+    """The data text is converted with from_chars and, for what it rejects, strtod -- together the reference's std::stod
+    (RawFileIO.cpp:418-459).  Separators: real or escaped newlines/tabs, ", " (Eigen's coeff separator), and \\uXXXX."""
+    vals = ["1.5", "-2.25e-3", "0.1", "123456789012345678", "4.9406564584124654e-324", "1e400", "-nan", "inf", "+3.5", "0x1p-2", "1E5", ".5"]
+    want = np.array([float(v.replace("-nan", "nan")) if not v.startswith("0x") else float.fromhex(v) for v in vals])
+    node = lambda data: json.dumps({"DataNodes": [{"stampNSec": 7, "wholeImageDescriptor": {"rows": len(vals), "cols": 1, "data": data}}]})
+    for sep in ("\n", ", ", "\t \n", " "):
+        rc, got = _parse_only(tmp_path, node(sep.join(vals)))
+        assert rc == 0 and np.array_equal(got[0], want, equal_nan=True), (sep, got)
+        assert np.signbit(got[0][8]) == False and got[0][5] == np.inf
+    # the same text with every newline spelled as a \u escape takes the decode-first path
+    doc = node("\n".join(vals)).replace("\\n", "\\u000a")
+    assert "\\u000a" in doc
+    rc, got = _parse_only(tmp_path, doc)
+    assert rc == 0 and np.array_equal(got[0], want, equal_nan=True)
+    # escaped quote / backslash pairs before the closing quote do not confuse the string scanner
+    doc = json.dumps({"DataNodes": [{"stampNSec": 7, "note": "a\\\\", "q": "x\\\"y", "wholeImageDescriptor": {"rows": 2, "cols": 1, "data": "1\n2"}}]})
+    rc, got = _parse_only(tmp_path, doc)
+    assert rc == 0 and got.tolist() == [[1.0, 2.0]]
+    for bad in ("1\n2\n3\n4", "1\nabc", "1\n2\n"):
+        rc, err = _parse_only(tmp_path, json.dumps({"DataNodes": [{"stampNSec": 7, "wholeImageDescriptor": {"rows": 3, "cols": 1, "data": bad}}]}))
+        assert rc == 6, (bad, err)
+    # many descriptors -> several conversion threads; every row lands in its own slot
+    N, D = 300, 8
+    vals2 = np.arange(N * D, dtype=np.float64).reshape(N, D) / 7
+    doc = json.dumps({"DataNodes": [{"stampNSec": i, "wholeImageDescriptor": {"rows": D, "cols": 1, "data": "\n".join(repr(float(x)) for x in vals2[i])}}
+                                    for i in range(N)]})
+    rc, got = _parse_only(tmp_path, doc)
+    assert rc == 0 and np.array_equal(got, vals2)
+
+
 @pytest.mark.gpu
 def test_cold_start_from_state_json_matches_oracle(tmp_path):
     D, N = 1024, 700
