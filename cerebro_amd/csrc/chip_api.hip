@@ -164,7 +164,15 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
     if (c->scan_blocks_per_cu < 1) c->scan_blocks_per_cu = 1;
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);
     c->max_grid = 512;  // K2 (one 512-thread workgroup) keeps one partial list per thread
-    CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_scan, hipStreamNonBlocking));
+    {
+        const int pr = env_int("CHIP_SCAN_STREAM_PRIORITY", 0);   // tuning only: 0 = default class, 1 = highest, -1 = lowest
+        if (pr == 0) CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_scan, hipStreamNonBlocking));
+        else {
+            int lo = 0, hi = 0;
+            CHIP_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            CHIP_HIP(c, hipStreamCreateWithPriority(&c->s_scan, hipStreamNonBlocking, pr > 0 ? hi : lo));
+        }
+    }
     for (int i = 0; i < Ctx::kRing; i++) {
         CHIP_HIP(c, hipMalloc(&c->partial_dev[i], (size_t)c->max_grid * CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry)));
         CHIP_HIP(c, hipEventCreateWithFlags(&c->ev_scan[i], hipEventDisableTiming));

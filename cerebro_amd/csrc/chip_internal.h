@@ -92,12 +92,15 @@ struct Ctx {
     // Scans run back-to-back on s_scan; the merge of tick i runs on the ctx stream (s_query) behind ev_scan[b], so
     // it (and, sharded, the all-gather + global merge that follow it on the ctx stream) overlaps the scan of tick
     // i+1.  Partial lists live in a ring of kRing buffers; a scan waits for the merge that last read its buffer.
-    static constexpr int kRing = 4;
+    // Deeper than the number of ticks a caller can keep in flight (CHIP_MAX_INFLIGHT): in steady state the merge that last
+    // read a buffer is long complete when its next scan is enqueued, so no barrier packet is put in front of the scan
+    // (each one costs the scan stream ~7 us; 64 x 512 KiB of HBM is nothing).
+    static constexpr int kRing = 64;
     hipStream_t s_scan = nullptr;
-    chip_topk_entry *partial_dev[kRing] = {nullptr, nullptr, nullptr, nullptr};   // [max_grid][CHIP_MAX_NQ][CHIP_MAX_TOPK]
-    int32_t partial_lists[kRing] = {0, 0, 0, 0};                                  // grid of the scan that filled it
-    hipEvent_t ev_scan[kRing] = {nullptr, nullptr, nullptr, nullptr};             // scan into buffer b finished
-    hipEvent_t ev_merged[kRing] = {nullptr, nullptr, nullptr, nullptr};           // merge out of buffer b finished
+    chip_topk_entry *partial_dev[kRing] = {};   // [max_grid][CHIP_MAX_NQ][CHIP_MAX_TOPK]
+    int32_t partial_lists[kRing] = {};                               // grid of the scan that filled it
+    hipEvent_t ev_scan[kRing] = {};             // scan into buffer b finished
+    hipEvent_t ev_merged[kRing] = {};           // merge out of buffer b finished
     uint64_t n_enqueued = 0;
     int32_t max_grid = 0;
     chip_topk_entry *topk_dev = nullptr;      // [CHIP_MAX_NQ][CHIP_MAX_TOPK]

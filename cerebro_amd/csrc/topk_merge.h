@@ -38,6 +38,59 @@ __device__ __forceinline__ int64_t readlane_i64(int64_t v, int j)
     return ((int64_t)hi << 32) | (unsigned int)lo;
 }
 
+// Order-preserving integer image of a finite (or -inf) double: a > b  <=>  okey(a) > okey(b).
+__device__ __forceinline__ unsigned long long okey(double s)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(s);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// Number of lanes of the wave whose key (score desc, idx desc) is strictly greater than this lane's.  Fast path: the
+// upper 32 bits of okey (sign, exponent, 20 mantissa bits) are compared with full-rate 32-bit ops; only when two VALID
+// lanes agree in those bits (scores within ~1e-6 relative, e.g. exact duplicates) does the wave redo the loop with the
+// exact (f64, i64) comparison.  Both paths give the same ranks; the branch is wave-uniform.
+__device__ __forceinline__ int wave_rank(double s, int64_t i, bool valid)
+{
+    const unsigned kh = (unsigned)(okey(s) >> 32);
+    int rank = 0, eq = 0;
+#pragma unroll 16
+    for (int j = 0; j < 64; j++) {
+        const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)kh, j);
+        rank += o > kh ? 1 : 0;
+        eq += o == kh ? 1 : 0;
+    }
+    if (__ballot(valid && eq > 1) == 0ull) return rank;   // eq counts the lane itself
+    rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < 64; j++) rank += key_gt(readlane_f64(s, j), readlane_i64(i, j), s, i) ? 1 : 0;
+    return rank;
+}
+
+// Same for two keys per lane (128 candidates): ranks of (s0,i0) and (s1,i1) among all 128.
+__device__ __forceinline__ void wave_rank2(const double s[2], const int64_t i[2], int &r0, int &r1)
+{
+    const unsigned k0 = (unsigned)(okey(s[0]) >> 32), k1 = (unsigned)(okey(s[1]) >> 32);
+    int e0 = 0, e1 = 0;
+    r0 = r1 = 0;
+#pragma unroll 16
+    for (int j = 0; j < 64; j++) {
+        const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)k0, j), b = (unsigned)__builtin_amdgcn_readlane((int)k1, j);
+        r0 += (a > k0 ? 1 : 0) + (b > k0 ? 1 : 0);
+        e0 += (a == k0 ? 1 : 0) + (b == k0 ? 1 : 0);
+        r1 += (a > k1 ? 1 : 0) + (b > k1 ? 1 : 0);
+        e1 += (a == k1 ? 1 : 0) + (b == k1 ? 1 : 0);
+    }
+    if (__ballot((i[0] >= 0 && e0 > 1) || (i[1] >= 0 && e1 > 1)) == 0ull) return;
+    r0 = r1 = 0;
+#pragma unroll 8
+    for (int j = 0; j < 64; j++) {
+        const double a0 = readlane_f64(s[0], j), a1 = readlane_f64(s[1], j);
+        const int64_t b0 = readlane_i64(i[0], j), b1 = readlane_i64(i[1], j);
+        r0 += (key_gt(a0, b0, s[0], i[0]) ? 1 : 0) + (key_gt(a1, b1, s[0], i[0]) ? 1 : 0);
+        r1 += (key_gt(a0, b0, s[1], i[1]) ? 1 : 0) + (key_gt(a1, b1, s[1], i[1]) ? 1 : 0);
+    }
+}
+
 template <int NQ>
 __device__ __forceinline__ void merge_sorted_lists(const chip_topk_entry *in, int n_lists, int list_stride, int q_off, int K, chip_topk_entry *out,
                                                    chip_tick_result *result, int64_t l, int locality, double thresh, char *smem)
@@ -62,10 +115,8 @@ __device__ __forceinline__ void merge_sorted_lists(const chip_topk_entry *in, in
     // ---- 2. per-wave rank of the heads; the K best of each wave go to candA[q][w*K + rank] ----
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-        int rank = 0;
-#pragma unroll 8
-        for (int j = 0; j < 64; j++) rank += key_gt(readlane_f64(hs[q], j), readlane_i64(hi[q], j), hs[q], hi[q]) ? 1 : 0;
         const bool valid = hi[q] >= 0;
+        const int rank = wave_rank(hs[q], hi[q], valid);
         const int nvalid = __popcll(__ballot(valid));
         chip_topk_entry *dst = candA + (q * 8 + w) * CHIP_MAX_TOPK;
         if (valid && rank < K) { dst[rank].score = hs[q]; dst[rank].idx = hi[q]; }
@@ -83,14 +134,8 @@ __device__ __forceinline__ void merge_sorted_lists(const chip_topk_entry *in, in
             if (c < nw * K) { const chip_topk_entry x = candA[(q * 8 + c / K) * CHIP_MAX_TOPK + (c % K)]; cs[h] = x.score; ci[h] = x.idx; }
             else { cs[h] = -INFINITY; ci[h] = -1; }
         }
-        int r0 = 0, r1 = 0;
-#pragma unroll 8
-        for (int j = 0; j < 64; j++) {
-            const double a0 = readlane_f64(cs[0], j), a1 = readlane_f64(cs[1], j);
-            const int64_t b0 = readlane_i64(ci[0], j), b1 = readlane_i64(ci[1], j);
-            r0 += (key_gt(a0, b0, cs[0], ci[0]) ? 1 : 0) + (key_gt(a1, b1, cs[0], ci[0]) ? 1 : 0);
-            r1 += (key_gt(a0, b0, cs[1], ci[1]) ? 1 : 0) + (key_gt(a1, b1, cs[1], ci[1]) ? 1 : 0);
-        }
+        int r0, r1;
+        wave_rank2(cs, ci, r0, r1);
         const int nv = __popcll(__ballot(ci[0] >= 0)) + __popcll(__ballot(ci[1] >= 0));
         if (nv >= K) {
             if (ci[0] >= 0 && r0 == K - 1) { T1s[q].score = cs[0]; T1s[q].idx = ci[0]; }
