@@ -114,6 +114,7 @@ static void destroy_ctx(chip_ctx *c)
         if (c->ev_merged[i]) (void)hipEventDestroy(c->ev_merged[i]);
     }
     if (c->s_scan) (void)hipStreamDestroy(c->s_scan);
+    if (c->s_scan2) (void)hipStreamDestroy(c->s_scan2);
     if (c->topk_host) (void)hipHostFree(c->topk_host);
     if (c->qvec_dev) (void)hipFree(c->qvec_dev);
     for (Slot &s : c->slots) {
@@ -173,6 +174,7 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
             CHIP_HIP(c, hipStreamCreateWithPriority(&c->s_scan, hipStreamNonBlocking, pr > 0 ? hi : lo));
         }
     }
+    if (env_int("CHIP_SCAN_STREAMS", 2) >= 2) CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_scan2, hipStreamNonBlocking));
     for (int i = 0; i < Ctx::kRing; i++) {
         CHIP_HIP(c, hipMalloc(&c->partial_dev[i], (size_t)c->max_grid * CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry)));
         CHIP_HIP(c, hipEventCreateWithFlags(&c->ev_scan[i], hipEventDisableTiming));
@@ -202,9 +204,16 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
 // [nq][K]; res (optional) the decision record of Cerebro.cpp:1056.  Consecutive calls pipeline: scans run back to
 // back on s_scan while the previous merge (and whatever the caller enqueues after it on the ctx stream) proceeds.
 static int enqueue_scan_merge(Ctx *c, int64_t k, const float *const *q, int nq, int K, int64_t l,
-                              const chip_dot_params *p, chip_topk_entry *out, chip_tick_result *res)
+                              const chip_dot_params *p, chip_topk_entry *out, chip_tick_result *res, bool tick = false)
 {
     const int b = (int)(c->n_enqueued++ % Ctx::kRing);
+    // Ticks (queries already resident) over a short prefix alternate between two scan streams so that the ramp-down of
+    // one launch overlaps the ramp-up of the next (measured, 1 -> 2 streams: 10k rows 45 -> 38 us/tick, 60k 172 -> 153,
+    // 125k 317 -> 308, 500k 1191 -> 1157; at 1M the gain is < 1 %, and launches that overlap would no longer have a
+    // meaningful per-launch duration for the roofline, so long scans and profiled runs stay on one stream).  Anything that
+    // uploads its queries on s_scan first stays on s_scan.
+    const bool short_scan = (double)local_count(c, k) * c->D * sizeof(float) <= 8.0 * 1024 * 1024 * 1024;
+    hipStream_t s_scan = (tick && short_scan && !c->prof_on && c->s_scan2 && (c->n_enqueued & 1)) ? c->s_scan2 : c->s_scan;
     ScanArgs a;
     a.seg_table = c->seg_table_dev;
     a.seg_shift = c->seg_shift;
@@ -220,7 +229,7 @@ static int enqueue_scan_merge(Ctx *c, int64_t k, const float *const *q, int nq, 
 
     // The merge that last read this buffer ran kRing ticks ago; only when it is not already complete (a stalled ctx
     // stream) does the scan stream need a barrier packet -- in steady state this costs nothing.
-    if (hipEventQuery(c->ev_merged[b]) != hipSuccess) CHIP_HIP(c, hipStreamWaitEvent(c->s_scan, c->ev_merged[b], 0));
+    if (hipEventQuery(c->ev_merged[b]) != hipSuccess) CHIP_HIP(c, hipStreamWaitEvent(s_scan, c->ev_merged[b], 0));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->prof_on) {
         if (c->prof_used + 2 > c->prof_ev.size()) {
@@ -234,12 +243,12 @@ static int enqueue_scan_merge(Ctx *c, int64_t k, const float *const *q, int nq, 
         e1 = c->prof_ev[c->prof_used + 1];
         c->prof_used += 2;
         c->prof_bytes_last = (double)a.n_rows * c->D * 4.0;
-        CHIP_HIP(c, hipEventRecord(e0, c->s_scan));
+        CHIP_HIP(c, hipEventRecord(e0, s_scan));
     }
-    int rc = launch_scan(c, c->s_scan, a, nq, grid);
+    int rc = launch_scan(c, s_scan, a, nq, grid);
     if (rc != CHIP_OK) return rc;
-    if (e1) CHIP_HIP(c, hipEventRecord(e1, c->s_scan));
-    CHIP_HIP(c, hipEventRecord(c->ev_scan[b], c->s_scan));
+    if (e1) CHIP_HIP(c, hipEventRecord(e1, s_scan));
+    CHIP_HIP(c, hipEventRecord(c->ev_scan[b], s_scan));
     CHIP_HIP(c, hipStreamWaitEvent(c->s_query, c->ev_scan[b], 0));
 
     MergeArgs m;
@@ -321,7 +330,7 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
     const float *q[3];
     rc = query_row_ptrs(c, rows, 3, l, q);
     if (rc != CHIP_OK) return rc;
-    rc = enqueue_scan_merge(c, k, q, 3, CHIP_DEFAULT_TOPK, l, p, nullptr, s.dev);
+    rc = enqueue_scan_merge(c, k, q, 3, CHIP_DEFAULT_TOPK, l, p, nullptr, s.dev, true);
     if (rc != CHIP_OK) return rc;
     CHIP_HIP(c, hipEventRecord(s.done, c->s_query));
     s.immediate = false;
@@ -461,6 +470,7 @@ int chip_synchronize(chip_ctx *c)
     CHIP_HIP(c, hipSetDevice(c->device));
     CHIP_HIP(c, hipStreamSynchronize(c->s_append));
     CHIP_HIP(c, hipStreamSynchronize(c->s_scan));
+    if (c->s_scan2) CHIP_HIP(c, hipStreamSynchronize(c->s_scan2));
     CHIP_HIP(c, hipStreamSynchronize(c->s_query));
     CHIP_HIP(c, hipStreamSynchronize(c->s_pnp));
     return CHIP_OK;
@@ -646,7 +656,7 @@ int chip_scan_local(chip_ctx *c, int64_t l, const chip_dot_params *p, int32_t to
     // scan on s_scan, then (behind an event) the local merge on the ctx stream writes this rank's 3 x topk list to
     // dev_out: everything the caller enqueues next on the ctx stream (the all-gather) is ordered after it, while the
     // next tick's scan is free to start as soon as this scan ends.
-    return enqueue_scan_merge(c, k, q, 3, topk, l, nullptr, (chip_topk_entry *)dev_out, nullptr);
+    return enqueue_scan_merge(c, k, q, 3, topk, l, nullptr, (chip_topk_entry *)dev_out, nullptr, true);
 }
 
 static int merge_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, const void *dev_gathered, int32_t n_lists, int32_t topk, Slot &s)
@@ -734,6 +744,7 @@ int chip_profile_scan(chip_ctx *c, double *total_ms, int64_t *n_launches, double
     std::lock_guard<std::mutex> qlk(c->query_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
     CHIP_HIP(c, hipStreamSynchronize(c->s_scan));
+    if (c->s_scan2) CHIP_HIP(c, hipStreamSynchronize(c->s_scan2));
     CHIP_HIP(c, hipStreamSynchronize(c->s_query));
     double tot = 0.0, span = 0.0;
     for (size_t i = 0; i + 1 < c->prof_used; i += 2) {

@@ -97,6 +97,7 @@ struct Ctx {
     // (each one costs the scan stream ~7 us; 64 x 512 KiB of HBM is nothing).
     static constexpr int kRing = 64;
     hipStream_t s_scan = nullptr;
+    hipStream_t s_scan2 = nullptr;   // second scan stream for short scans (CHIP_SCAN_STREAMS=1 disables)
     chip_topk_entry *partial_dev[kRing] = {};   // [max_grid][CHIP_MAX_NQ][CHIP_MAX_TOPK]
     int32_t partial_lists[kRing] = {};                               // grid of the scan that filled it
     hipEvent_t ev_scan[kRing] = {};             // scan into buffer b finished
