@@ -434,6 +434,15 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
 // ------------------------------------------------------------------------------------------------ K5b + K6
 constexpr int EN = 27;
 
+// value of `v` in lane j (wave-uniform j): two v_readlane_b32, result in SGPRs
+__device__ __forceinline__ double lane_value_f64(double v, int j)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), j);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), j);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 struct EigArgs {
     PnpProblem prob[kPnpMaxBatch];
     int32_t H, S;
@@ -677,22 +686,43 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             __syncthreads();
             if (lane >= m + 2 && lane <= n) { HH(lane, lane - 2) = 0.0; if (lane > m + 2) HH(lane, lane - 3) = 0.0; }
             __syncthreads();
-            for (int k = m; k <= n - 1; k++) {  // double QR step on rows l..n, columns m..n
+            // Double QR step on rows l..n, columns m..n.  Per step: (1) the reflector from column k-1, (2) row modification
+            // (lane = column j of H), (3) column modification (lane = row i of H) together with the accumulation into V
+            // (lanes 32..58 = row i of V): both have the form  pp = x*A(i,k) + y*A(i,k+1) [+ z*A(i,k+2)], so one
+            // instruction stream serves them with a per-lane base pointer instead of two divergent blocks executed back
+            // to back.  The first column of (3) is also what the next step's reflector is built from: it is forwarded
+            // through v_readlane instead of an LDS write -> barrier -> read.
+            double *const Abase = (lane < 32) ? Hs : Vs;     // lanes 0..26 work on H, lanes 32..58 on V
+            const int arow = (lane < 32) ? lane : lane - 32;
+            bool fwd = false;
+            double fp = 0.0, fq = 0.0, fr = 0.0;
+            for (int k = m; k <= n - 1; k++) {
                 const bool notlast = (k != n - 1);
                 if (k != m) {
-                    p = HH(k, k - 1); q = HH(k + 1, k - 1); r = notlast ? HH(k + 2, k - 1) : 0.0;
+                    if (fwd) { p = fp; q = fq; r = fr; }
+                    else { p = HH(k, k - 1); q = HH(k + 1, k - 1); r = notlast ? HH(k + 2, k - 1) : 0.0; }
+                    fwd = false;
                     x = fabs(p) + fabs(q) + fabs(r);
                     if (x == 0.0) continue;
-                    p = p / x; q = q / x; r = r / x;
+                    // p/x, q/x, r/x: the operands are wave-uniform, so the three IEEE divisions are issued as ONE vector
+                    // division (lanes 0,1,2) and read back -- same quotients, a third of the instructions
+                    const double quo = ((lane == 0) ? p : ((lane == 1) ? q : r)) / x;
+                    p = lane_value_f64(quo, 0); q = lane_value_f64(quo, 1); r = lane_value_f64(quo, 2);
                 }
+                fwd = false;
                 s = sqrt(p * p + q * q + r * r);
                 if (p < 0) s = -s;
                 if (s != 0.0) {
                     const double hkk1 = (k != m) ? -s * x : ((l != m) ? -HH(k, k - 1) : 0.0);
                     const bool wr_sub = (k != m) || (l != m);
                     p = p + s;
-                    x = p / s; y = q / s; z = r / s;
-                    q = q / p; r = r / p;
+                    {   // x = p/s, y = q/s, z = r/s, q = q/p, r = r/p as one vector division over lanes 0..4
+                        const double num = (lane == 0) ? p : ((lane & 1) ? q : r);
+                        const double den = (lane < 3) ? s : p;
+                        const double quo = num / den;
+                        x = lane_value_f64(quo, 0); y = lane_value_f64(quo, 1); z = lane_value_f64(quo, 2);
+                        q = lane_value_f64(quo, 3); r = lane_value_f64(quo, 4);
+                    }
                     __syncthreads();
                     if (wr_sub && lane == 63) HH(k, k - 1) = hkk1;
                     if (lane >= k && lane < nn) {  // row modification, column j = lane
@@ -702,21 +732,23 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                         HH(k, j) = HH(k, j) - pp * x;
                         HH(k + 1, j) = HH(k + 1, j) - pp * y;
                     }
-                    if (lane >= 32 && lane - 32 <= high) {  // accumulate transformations, row i of V (lanes 32..58)
-                        const int i = lane - 32;
-                        double pp = x * VV(i, k) + y * VV(i, k + 1);
-                        if (notlast) { pp = pp + z * VV(i, k + 2); VV(i, k + 2) = VV(i, k + 2) - pp * r; }
-                        VV(i, k) = VV(i, k) - pp;
-                        VV(i, k + 1) = VV(i, k + 1) - pp * q;
-                    }
                     __syncthreads();
                     const int imax = (n < k + 3) ? n : k + 3;
-                    if (lane <= imax) {  // column modification, row i = lane
-                        const int i = lane;
-                        double pp = x * HH(i, k) + y * HH(i, k + 1);
-                        if (notlast) { pp = pp + z * HH(i, k + 2); HH(i, k + 2) = HH(i, k + 2) - pp * r; }
-                        HH(i, k) = HH(i, k) - pp;
-                        HH(i, k + 1) = HH(i, k + 1) - pp * q;
+                    double c0 = 0.0;
+                    if ((lane < 32) ? (lane <= imax) : (lane - 32 <= high)) {  // H rows 0..imax | V rows 0..26
+                        double *row = Abase + arow * EN + k;
+                        double pp = x * row[0] + y * row[1];
+                        if (notlast) { pp = pp + z * row[2]; row[2] = row[2] - pp * r; }
+                        c0 = row[0] - pp;
+                        row[0] = c0;
+                        row[1] = row[1] - pp * q;
+                    }
+                    // next reflector: H(k+1,k), H(k+2,k), H(k+3,k) as just computed by lanes k+1, k+2, k+3 (<= imax)
+                    if (k + 1 <= n - 1) {
+                        fp = lane_value_f64(c0, k + 1);
+                        fq = lane_value_f64(c0, k + 2);
+                        fr = (k + 1 != n - 1) ? lane_value_f64(c0, k + 3) : 0.0;
+                        fwd = true;
                     }
                     __syncthreads();
                 }
