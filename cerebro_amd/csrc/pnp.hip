@@ -127,6 +127,15 @@ __device__ __forceinline__ double wave_max_nonneg(double v)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// value of `v` in lane j (wave-uniform j): two v_readlane_b32, result in SGPRs
+__device__ __forceinline__ double lane_value_f64(double v, int j)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), j);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), j);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // ------------------------------------------------------------------------------------------------ K4 + K5a
 constexpr int kNR = 93, kNC = 120;
 
@@ -153,6 +162,11 @@ struct SolveArgs {
 };
 
 constexpr int kSolveThreads = 512;
+constexpr int kPanel = 4;   // pivot columns factorised per panel of the blocked LU
+// dynamic LDS of pnp_build_solve (must match the carve-up at the top of the kernel)
+constexpr size_t kSolveLds = sizeof(double) * (kSampleMax * 8 + 9 + 9 + 27 + 27 + 81 + 90 + 100 + 36 + 60 + 4 + 27 * 27 +
+                                               96 * kPanel * 2 + kPanel * 128 + kPanel * kPanel + 27 * kNC) +
+                             sizeof(int) * (16 + 32 + 32 + 4 + kPanel) + sizeof(short) * (kNR * 20) + 64;
 
 __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
 {
@@ -172,17 +186,17 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     double *fc = sm;            sm += 60;                         // f[3][20]
     double *uu = sm;            sm += 4;
     double *Xb = sm;            sm += 27 * 27;                    // X[66+t][c]
-    double *Lcol = sm;          sm += 8 * 24;                     // multipliers of the current elimination step, per wave
-    double *prow_buf = sm;      sm += 128;                        // the pivot row (broadcast operand of the update)
-    double *colbuf = sm;        sm += 96;                         // column k of the not-yet-pivoted rows (by physical row)
+    double *panel = sm;         sm += 96 * kPanel;                // the kPanel pivot columns of the current panel, [physical row][c]
+    double *Lp = sm;            sm += 96 * kPanel;                // multipliers of the current panel, [physical row][c]
+    double *prow_raw = sm;      sm += kPanel * 128;               // the panel's pivot rows as they were before the panel, [c][column]
+    double *Lsub = sm;          sm += kPanel * kPanel;            // multipliers among the panel's pivot rows, [c][c' < c]
     double *Urows = sm;         sm += 27 * kNC;                   // pivot rows of steps 66..92 = rows of U needed by the back-substitution
     int *smp = reinterpret_cast<int *>(sm);                       // [16]
     int *fy_key = smp + 16;                                        // sparse Fisher-Yates map (<= 32 entries)
     int *fy_val = fy_key + 32;
-    int *flag = fy_val + 32;                                       // [4] : singular, pivot physical row, spare
-    int *logpos = flag + 4;                                        // [96] logical position of each physical row (partial-pivoting swaps)
-    int *physof = logpos + 96;                                     // [96] inverse map
-    short *rdst = reinterpret_cast<short *>(physof + 96);          // [93][20] LDS copy of the Macaulay destination table
+    int *flag = fy_val + 32;                                       // [4] : singular, spare
+    int *prow_s = flag + 4;                                        // [kPanel] physical pivot rows of the current panel
+    short *rdst = reinterpret_cast<short *>(prow_s + kPanel);      // [93][20] LDS copy of the Macaulay destination table
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -308,7 +322,6 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     //      column in er[0..23] (static slot indices); only column k, the pivot row and the multipliers cross LDS. ----
     const int tx = tid & 127, ty = tid >> 7;
     for (int e = tid; e < kNR * 20; e += kSolveThreads) rdst[e] = tb.row_dst[e / 20][e % 20];
-    if (tid < 96) { logpos[tid] = tid; physof[tid] = tid; }
     __syncthreads();
     double er[24];
     unsigned live = 0;   // bit s set <=> physical row ty + 4*s exists and has not been used as a pivot yet
@@ -324,79 +337,164 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
         }
         er[sl] = v;
     }
-    // column 0 of the live rows -> colbuf
-    if (tx == 0) {
+    // columns 0..kPanel-1 -> panel
+    if (tx < kPanel) {
 #pragma unroll
-        for (int sl = 0; sl < 24; sl++)
-            if (live >> sl & 1u) colbuf[ty + 4 * sl] = er[sl];
+        for (int sl = 0; sl < 24; sl++) panel[(ty + 4 * sl) * kPanel + tx] = er[sl];
     }
+    if (tid == 0) flag[0] = 0;
     __syncthreads();
 
-    // ---- LU with partial (row) pivoting, no physical swaps: logpos[] tracks where the reference's swaps would have put
-    //      every row, so "first row attaining the max" (ties -> smallest logical index) is reproduced exactly. ----
+    // ---- Blocked right-looking LU with partial (row) pivoting, no physical swaps.  Per panel of kPanel pivot columns:
+    //   P2  wave 0 factorises the panel alone (2 physical rows per lane, everything in registers / DPP / readlane): pivot =
+    //       max |column| over the rows not yet used, ties -> smallest LOGICAL index (lp0/lp1 track where the reference's row
+    //       swaps would have put every row), multipliers, update of the remaining panel columns;
+    //   P3  the owners of the kPanel pivot rows publish them as they were before the panel;
+    //   P4  every thread rebuilds the pivot rows' values for its column (triangular solve with the multipliers among the
+    //       pivot rows), applies the kPanel rank-1 updates to its 24 register-resident rows ONE AFTER THE OTHER (so every
+    //       element sees exactly the operation sequence of the unblocked elimination), and the owners of the next kPanel
+    //       columns refill the panel.
+    //   3 barriers per kPanel columns instead of 2 per column, and one pivot search latency chain per panel. ----
     bool singular = false;
-    double *Lw = Lcol;   // [8 waves][24]: multipliers of each wave's own row group (rows ty, ty+4, ...), wave-private
-    for (int k = 0; k < kNR; k++) {
-        // -- S1: EVERY wave finds the pivot itself (no cross-wave hand-off): max |column k| over the live rows and, among the
-        //    rows attaining it, the smallest LOGICAL index (the reference's "first row attaining the max")
-        const int i0 = lane, i1 = lane + 64;
-        const int lp0 = logpos[i0], lp1 = i1 < kNR ? logpos[i1] : -1;   // i0 < 64 < 93 always valid
-        const bool al0 = lp0 >= k, al1 = lp1 >= k;                      // pivots sit at logical positions < k
-        const double v0 = al0 ? fabs(colbuf[i0]) : -1.0, v1 = al1 ? fabs(colbuf[i1]) : -1.0;
-        double vm = v0 > 0.0 ? v0 : 0.0;                                // NaN never wins, as in the reference scan
-        if (v1 > vm) vm = v1;
-        const double best = wave_max_nonneg(vm);
-        const unsigned long long t0 = __ballot(al0 && v0 == best), t1 = __ballot(al1 && v1 == best);
-        int plog = 0x7fffffff;
-        if (__popcll(t0) + __popcll(t1) == 1) plog = t0 ? __builtin_amdgcn_readlane(lp0, __builtin_ctzll(t0)) : __builtin_amdgcn_readlane(lp1, __builtin_ctzll(t1 ? t1 : 1ull));
-        else if (t0 | t1) {                                              // exact ties are rare: butterfly min over logical indices
-            plog = (al0 && v0 == best) ? lp0 : 0x7fffffff;
-            if (al1 && v1 == best && lp1 < plog) plog = lp1;
+    int lp0 = lane, lp1 = lane + 64;   // wave 0: logical position of physical rows lane, lane + 64
+    for (int k = 0; k < kNR; k += kPanel) {
+        const int bw = (kNR - k) < kPanel ? (kNR - k) : kPanel;
+        if (wave == 0) {
+            const int r0 = lane, r1 = lane + 64;
+            const bool has1 = r1 < kNR;
+            double a0[kPanel], a1[kPanel], l0[kPanel], l1[kPanel];
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(plog, m, 64); plog = o < plog ? o : plog; }
-        }
-        if (!(best > 0.0) || plog == 0x7fffffff) { singular = true; break; }   // same decision in every wave
-        const int prow = physof[plog];
-        const double piv = colbuf[prow];
-        if (lane < 24) {   // multipliers of this wave's row group
-            const int row = ty + 4 * lane;
-            double l = 0.0;
-            if (row < kNR && logpos[row] >= k && row != prow) l = colbuf[row] / piv;
-            Lw[wave * 24 + lane] = l;
-        }
-        if ((prow & 3) == ty && tx < kNC) {   // owners of the pivot row publish it: dynamic slot -> static select chain
-            const int ps = prow >> 2;
-            double u = er[0];
+            for (int c = 0; c < kPanel; c++) {
+                a0[c] = panel[r0 * kPanel + c];
+                a1[c] = has1 ? panel[r1 * kPanel + c] : 0.0;
+                l0[c] = 0.0; l1[c] = 0.0;
+            }
+            double ls[kPanel][kPanel];
+            int pr_c[kPanel];
+            bool sing = false;
 #pragma unroll
-            for (int sl = 1; sl < 24; sl++) u = (ps == sl) ? er[sl] : u;
-            prow_buf[tx] = u;
-            if (k >= 66) Urows[(k - 66) * kNC + tx] = u;
-            live &= ~(1u << ps);
+            for (int c = 0; c < kPanel; c++) {
+                pr_c[c] = 0;
+#pragma unroll
+                for (int c2 = 0; c2 < kPanel; c2++) ls[c][c2] = 0.0;
+                if (c < bw && !sing) {
+                    const int kk = k + c;
+                    const bool al0 = lp0 >= kk, al1 = has1 && lp1 >= kk;   // pivots sit at logical positions < kk
+                    const double v0 = al0 ? fabs(a0[c]) : -1.0, v1 = al1 ? fabs(a1[c]) : -1.0;
+                    double vm = v0 > 0.0 ? v0 : 0.0;                       // NaN never wins, as in the reference scan
+                    if (v1 > vm) vm = v1;
+                    const double best = wave_max_nonneg(vm);
+                    const bool w0 = al0 && v0 == best, w1 = al1 && v1 == best;
+                    const unsigned long long t0 = __ballot(w0), t1 = __ballot(w1);
+                    int olane, plog;
+                    bool ohalf;
+                    if (__popcll(t0) + __popcll(t1) == 1) {               // the usual case: one row attains the max
+                        ohalf = t0 == 0ull;
+                        olane = __builtin_ctzll(ohalf ? t1 : t0);
+                        plog = __builtin_amdgcn_readlane(ohalf ? lp1 : lp0, olane);
+                    } else {                                               // exact ties: smallest logical index among them
+                        plog = w0 ? lp0 : 0x7fffffff;
+                        if (w1 && lp1 < plog) plog = lp1;
+#pragma unroll
+                        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(plog, m, 64); plog = o < plog ? o : plog; }
+                        const unsigned long long o0 = __ballot(al0 && lp0 == plog), o1 = __ballot(al1 && lp1 == plog);
+                        ohalf = o0 == 0ull;
+                        olane = __builtin_ctzll(ohalf ? (o1 ? o1 : 1ull) : o0);
+                    }
+                    if (!(best > 0.0) || plog == 0x7fffffff) { sing = true; }
+                    else {
+                        pr_c[c] = olane + (ohalf ? 64 : 0);
+                        double urow[kPanel];
+#pragma unroll
+                        for (int c2 = 0; c2 < kPanel; c2++) {
+                            urow[c2] = lane_value_f64(ohalf ? a1[c2] : a0[c2], olane);
+                            ls[c][c2] = (c2 < c) ? lane_value_f64(ohalf ? l1[c2] : l0[c2], olane) : 0.0;
+                        }
+                        const double piv = urow[c];
+                        const bool is0 = !ohalf && lane == olane, is1 = ohalf && lane == olane;
+                        const double m0 = (al0 && !is0) ? a0[c] / piv : 0.0;
+                        const double m1 = (al1 && !is1) ? a1[c] / piv : 0.0;
+                        l0[c] = m0; l1[c] = m1;
+#pragma unroll
+                        for (int c2 = 0; c2 < kPanel; c2++)
+                            if (c2 > c) {
+                                const double n0 = a0[c2] - m0 * urow[c2], n1 = a1[c2] - m1 * urow[c2];
+                                a0[c2] = (m0 != 0.0) ? n0 : a0[c2];      // the reference skips l == 0
+                                a1[c2] = (m1 != 0.0) ? n1 : a1[c2];
+                            }
+                        // the reference swaps logical rows kk and plog
+                        lp0 = is0 ? kk : (lp0 == kk ? plog : lp0);
+                        lp1 = is1 ? kk : (lp1 == kk ? plog : lp1);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < kPanel; c++) {
+                Lp[r0 * kPanel + c] = l0[c];
+                if (has1) Lp[r1 * kPanel + c] = l1[c];
+            }
+            if (lane == 0) {
+                flag[0] = sing ? 1 : 0;
+#pragma unroll
+                for (int c = 0; c < kPanel; c++) {
+                    prow_s[c] = pr_c[c];
+#pragma unroll
+                    for (int c2 = 0; c2 < kPanel; c2++) Lsub[c * kPanel + c2] = ls[c][c2];
+                }
+            }
         }
         __syncthreads();
-        // -- S2: rank-1 update of the live rows (registers), next pivot column -> colbuf, logical swap bookkeeping
-        if (tid == 0) {   // the reference swaps logical rows k and plog
-            const int rk = physof[k];
-            physof[k] = prow; physof[plog] = rk;
-            logpos[rk] = plog; logpos[prow] = k;
-        }
-        {
-            // all 24 multipliers of this wave's row group in one batch of independent LDS reads (dead rows and the pivot
-            // row carry l = 0); `live` is wave-uniform (same ty across a wave), so dead slots are skipped by scalar branches
-            double lv[24];
+        if (flag[0]) { singular = true; break; }
+        // -- P3: owners of the pivot rows publish them (dynamic slot -> static select chain; wave-uniform branches)
 #pragma unroll
-            for (int sl = 0; sl < 24; sl++) lv[sl] = Lw[wave * 24 + sl];
-            const double ukj = prow_buf[tx < kNC ? tx : 0];
-            const bool upd = tx > k && tx < kNC;
-            // branch-free: dead rows and the pivot row have l == 0 and keep their value (the reference skips l == 0 too)
+        for (int c = 0; c < kPanel; c++) {
+            if (c < bw) {
+                const int prow = prow_s[c];
+                if ((prow & 3) == ty) {
+                    const int ps = prow >> 2;
+                    double u = er[0];
+#pragma unroll
+                    for (int sl = 1; sl < 24; sl++) u = (ps == sl) ? er[sl] : u;
+                    prow_raw[c * 128 + tx] = u;
+                    live &= ~(1u << ps);
+                }
+            }
+        }
+        __syncthreads();
+        // -- P4
+        {
+            double u[kPanel];
+#pragma unroll
+            for (int c = 0; c < kPanel; c++) {
+                double v = prow_raw[c * 128 + tx];
+#pragma unroll
+                for (int c2 = 0; c2 < kPanel; c2++)
+                    if (c2 < c) {
+                        const double l = Lsub[c * kPanel + c2];
+                        const double nv = v - l * u[c2];
+                        v = (l != 0.0 && tx > k + c2) ? nv : v;
+                    }
+                u[c] = v;
+                if (ty == 0 && tx < kNC && c < bw && k + c >= 66) Urows[(k + c - 66) * kNC + tx] = v;
+            }
 #pragma unroll
             for (int sl = 0; sl < 24; sl++) {
-                const double nv = er[sl] - lv[sl] * ukj;
-                er[sl] = (upd && lv[sl] != 0.0) ? nv : er[sl];
-            }
-            if (tx == k + 1) {   // next pivot column (dead rows are written too, nobody reads them)
+                if (live >> sl & 1u) {   // wave-uniform: rows already used as pivots are skipped by a scalar branch
+                    const double *lq = Lp + (ty + 4 * sl) * kPanel;
+                    double e = er[sl];
 #pragma unroll
-                for (int sl = 0; sl < 24; sl++) colbuf[ty + 4 * sl] = er[sl];
+                    for (int c = 0; c < kPanel; c++) {
+                        const double l = lq[c];
+                        const double nv = e - l * u[c];
+                        e = (c < bw && l != 0.0 && tx > k + c) ? nv : e;
+                    }
+                    er[sl] = e;
+                }
+            }
+            const int nc = tx - (k + kPanel);   // column of the next panel held by this thread
+            if (nc >= 0 && nc < kPanel) {
+#pragma unroll
+                for (int sl = 0; sl < 24; sl++) panel[(ty + 4 * sl) * kPanel + nc] = er[sl];
             }
         }
         __syncthreads();
@@ -434,14 +532,6 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
 // ------------------------------------------------------------------------------------------------ K5b + K6
 constexpr int EN = 27;
 
-// value of `v` in lane j (wave-uniform j): two v_readlane_b32, result in SGPRs
-__device__ __forceinline__ double lane_value_f64(double v, int j)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), j);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), j);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 
 struct EigArgs {
     PnpProblem prob[kPnpMaxBatch];
@@ -988,7 +1078,7 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
     }
     sa.H = H; sa.S = S; sa.tab = st->tab_dev;
     sa.Sg = st->Sg; sa.Tg = st->Tg; sa.sample = st->sample; sa.ok = st->ok;
-    const size_t lds = sizeof(double) * (kSampleMax * 8 + 9 + 9 + 27 + 27 + 81 + 90 + 100 + 36 + 60 + 4 + 27 * 27 + 8 * 24 + 128 + 96 + 27 * kNC) + sizeof(int) * (16 + 32 + 32 + 4 + 96 + 96) + sizeof(short) * (kNR * 20) + 64;
+    const size_t lds = kSolveLds;
     hipLaunchKernelGGL(pnp_build_solve, dim3(P * H), dim3(kSolveThreads), lds, s, sa);
     CHIP_HIP(c, hipGetLastError());
 
