@@ -65,12 +65,15 @@ constexpr int kJacobiSweeps = 8;
 
 __global__ __launch_bounds__(64) void icp_hyp_score(IcpArgs a)
 {
-    __shared__ int smp[kSampleMax], fy_key[2 * kSampleMax], fy_val[2 * kSampleMax];
+    __shared__ int smp[kSampleMax];
     __shared__ double sa[kSampleMax * 3], sb[kSampleMax * 3];
     const int lane = threadIdx.x;
     const int hyp = blockIdx.x;
     const int n = a.S;
-    if (lane == 0) ransac_sample_sparse(a.seed, hyp, a.N, n, fy_key, fy_val, smp);
+    {
+        const int sv = ransac_sample_wave(a.seed, hyp, a.N, n, lane);
+        if (lane < n) smp[lane] = sv;
+    }
     __syncthreads();
     if (lane < n) {
         const int s = smp[lane];

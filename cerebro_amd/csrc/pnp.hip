@@ -36,6 +36,7 @@ struct PnpTables {
     int8_t row_which[93];     // Macaulay row (non-reduced monomial) -> which cubic multiplies it
     int16_t row_dst[93][20];  // destination column in E = [D | C] of each of the 20 terms
     int16_t s_col[27][4];     // Macaulay column of m * {1, s1, s2, s3} for reduced monomial m
+    int8_t col_term[93][128]; // inverse of row_dst: which of the row's 20 terms lands in column c (-1: structural zero)
 };
 
 static int idx_le(int a, int b, int c, int d)
@@ -99,6 +100,10 @@ static void build_tables(PnpTables &t)
         for (int b = 0; b <= 2; b++)
             for (int c = 0; c <= 2; c++)
                 for (int s = 0; s < 4; s++) t.s_col[9 * a + 3 * b + c][s] = (int16_t)pos[a + SH[s][0]][b + SH[s][1]][c + SH[s][2]];
+    for (int r = 0; r < 93; r++) {
+        for (int c = 0; c < 128; c++) t.col_term[r][c] = -1;
+        for (int term = 0; term < 20; term++) t.col_term[r][t.row_dst[r][term]] = (int8_t)term;   // a later term overwrites, as the fill did
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ device helpers
@@ -161,12 +166,12 @@ struct SolveArgs {
     int32_t *ok;        // [H] 1 = S valid, 0 = singular D
 };
 
-constexpr int kSolveThreads = 512;
+constexpr int kSolveThreads = 448;   // waves 0..5 hold the Macaulay block (3 row groups x 128 columns), wave 6 factorises panels
 constexpr int kPanel = 4;   // pivot columns factorised per panel of the blocked LU
 // dynamic LDS of pnp_build_solve (must match the carve-up at the top of the kernel)
 constexpr size_t kSolveLds = sizeof(double) * (kSampleMax * 8 + 9 + 9 + 27 + 27 + 81 + 90 + 100 + 36 + 60 + 4 + 27 * 27 +
-                                               96 * kPanel * 2 + kPanel * 128 + kPanel * kPanel + 27 * kNC) +
-                             sizeof(int) * (16 + 32 + 32 + 4 + kPanel) + sizeof(short) * (kNR * 20) + 64;
+                                               2 * 96 * kPanel * 2 + kPanel * 128 + 2 * kPanel * kPanel + 27 * kNC) +
+                             sizeof(int) * (16 + 32 + 32 + 4 + 2 * kPanel) + 64;
 
 __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
 {
@@ -186,17 +191,16 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     double *fc = sm;            sm += 60;                         // f[3][20]
     double *uu = sm;            sm += 4;
     double *Xb = sm;            sm += 27 * 27;                    // X[66+t][c]
-    double *panel = sm;         sm += 96 * kPanel;                // the kPanel pivot columns of the current panel, [physical row][c]
-    double *Lp = sm;            sm += 96 * kPanel;                // multipliers of the current panel, [physical row][c]
+    double *panel = sm;         sm += 2 * 96 * kPanel;            // [parity][physical row][c]: pivot columns of panels p, p+1
+    double *Lp = sm;            sm += 2 * 96 * kPanel;            // [parity][physical row][c]: multipliers of a panel
     double *prow_raw = sm;      sm += kPanel * 128;               // the panel's pivot rows as they were before the panel, [c][column]
-    double *Lsub = sm;          sm += kPanel * kPanel;            // multipliers among the panel's pivot rows, [c][c' < c]
+    double *Lsub = sm;          sm += 2 * kPanel * kPanel;        // [parity][c][c' < c]: multipliers among a panel's pivot rows
     double *Urows = sm;         sm += 27 * kNC;                   // pivot rows of steps 66..92 = rows of U needed by the back-substitution
     int *smp = reinterpret_cast<int *>(sm);                       // [16]
     int *fy_key = smp + 16;                                        // sparse Fisher-Yates map (<= 32 entries)
     int *fy_val = fy_key + 32;
     int *flag = fy_val + 32;                                       // [4] : singular, spare
-    int *prow_s = flag + 4;                                        // [kPanel] physical pivot rows of the current panel
-    short *rdst = reinterpret_cast<short *>(prow_s + kPanel);      // [93][20] LDS copy of the Macaulay destination table
+    int *prow_s = flag + 4;                                        // [parity][kPanel] physical pivot rows of a panel
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -209,14 +213,15 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     const PnpTables &tb = *a.tab;
 
     // ---- sampler: partial Fisher-Yates over a virtual identity permutation (theia::RandomSampler restated) ----
-    if (tid == 0) {
-        ransac_sample_sparse(pr.seed, hyp, pr.N, n, fy_key, fy_val, smp);
-        for (int j = 0; j < 4; j++) {   // random linear form f0 (Theia: 100 * Vector4d::Random())
-            const uint64_t x = rng_draw(pr.seed, (uint32_t)hyp, (uint32_t)(64 + j));
+    if (wave == 0) {
+        const int sv = ransac_sample_wave(pr.seed, hyp, pr.N, n, lane);
+        if (lane < n) smp[lane] = sv;
+        if (lane < 4) {   // random linear form f0 (Theia: 100 * Vector4d::Random())
+            const uint64_t x = rng_draw(pr.seed, (uint32_t)hyp, (uint32_t)(64 + lane));
             const double f = (double)(x >> 11) * (1.0 / 9007199254740992.0);
-            uu[j] = 100.0 * (2.0 * f - 1.0);
+            uu[lane] = 100.0 * (2.0 * f - 1.0);
         }
-        flag[0] = 0;
+        if (lane == 0) flag[0] = 0;
     }
     __syncthreads();
     if (tid < n) {
@@ -318,151 +323,178 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
         const int k = tid / 20, mth = tid % 20;
         fc[tid] = (double)tb.fmul[k][mth] * c4[tb.fsrc[k][mth]];
     }
-    // ---- Macaulay [D | C] (93 x 120) lives in REGISTERS: thread (tx = column, ty) holds rows ty, ty+4, ..., ty+92 of its
-    //      column in er[0..23] (static slot indices); only column k, the pivot row and the multipliers cross LDS. ----
-    const int tx = tid & 127, ty = tid >> 7;
-    for (int e = tid; e < kNR * 20; e += kSolveThreads) rdst[e] = tb.row_dst[e / 20][e % 20];
     __syncthreads();
-    double er[24];
-    unsigned live = 0;   // bit s set <=> physical row ty + 4*s exists and has not been used as a pivot yet
+    // ---- Macaulay [D | C] (93 x 120) lives in REGISTERS of waves 0..5: thread (tx = column, ty = row group) holds rows
+    //      ty, ty+3, ..., ty+90 of its column in er[0..30] (static slot indices); wave 6 never touches it. ----
+    const int tx = tid & 127, ty = tid >> 7;          // ty == 3 <=> the factor wave
+    const bool is_factor = wave == 6;
+    double er[31];
+    unsigned live = 0;   // bit s set <=> physical row ty + 3*s has not been used as a pivot yet (wave-uniform)
+    if (!is_factor) {
+        // row r of the Macaulay block = cubic `row_which[r]` times a monomial: its 20 coefficients land in the columns listed
+        // by row_dst; col_term is the inverse map, so each thread fetches "its" term of each of its rows directly
+        signed char term[31];
 #pragma unroll
-    for (int sl = 0; sl < 24; sl++) {
-        const int row = ty + 4 * sl;
-        double v = 0.0;
-        if (row < kNR) {
+        for (int sl = 0; sl < 31; sl++) term[sl] = tb.col_term[ty + 3 * sl][tx];
+#pragma unroll
+        for (int sl = 0; sl < 31; sl++) {
+            const int row = ty + 3 * sl;
             live |= 1u << sl;
-            const int which = tb.row_which[row];
-            for (int term = 0; term < 20; term++)
-                if (rdst[row * 20 + term] == tx) v = fc[20 * which + term];
+            er[sl] = term[sl] >= 0 ? fc[20 * tb.row_which[row] + term[sl]] : 0.0;
         }
-        er[sl] = v;
-    }
-    // columns 0..kPanel-1 -> panel
-    if (tx < kPanel) {
+        if (tx < 2 * kPanel) {   // columns of panels 0 and 1 -> panel[0], panel[1]
+            double *dst = panel + (tx / kPanel) * 96 * kPanel + (tx % kPanel);
 #pragma unroll
-        for (int sl = 0; sl < 24; sl++) panel[(ty + 4 * sl) * kPanel + tx] = er[sl];
+            for (int sl = 0; sl < 31; sl++) dst[(ty + 3 * sl) * kPanel] = er[sl];
+        }
+    } else {
+#pragma unroll
+        for (int sl = 0; sl < 31; sl++) er[sl] = 0.0;
     }
     if (tid == 0) flag[0] = 0;
     __syncthreads();
 
-    // ---- Blocked right-looking LU with partial (row) pivoting, no physical swaps.  Per panel of kPanel pivot columns:
-    //   P2  wave 0 factorises the panel alone (2 physical rows per lane, everything in registers / DPP / readlane): pivot =
-    //       max |column| over the rows not yet used, ties -> smallest LOGICAL index (lp0/lp1 track where the reference's row
-    //       swaps would have put every row), multipliers, update of the remaining panel columns;
-    //   P3  the owners of the kPanel pivot rows publish them as they were before the panel;
-    //   P4  every thread rebuilds the pivot rows' values for its column (triangular solve with the multipliers among the
-    //       pivot rows), applies the kPanel rank-1 updates to its 24 register-resident rows ONE AFTER THE OTHER (so every
-    //       element sees exactly the operation sequence of the unblocked elimination), and the owners of the next kPanel
-    //       columns refill the panel.
-    //   3 barriers per kPanel columns instead of 2 per column, and one pivot search latency chain per panel. ----
+    // ---- Blocked right-looking LU with partial (row) pivoting, no physical swaps, with LOOKAHEAD: the panel of kPanel pivot
+    //      columns is factorised by a wave of its own (wave 6, two physical rows per lane, registers / DPP / readlane only)
+    //      while waves 0..5 apply the previous panel to the trailing matrix.  Per panel p:
+    //   P3  (waves 0..5) the owners of panel p's pivot rows publish them as they were before the panel;   -- barrier --
+    //   P4  (waves 0..5) every thread rebuilds the pivot rows' values for its column (triangular solve with the multipliers
+    //       among the pivot rows), applies the kPanel rank-1 updates to its 31 register-resident rows ONE AFTER THE OTHER (so
+    //       every element sees exactly the operation sequence of the unblocked elimination), and the owners of panel p+2's
+    //       columns dump them;
+    //   F   (wave 6, concurrently with P4) brings its copy of panel p+1's columns up to date with panel p (same operations),
+    //       then factorises it: pivot = max |column| over the rows not yet used, ties -> smallest LOGICAL index (lp0/lp1 track
+    //       where the reference's row swaps would have put every row), multipliers by IEEE division, remaining panel
+    //       columns updated; publishes multipliers / pivot rows / sub-multipliers of panel p+1.                -- barrier --
+    //   The critical path is F's chain (one pivot-search latency chain per column); the trailing update hides behind it. ----
     bool singular = false;
-    int lp0 = lane, lp1 = lane + 64;   // wave 0: logical position of physical rows lane, lane + 64
-    for (int k = 0; k < kNR; k += kPanel) {
-        const int bw = (kNR - k) < kPanel ? (kNR - k) : kPanel;
-        if (wave == 0) {
-            const int r0 = lane, r1 = lane + 64;
-            const bool has1 = r1 < kNR;
-            double a0[kPanel], a1[kPanel], l0[kPanel], l1[kPanel];
+    constexpr int kPanels = (kNR + kPanel - 1) / kPanel;
+    // factor-wave state.  The factor wave does not hold matrix rows, so its panel lives in the (otherwise idle) er[] registers
+    // -- the kernel's register budget is set by the matrix waves, and two workgroups per CU need <= 128 VGPRs:
+    //   A0(c)/A1(c): panel entries of physical rows lane / lane+64;  L0(c)/L1(c): their multipliers;
+    //   LS(c,c2), c2 < c: multipliers among the panel's pivot rows;  B0/B1: the next panel while it is brought up to date
+#define A0(c) er[(c)]
+#define A1(c) er[4 + (c)]
+#define L0(c) er[8 + (c)]
+#define L1(c) er[12 + (c)]
+#define LS(c, c2) er[16 + ((c) * ((c) - 1)) / 2 + (c2)]
+#define B0(c) er[22 + (c)]
+#define B1(c) er[26 + (c)]
+    int lp0 = lane, lp1 = lane + 64;   // logical position of physical rows lane, lane + 64
+    const bool has1 = lane + 64 < kNR;
+
+    // factorise the panel held in a0/a1 (columns k .. k+bw-1), publish into parity set `par`
+    auto factor_panel = [&](int k, int bw, int par) {
+        int pr_c[kPanel];
+        bool sing = false;
 #pragma unroll
-            for (int c = 0; c < kPanel; c++) {
-                a0[c] = panel[r0 * kPanel + c];
-                a1[c] = has1 ? panel[r1 * kPanel + c] : 0.0;
-                l0[c] = 0.0; l1[c] = 0.0;
-            }
-            double ls[kPanel][kPanel];
-            int pr_c[kPanel];
-            bool sing = false;
-#pragma unroll
-            for (int c = 0; c < kPanel; c++) {
-                pr_c[c] = 0;
-#pragma unroll
-                for (int c2 = 0; c2 < kPanel; c2++) ls[c][c2] = 0.0;
-                if (c < bw && !sing) {
-                    const int kk = k + c;
-                    const bool al0 = lp0 >= kk, al1 = has1 && lp1 >= kk;   // pivots sit at logical positions < kk
-                    const double v0 = al0 ? fabs(a0[c]) : -1.0, v1 = al1 ? fabs(a1[c]) : -1.0;
-                    double vm = v0 > 0.0 ? v0 : 0.0;                       // NaN never wins, as in the reference scan
-                    if (v1 > vm) vm = v1;
-                    const double best = wave_max_nonneg(vm);
-                    const bool w0 = al0 && v0 == best, w1 = al1 && v1 == best;
-                    const unsigned long long t0 = __ballot(w0), t1 = __ballot(w1);
-                    int olane, plog;
-                    bool ohalf;
-                    if (__popcll(t0) + __popcll(t1) == 1) {               // the usual case: one row attains the max
-                        ohalf = t0 == 0ull;
-                        olane = __builtin_ctzll(ohalf ? t1 : t0);
-                        plog = __builtin_amdgcn_readlane(ohalf ? lp1 : lp0, olane);
-                    } else {                                               // exact ties: smallest logical index among them
-                        plog = w0 ? lp0 : 0x7fffffff;
-                        if (w1 && lp1 < plog) plog = lp1;
-#pragma unroll
-                        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(plog, m, 64); plog = o < plog ? o : plog; }
-                        const unsigned long long o0 = __ballot(al0 && lp0 == plog), o1 = __ballot(al1 && lp1 == plog);
-                        ohalf = o0 == 0ull;
-                        olane = __builtin_ctzll(ohalf ? (o1 ? o1 : 1ull) : o0);
-                    }
-                    if (!(best > 0.0) || plog == 0x7fffffff) { sing = true; }
-                    else {
-                        pr_c[c] = olane + (ohalf ? 64 : 0);
-                        double urow[kPanel];
-#pragma unroll
-                        for (int c2 = 0; c2 < kPanel; c2++) {
-                            urow[c2] = lane_value_f64(ohalf ? a1[c2] : a0[c2], olane);
-                            ls[c][c2] = (c2 < c) ? lane_value_f64(ohalf ? l1[c2] : l0[c2], olane) : 0.0;
-                        }
-                        const double piv = urow[c];
-                        const bool is0 = !ohalf && lane == olane, is1 = ohalf && lane == olane;
-                        const double m0 = (al0 && !is0) ? a0[c] / piv : 0.0;
-                        const double m1 = (al1 && !is1) ? a1[c] / piv : 0.0;
-                        l0[c] = m0; l1[c] = m1;
-#pragma unroll
-                        for (int c2 = 0; c2 < kPanel; c2++)
-                            if (c2 > c) {
-                                const double n0 = a0[c2] - m0 * urow[c2], n1 = a1[c2] - m1 * urow[c2];
-                                a0[c2] = (m0 != 0.0) ? n0 : a0[c2];      // the reference skips l == 0
-                                a1[c2] = (m1 != 0.0) ? n1 : a1[c2];
-                            }
-                        // the reference swaps logical rows kk and plog
-                        lp0 = is0 ? kk : (lp0 == kk ? plog : lp0);
-                        lp1 = is1 ? kk : (lp1 == kk ? plog : lp1);
-                    }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < kPanel; c++) {
-                Lp[r0 * kPanel + c] = l0[c];
-                if (has1) Lp[r1 * kPanel + c] = l1[c];
-            }
-            if (lane == 0) {
-                flag[0] = sing ? 1 : 0;
-#pragma unroll
-                for (int c = 0; c < kPanel; c++) {
-                    prow_s[c] = pr_c[c];
-#pragma unroll
-                    for (int c2 = 0; c2 < kPanel; c2++) Lsub[c * kPanel + c2] = ls[c][c2];
-                }
-            }
-        }
-        __syncthreads();
-        if (flag[0]) { singular = true; break; }
-        // -- P3: owners of the pivot rows publish them (dynamic slot -> static select chain; wave-uniform branches)
+        for (int c = 0; c < kPanel; c++) { L0(c) = 0.0; L1(c) = 0.0; }
 #pragma unroll
         for (int c = 0; c < kPanel; c++) {
-            if (c < bw) {
-                const int prow = prow_s[c];
-                if ((prow & 3) == ty) {
-                    const int ps = prow >> 2;
-                    double u = er[0];
+            pr_c[c] = 0;
+            if (c < bw && !sing) {
+                const int kk = k + c;
+                const bool al0 = lp0 >= kk, al1 = has1 && lp1 >= kk;   // pivots sit at logical positions < kk
+                const double v0 = al0 ? fabs(A0(c)) : -1.0, v1 = al1 ? fabs(A1(c)) : -1.0;
+                double vm = v0 > 0.0 ? v0 : 0.0;                       // NaN never wins, as in the reference scan
+                if (v1 > vm) vm = v1;
+                const double best = wave_max_nonneg(vm);
+                const bool w0 = al0 && v0 == best, w1 = al1 && v1 == best;
+                const unsigned long long t0 = __ballot(w0), t1 = __ballot(w1);
+                int olane, plog;
+                bool ohalf;
+                if (__popcll(t0) + __popcll(t1) == 1) {               // the usual case: one row attains the max
+                    ohalf = t0 == 0ull;
+                    olane = __builtin_ctzll(ohalf ? t1 : t0);
+                    plog = __builtin_amdgcn_readlane(ohalf ? lp1 : lp0, olane);
+                } else {                                               // exact ties: smallest logical index among them
+                    plog = w0 ? lp0 : 0x7fffffff;
+                    if (w1 && lp1 < plog) plog = lp1;
 #pragma unroll
-                    for (int sl = 1; sl < 24; sl++) u = (ps == sl) ? er[sl] : u;
-                    prow_raw[c * 128 + tx] = u;
-                    live &= ~(1u << ps);
+                    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(plog, m, 64); plog = o < plog ? o : plog; }
+                    const unsigned long long o0 = __ballot(al0 && lp0 == plog), o1 = __ballot(al1 && lp1 == plog);
+                    ohalf = o0 == 0ull;
+                    olane = __builtin_ctzll(ohalf ? (o1 ? o1 : 1ull) : o0);
+                }
+                if (!(best > 0.0) || plog == 0x7fffffff) { sing = true; }
+                else {
+                    pr_c[c] = olane + (ohalf ? 64 : 0);
+                    double urow[kPanel];
+#pragma unroll
+                    for (int c2 = 0; c2 < kPanel; c2++) {
+                        urow[c2] = lane_value_f64(ohalf ? A1(c2) : A0(c2), olane);
+                        if (c2 < c) LS(c, c2) = lane_value_f64(ohalf ? L1(c2) : L0(c2), olane);
+                    }
+                    const double piv = urow[c];
+                    const bool is0 = !ohalf && lane == olane, is1 = ohalf && lane == olane;
+                    const double m0 = (al0 && !is0) ? A0(c) / piv : 0.0;
+                    const double m1 = (al1 && !is1) ? A1(c) / piv : 0.0;
+                    L0(c) = m0; L1(c) = m1;
+#pragma unroll
+                    for (int c2 = 0; c2 < kPanel; c2++)
+                        if (c2 > c) {
+                            const double n0 = A0(c2) - m0 * urow[c2], n1 = A1(c2) - m1 * urow[c2];
+                            A0(c2) = (m0 != 0.0) ? n0 : A0(c2);      // the reference skips l == 0
+                            A1(c2) = (m1 != 0.0) ? n1 : A1(c2);
+                        }
+                    // the reference swaps logical rows kk and plog
+                    lp0 = is0 ? kk : (lp0 == kk ? plog : lp0);
+                    lp1 = is1 ? kk : (lp1 == kk ? plog : lp1);
+                }
+            }
+        }
+        double *Lpp = Lp + par * 96 * kPanel;
+#pragma unroll
+        for (int c = 0; c < kPanel; c++) {
+            Lpp[lane * kPanel + c] = L0(c);
+            if (has1) Lpp[(lane + 64) * kPanel + c] = L1(c);
+        }
+        if (lane == 0) {
+            if (sing) flag[0] = 1;
+#pragma unroll
+            for (int c = 0; c < kPanel; c++) {
+                prow_s[par * kPanel + c] = pr_c[c];
+#pragma unroll
+                for (int c2 = 0; c2 < kPanel; c2++) Lsub[par * kPanel * kPanel + c * kPanel + c2] = (c2 < c && c < bw) ? LS(c, c2) : 0.0;
+            }
+        }
+    };
+    auto load_panel = [&](int par) {
+        const double *pp = panel + par * 96 * kPanel;
+#pragma unroll
+        for (int c = 0; c < kPanel; c++) {
+            A0(c) = pp[lane * kPanel + c];
+            A1(c) = has1 ? pp[(lane + 64) * kPanel + c] : 0.0;
+        }
+    };
+
+    if (is_factor) { load_panel(0); factor_panel(0, kPanel, 0); }
+    __syncthreads();
+    for (int p = 0; p < kPanels; p++) {
+        const int k = p * kPanel, par = p & 1;
+        const int bw = (kNR - k) < kPanel ? (kNR - k) : kPanel;
+        if (flag[0]) { singular = true; break; }
+        // -- P3: owners of the pivot rows publish them (dynamic slot -> static select chain; wave-uniform branches)
+        if (!is_factor) {
+#pragma unroll
+            for (int c = 0; c < kPanel; c++) {
+                if (c < bw) {
+                    const int prow = prow_s[par * kPanel + c];
+                    if (prow % 3 == ty) {
+                        const int ps = prow / 3;
+                        double u = er[0];
+#pragma unroll
+                        for (int sl = 1; sl < 31; sl++) u = (ps == sl) ? er[sl] : u;
+                        prow_raw[c * 128 + tx] = u;
+                        live &= ~(1u << ps);
+                    }
                 }
             }
         }
         __syncthreads();
-        // -- P4
-        {
+        if (!is_factor) {
+            // -- P4
+            const double *Lss = Lsub + par * kPanel * kPanel;
             double u[kPanel];
 #pragma unroll
             for (int c = 0; c < kPanel; c++) {
@@ -470,17 +502,18 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
 #pragma unroll
                 for (int c2 = 0; c2 < kPanel; c2++)
                     if (c2 < c) {
-                        const double l = Lsub[c * kPanel + c2];
+                        const double l = Lss[c * kPanel + c2];
                         const double nv = v - l * u[c2];
                         v = (l != 0.0 && tx > k + c2) ? nv : v;
                     }
                 u[c] = v;
                 if (ty == 0 && tx < kNC && c < bw && k + c >= 66) Urows[(k + c - 66) * kNC + tx] = v;
             }
+            const double *Lpp = Lp + par * 96 * kPanel;
 #pragma unroll
-            for (int sl = 0; sl < 24; sl++) {
+            for (int sl = 0; sl < 31; sl++) {
                 if (live >> sl & 1u) {   // wave-uniform: rows already used as pivots are skipped by a scalar branch
-                    const double *lq = Lp + (ty + 4 * sl) * kPanel;
+                    const double *lq = Lpp + (ty + 3 * sl) * kPanel;
                     double e = er[sl];
 #pragma unroll
                     for (int c = 0; c < kPanel; c++) {
@@ -491,11 +524,45 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
                     er[sl] = e;
                 }
             }
-            const int nc = tx - (k + kPanel);   // column of the next panel held by this thread
+            const int nc = tx - (k + 2 * kPanel);   // column of panel p+2 held by this thread -> panel[par]
             if (nc >= 0 && nc < kPanel) {
+                double *dst = panel + par * 96 * kPanel + nc;
 #pragma unroll
-                for (int sl = 0; sl < 24; sl++) panel[(ty + 4 * sl) * kPanel + nc] = er[sl];
+                for (int sl = 0; sl < 31; sl++) dst[(ty + 3 * sl) * kPanel] = er[sl];
             }
+        } else if (p + 1 < kPanels) {
+            // -- F: panel p+1 (dumped before panel p was applied) -> apply panel p -> factorise
+            const int kn = k + kPanel;
+            const int bwn = (kNR - kn) < kPanel ? (kNR - kn) : kPanel;
+            const double *pp = panel + (par ^ 1) * 96 * kPanel;
+#pragma unroll
+            for (int c2 = 0; c2 < kPanel; c2++) {
+                // un[c]: pivot row c of panel p at column kn + c2, after the updates inside panel p (column > every step index)
+                double un[kPanel];
+#pragma unroll
+                for (int c = 0; c < kPanel; c++) {
+                    double v = prow_raw[c * 128 + kn + c2];
+#pragma unroll
+                    for (int c3 = 0; c3 < kPanel; c3++)
+                        if (c3 < c) {
+                            const double nv = v - LS(c, c3) * un[c3];
+                            v = (c < bw && LS(c, c3) != 0.0) ? nv : v;
+                        }
+                    un[c] = v;
+                }
+                double e0 = pp[lane * kPanel + c2];
+                double e1 = has1 ? pp[(lane + 64) * kPanel + c2] : 0.0;
+#pragma unroll
+                for (int c = 0; c < kPanel; c++) {
+                    const double n0 = e0 - L0(c) * un[c], n1 = e1 - L1(c) * un[c];
+                    e0 = (c < bw && L0(c) != 0.0) ? n0 : e0;
+                    e1 = (c < bw && L1(c) != 0.0) ? n1 : e1;
+                }
+                B0(c2) = e0; B1(c2) = e1;
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < kPanel; c2++) { A0(c2) = B0(c2); A1(c2) = B1(c2); }
+            factor_panel(kn, bwn, par ^ 1);
         }
         __syncthreads();
     }

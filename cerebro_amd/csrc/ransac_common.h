@@ -45,6 +45,34 @@ __device__ __forceinline__ void ransac_sample_sparse(uint64_t seed, int hyp, int
     }
 }
 
+// The same sampler executed by a WHOLE WAVE (identical draws, identical result): the S draws and their 64-bit modulo are
+// computed by lanes 0..S-1 at once, and the sparse permutation map lives in registers (lane e holds entry e) so that every
+// lookup is a __ballot + v_readlane instead of a serial scan of LDS.  Returns sample i in lane i (< S).
+__device__ __forceinline__ int ransac_sample_wave(uint64_t seed, int hyp, int N, int S, int lane)
+{
+    int jv = 0;
+    if (lane < S) {
+        const uint64_t x = rng_draw(seed, (uint32_t)hyp, (uint32_t)lane);
+        jv = lane + (int)(x % (uint64_t)(N - lane));
+    }
+    int key = -1, val = 0, used = 0, mine = 0;
+    for (int i = 0; i < S; i++) {
+        const int j = __builtin_amdgcn_readlane(jv, i);
+        const unsigned long long mi = __ballot(lane < used && key == i), mj = __ballot(lane < used && key == j);
+        int vi = i, vj = j, pi = -1, pj = -1;
+        if (mi) { pi = __builtin_ctzll(mi); vi = __builtin_amdgcn_readlane(val, pi); }
+        if (mj) { pj = __builtin_ctzll(mj); vj = __builtin_amdgcn_readlane(val, pj); }
+        if (pi < 0) { pi = used++; if (lane == pi) key = i; }   // idx[i] <- vj ; idx[j] <- vi
+        if (lane == pi) val = vj;
+        if (j != i) {
+            if (pj < 0) { pj = used++; if (lane == pj) key = j; }
+            if (lane == pj) val = vi;
+        }
+        if (lane == i) mine = vj;
+    }
+    return mine;
+}
+
 // theia::SampleConsensusEstimator::ComputeMaxIterations
 inline int32_t ransac_max_iterations(int32_t S, double ratio, double log_fail, int32_t min_it, int32_t max_it)
 {
