@@ -169,6 +169,18 @@ def pnp_leg(chip, cpu_budget_s: float):
                 break
         out["cpu_baseline"] = {"value": n * 1000 / d, "unit": "hypotheses/s", "cores": 1, "kind": "port",
                                "sample": f"{n} oracle calls of 1000 hypotheses ({d:.1f} s), single thread"}
+        nt = usable_cpus()
+        prm = oracle_lib.ransac_params(n_hypotheses=1000, seed=4242)
+        t4 = time.perf_counter()
+        m = 0
+        while True:
+            best, _ = oracle_lib.pnp_hypotheses_mt(X, uv, prm, 4000, nt)
+            m += 1
+            d4 = time.perf_counter() - t4
+            if d4 > cpu_budget_s or m >= 10:
+                break
+        out["cpu_baseline_all_cores"] = {"value": m * 4000 / d4, "unit": "hypotheses/s", "cores": nt, "kind": "port",
+                                         "sample": f"{m} x 4000 oracle hypotheses, OpenMP over hypotheses ({d4:.1f} s)"}
     return out
 
 

@@ -138,6 +138,10 @@ int32_t orc_ransac_max_iterations(int32_t S, double ratio, double log_fail, int3
 int    orc_pnp_ransac(const double *X, const double *uv, int32_t N, const orc_ransac_params *p,
                       double T[16], float *confidence, uint8_t *mask, orc_ransac_summary *summary);
 
+/* Benchmark-mode hypotheses on `nthreads` threads (OpenMP over hypotheses); returns the winning hypothesis index. */
+int32_t orc_pnp_hypotheses_mt(const double *X, const double *uv, int32_t N, const orc_ransac_params *p, int32_t H, int32_t nthreads,
+                              int32_t *n_models_out);
+
 /* ================================================================== Umeyama-ICP / RANSAC (icp_ransac.c) */
 int    orc_umeyama(const double *a, const double *b, int32_t n, double R[9], double t[3], double *scale);
 double orc_icp_error(const double *T_colmajor, const double *a, const double *b);

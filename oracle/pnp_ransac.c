@@ -730,3 +730,33 @@ int orc_pnp_ransac(const double *X, const double *uv, int32_t N, const orc_ransa
     }
     return 0;
 }
+
+/* Benchmark-mode throughput of the same hypotheses on `nthreads` host threads (OpenMP over the independent hypotheses):
+ * bench.py's all-cores CPU figure for the PnP leg (SURVEY.md 8d "RANSAC CPU: oracle, single thread and all cores over
+ * hypotheses").  Returns the index of the first hypothesis with the smallest cost (the benchmark-mode winner), so the
+ * caller can check it against orc_pnp_ransac. */
+int32_t orc_pnp_hypotheses_mt(const double *X, const double *uv, int32_t N, const orc_ransac_params *p, int32_t H, int32_t nthreads,
+                              int32_t *n_models_out)
+{
+    double *cost = (double *)malloc(sizeof(double) * (size_t)H);
+    if (!cost) return -1;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+    for (int32_t h = 0; h < H; h++) {
+        double Th[16], c;
+        int32_t nin;
+        cost[h] = INFINITY;
+        if (!orc_pnp_hypothesis(X, uv, N, p->seed, h, p->sample_size, Th, NULL)) continue;
+        orc_score_model(Th, X, uv, N, p->error_thresh, p->use_mle, &c, &nin, NULL);
+        cost[h] = c;
+    }
+    int32_t best = -1, nm = 0;
+    double bc = DBL_MAX;
+    for (int32_t h = 0; h < H; h++) {
+        if (cost[h] != INFINITY) nm++;
+        if (cost[h] < bc) { bc = cost[h]; best = h; }
+    }
+    if (n_models_out) *n_models_out = nm;
+    free(cost);
+    return best;
+}

@@ -299,6 +299,16 @@ def pnp_ransac(X, uv, params: OrcRansacParams | None = None):
                              n_models=s.n_models, best_cost=s.best_cost))
 
 
+def pnp_hypotheses_mt(X, uv, params: OrcRansacParams, H: int, nthreads: int):
+    """Benchmark-mode hypotheses 0..H-1 on `nthreads` host threads; returns (winning hypothesis, number of models)."""
+    lib = _bind_pnp()
+    X = np.ascontiguousarray(X, dtype=np.float64); uv = np.ascontiguousarray(uv, dtype=np.float64)
+    nm = C.c_int32()
+    lib.orc_pnp_hypotheses_mt.restype = C.c_int32
+    best = lib.orc_pnp_hypotheses_mt(_p(X), _p(uv), C.c_int32(X.shape[0]), C.byref(params), C.c_int32(H), C.c_int32(nthreads), C.byref(nm))
+    return int(best), int(nm.value)
+
+
 # ================================================================== Umeyama-ICP oracle bindings
 def _bind_icp():
     lib = _bind_pnp()

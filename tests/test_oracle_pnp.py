@@ -209,3 +209,13 @@ def test_golden_fixture_pnp():
         assert r["summary"]["n_models"] == case["n_models"]
         assert np.packbits(r["mask"]).tobytes().hex() == case["mask_hex"]
         assert [float(x).hex() for x in r["T"].T.reshape(16)] == case["T_colmajor_hex"]
+
+
+def test_all_cores_hypothesis_loop_equals_serial_driver():
+    """bench.py's all-cores PnP baseline (OpenMP over hypotheses) selects the same benchmark-mode winner and counts the same
+    number of models as the serial orc_pnp_ransac."""
+    X, uv, T, inl = M.make_scene(N=128, outlier_frac=0.3, noise_px=0.5, seed=11)
+    prm = O.ransac_params(n_hypotheses=120, seed=5)
+    r = O.pnp_ransac(X, uv, prm)
+    best, nm = O.pnp_hypotheses_mt(X, uv, prm, 120, 4)
+    assert best == r["summary"]["best_hypothesis"] and nm == r["summary"]["n_models"]
