@@ -33,7 +33,9 @@ def main(tag: str, src: str = "gpurun_out/prof"):
                 scan_avg_us = a
                 g = con.execute("select grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count, scratch_size from kernels where name=? limit 1", (n,)).fetchone()
                 geom = dict(grid_x=g[0], workgroup_x=g[1], lds_size=g[2], vgpr_count=g[3], sgpr_count=g[4], scratch_size=g[5])
-        lines.append("")
+        lines += ["", "Note on `topk_merge`: its rocprofv3 duration includes the time its dispatch packet spends blocked on the scan-finished",
+                  "event (the host enqueues tick i's merge while scan i is still running; the packet is picked up at once and waits), so",
+                  "avg/max are about one scan long while min is the kernel itself. It runs on the ctx stream, overlapped with the next scan.", ""]
     pmc = {}
     for db in sorted(glob.glob(str(src / "pmc*" / "*_results.db"))):
         con = sqlite3.connect(db)
