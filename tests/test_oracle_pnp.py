@@ -219,3 +219,61 @@ def test_all_cores_hypothesis_loop_equals_serial_driver():
     r = O.pnp_ransac(X, uv, prm)
     best, nm = O.pnp_hypotheses_mt(X, uv, prm, 120, 4)
     assert best == r["summary"]["best_hypothesis"] and nm == r["summary"]["n_models"]
+
+
+def _dls_cost(R, X, uv):
+    """Hesch & Roumeliotis' objective for a rotation R with the translation eliminated in closed form:
+    J(R) = sum_i || (I - z_i z_i^T) (R X_i + t*(R)) ||^2, z_i = unit bearing of uv_i."""
+    z = np.column_stack([uv, np.ones(len(uv))]); z /= np.linalg.norm(z, axis=1, keepdims=True)
+    P = np.eye(3)[None] - z[:, :, None] * z[:, None, :]                     # (n,3,3) projectors orthogonal to the bearings
+    RX = X @ R.T
+    t = -np.linalg.solve(P.sum(0), np.einsum("nij,nj->i", P, RX))
+    r = np.einsum("nij,nj->ni", P, RX + t)
+    return float((r * r).sum()), t
+
+
+def _rotvec(w):
+    th = np.linalg.norm(w)
+    if th == 0:
+        return np.eye(3)
+    k = w / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def _cayley_R(s):
+    """R(s) = ((1 - s.s) I + 2 [s]x + 2 s s^T) / (1 + s.s)  (Hesch & Roumeliotis eq. 9)"""
+    K = np.array([[0, -s[2], s[1]], [s[2], 0, -s[0]], [-s[1], s[0], 0]])
+    return ((1 - s @ s) * np.eye(3) + 2 * K + 2 * np.outer(s, s)) / (1 + s @ s)
+
+
+def _cayley_s(R):
+    """inverse of _cayley_R (rotation angle != pi): s = axis * tan(angle/2), read off the skew part: R - R^T = 4 [s]x / (1 + s.s)"""
+    w = 0.5 * np.sqrt(max(1e-300, 1.0 + np.trace(R)))          # quaternion scalar part = cos(angle/2)
+    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]) / (4.0 * w)
+    return v / w
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_dls_solutions_are_stationary_points_of_the_least_squares_cost(seed):
+    """Independent of any implementation detail: what the Macaulay/eigen machinery solves on NOISY data.  DLS minimises the
+    Cayley-polynomial cost J'(s) = (1 + s.s)^2 J(R(s)) (the denominators of R(s) are cleared so that the optimality
+    conditions are cubic); every returned rotation must be a stationary point of J' in s, with the returned translation
+    being the closed-form minimiser for that rotation."""
+    rng = np.random.default_rng(seed)
+    X, uv, T, _ = M.make_scene(N=200, outlier_frac=0.0, noise_px=2.0, seed=300 + seed)
+    idx = rng.choice(200, 15, replace=False)
+    Xs, uvs = X[idx], uv[idx]
+    n, Rs, ts = O.dls_pnp(Xs, uvs, O.dls_linear_form(seed, 2))
+    assert n >= 1
+    Jp = lambda s: (1 + s @ s) ** 2 * _dls_cost(_cayley_R(s), Xs, uvs)[0]
+    for R, t in zip(Rs, ts):
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-9) and np.linalg.det(R) > 0
+        J0, t_star = _dls_cost(R, Xs, uvs)
+        assert np.allclose(t, t_star, rtol=1e-7, atol=1e-9)                  # t = closed-form translation for that R
+        s0 = _cayley_s(R)
+        assert np.allclose(_cayley_R(s0), R, atol=1e-9)
+        h = 1e-5
+        g = np.array([(Jp(s0 + h * e) - Jp(s0 - h * e)) / (2 * h) for e in np.eye(3)])
+        curv = max(abs(Jp(s0 + 1e-2 * e) + Jp(s0 - 1e-2 * e) - 2 * Jp(s0)) / 1e-4 for e in np.eye(3))   # second-derivative scale
+        assert np.abs(g).max() <= 1e-6 * max(curv, 1e-12), (g, curv)          # gradient vanishes relative to the curvature
