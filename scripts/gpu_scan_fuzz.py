@@ -43,10 +43,69 @@ def run(n=120, seed=11):
     return bad
 
 
+def run_ticks(n=12, seed=5):
+    """Random tick schedules (skips, jumps, too-short prefixes), random accept-rule parameters, synchronous and pipelined
+    ticks, and a random shard count emulated on one GPU -- every record against the oracle's."""
+    import torch
+    import scenarios
+    rng = np.random.default_rng(seed)
+    bad = []
+    def same(g, o):
+        g = g.as_dict()
+        return all(g[k] == o[k] for k in ("status", "found", "idx_curr", "idx_prev", "argmax")) and \
+            float(g["score"]).hex() == float(o["score"]).hex() and [float(x).hex() for x in g["maxv"]] == [float(x).hex() for x in o["maxv"]]
+    for it in range(n):
+        D = int(rng.choice([64, 256, 512, 1000])); N = int(rng.integers(300, 1200))
+        plants, loops, ties = scenarios.loop_plants(N, 4, seed=100 + it, lag=int(rng.integers(10, 60)))
+        db = scenarios.build_db(200 + it, N, D, plants)
+        vals = dict(locality=int(rng.integers(1, 25)), thresh=float(rng.choice([0.5, 0.85000002384185791015625, 0.95])),
+                    lag=int(rng.integers(5, 80)), min_new=int(rng.integers(1, 6)), min_k=int(rng.integers(0, 12)))
+        ls, l = [], 0
+        while True:
+            l += int(rng.choice([1, 2, 3, 3, 3, 4, 7, 20]))
+            if l > N: break
+            ls.append(l)
+        op = O.OrcDotParams(vals["locality"], vals["thresh"], vals["lag"], vals["min_new"], vals["min_k"])
+        want = []
+        orc = O.LoopOracle(db, op)
+        for l in ls: want.append(orc.tick(l))
+        gp = capi.default_dot_params()
+        for k_, v_ in vals.items(): setattr(gp, k_, v_)
+        with capi.Chip(D) as chip:
+            chip.append_f32(db)
+            got = [chip.loop_tick(l, gp) for l in ls]
+            if not all(same(g, o) for g, o in zip(got, want)): bad.append(("sync", it, vals))
+            chip.loop_reset()
+            W = int(rng.integers(1, 9)); pend = []; got = []
+            for i, l in enumerate(ls):
+                if len(pend) == W: got.append(chip.loop_tick_collect(pend.pop(0)))
+                chip.loop_tick_enqueue(l, i % W, gp); pend.append(i % W)
+            while pend: got.append(chip.loop_tick_collect(pend.pop(0)))
+            if not all(same(g, o) for g, o in zip(got, want)): bad.append(("pipelined", it, W, vals))
+        G = int(rng.choice([2, 3, 5, 8])); K = int(rng.integers(1, 17))
+        chips = [capi.Chip(D, shard_rank=r, shard_count=G) for r in range(G)]
+        try:
+            for c in chips: c.append_f32(db)
+            bufs = torch.zeros((G, 3, K, 2), dtype=torch.float64, device="cuda")
+            for l, o in zip(ls, want):
+                st = [c.scan_local(l, bufs[r].data_ptr(), K, gp) for r, c in enumerate(chips)]
+                if len(set(st)) != 1 or st[0] != o["status"]: bad.append(("shard-status", it, l)); break
+                if st[0] != capi.CHIP_TICK_SCANNED: continue
+                for c in chips: c.synchronize()
+                if not all(same(c.merge_decide(l, bufs.data_ptr(), G, K, gp), o) for c in chips): bad.append(("sharded", it, G, K, l)); break
+        finally:
+            for c in chips: c.close()
+    return bad
+
+
 if __name__ == "__main__":
     t0 = time.time()
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
     bad = run(n)
     print(f"scan fuzz: {len(bad)} mismatches in {n} cases, {time.time()-t0:.1f} s")
     for b in bad[:10]: print(b)
+    sys.path.insert(0, 'tests')
+    bt = run_ticks(12)
+    print(f"tick fuzz: {len(bt)} mismatches in 12 schedules")
+    for b in bt[:10]: print(b)
 

@@ -22,3 +22,9 @@ def test_scan_fuzz():
     import gpu_scan_fuzz
     bad = gpu_scan_fuzz.run(60)
     assert not bad, bad[:3]
+
+
+def test_tick_schedule_fuzz():
+    import gpu_scan_fuzz
+    bad = gpu_scan_fuzz.run_ticks(6)
+    assert not bad, bad[:3]
