@@ -31,6 +31,8 @@ namespace chip {
 struct PnpTables {
     double qmat[9][10];       // vec(Rbar) = Q * [1 s1 s2 s3 s1^2 s1s2 s1s3 s2^2 s2s3 s3^2]
     int8_t pair2c4[100];      // quartic monomial index of m10[l]*m10[q]
+    int8_t c4_cnt[35];        // inverse of pair2c4: how many (l,q) pairs feed quartic monomial k ...
+    int8_t c4_src[35][16];    // ... and which ones, ascending (the order the sum is taken in)
     int8_t fsrc[3][20];       // f_k[mono] = fmul * c4[fsrc]
     int8_t fmul[3][20];
     int8_t row_which[93];     // Macaulay row (non-reduced monomial) -> which cubic multiplies it
@@ -63,6 +65,11 @@ static void build_tables(PnpTables &t)
     for (int l = 0; l < 10; l++)
         for (int q = 0; q < 10; q++)
             t.pair2c4[l * 10 + q] = (int8_t)idx_le(M10[l][0] + M10[q][0], M10[l][1] + M10[q][1], M10[l][2] + M10[q][2], 4);
+    for (int k = 0; k < 35; k++) {
+        t.c4_cnt[k] = 0;
+        for (int e = 0; e < 100; e++)
+            if (t.pair2c4[e] == k && t.c4_cnt[k] < 16) t.c4_src[k][t.c4_cnt[k]++] = (int8_t)e;
+    }
     for (int a = 0; a <= 3; a++)
         for (int b = 0; a + b <= 3; b++)
             for (int c = 0; a + b + c <= 3; c++) {
@@ -314,8 +321,8 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     __syncthreads();
     if (tid < 35) {  // quartic coefficients: c4[k] = sum of G[l][q] with m10[l]*m10[q] == monomial k, in (l,q) row-major order
         double s = 0.0;
-        for (int e = 0; e < 100; e++)
-            if (tb.pair2c4[e] == tid) s = s + G[e];
+        const int cnt = tb.c4_cnt[tid];
+        for (int e = 0; e < cnt; e++) s = s + G[tb.c4_src[tid][e]];
         c4[tid] = s;
     }
     __syncthreads();
@@ -626,7 +633,7 @@ struct EigArgs {
 __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
 {
     __shared__ double Hs[EN * EN], Vs[EN * EN], Xs[EN * EN];
-    __shared__ double ort[EN], ortm[EN], wr[EN], wi[EN], Tf[27], sxs[kSampleMax * 3], model[16];
+    __shared__ double ortm[EN], wr[EN], wi[EN], Tf[27], sxs[kSampleMax * 3], model[16];
     const int lane = threadIdx.x;
     const int hyp = blockIdx.x;                                    // slot: hypothesis (hyp % H) of problem (hyp / H)
     const PnpProblem pr = a.prob[hyp / a.H];
@@ -647,41 +654,72 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
 
     if (a.debug_stop == 1) return;
     // ================= Householder reduction to Hessenberg form (orthes) =================
+    // The reflector vector u (EISPACK's ort[]) stays in a register, lane i holding u_i: wave-uniform reads of it are
+    // v_readlane pairs instead of LDS broadcasts, the two serial sums (scale, h) run off registers, and the matrix loops fetch
+    // H four elements at a time so one LDS round trip is exposed per four terms.  Term order is that of the reference loops.
     for (int m = low + 1; m <= high - 1; m++) {
+        const double colv = (lane <= high) ? HH(lane, m - 1) : 0.0;
         double scale = 0.0;
-        for (int i = m; i <= high; i++) scale = scale + fabs(HH(i, m - 1));
+        for (int i = m; i <= high; i++) scale = scale + fabs(lane_value_f64(colv, i));
         if (scale != 0.0) {
-            if (lane >= m && lane <= high) ort[lane] = HH(lane, m - 1) / scale;
-            __syncthreads();
+            double ov = colv / scale;                       // u_i = H(i, m-1) / scale on lanes m..high
             double h = 0.0;
-            for (int i = high; i >= m; i--) h = h + ort[i] * ort[i];
+            for (int i = high; i >= m; i--) { const double o = lane_value_f64(ov, i); h = h + o * o; }
             double g = sqrt(h);
-            const double om = ort[m];
+            const double om = lane_value_f64(ov, m);
             if (om > 0) g = -g;
             h = h - om * g;
-            __syncthreads();
-            if (lane == 0) ort[m] = om - g;
-            __syncthreads();
+            if (lane == m) ov = om - g;
             if (lane >= m && lane < nn) {  // H = (I - u u^T/h) H, column j = lane
                 const int j = lane;
                 double f = 0.0;
-                for (int i = high; i >= m; i--) f = f + ort[i] * HH(i, j);
+                int i = high;
+                for (; i - 3 >= m; i -= 4) {
+                    const double h0 = HH(i, j), h1 = HH(i - 1, j), h2 = HH(i - 2, j), h3 = HH(i - 3, j);
+                    f = f + lane_value_f64(ov, i) * h0;
+                    f = f + lane_value_f64(ov, i - 1) * h1;
+                    f = f + lane_value_f64(ov, i - 2) * h2;
+                    f = f + lane_value_f64(ov, i - 3) * h3;
+                }
+                for (; i >= m; i--) f = f + lane_value_f64(ov, i) * HH(i, j);
                 f = f / h;
-                for (int i = m; i <= high; i++) HH(i, j) = HH(i, j) - f * ort[i];
+                i = m;
+                for (; i + 3 <= high; i += 4) {
+                    const double h0 = HH(i, j), h1 = HH(i + 1, j), h2 = HH(i + 2, j), h3 = HH(i + 3, j);
+                    HH(i, j) = h0 - f * lane_value_f64(ov, i);
+                    HH(i + 1, j) = h1 - f * lane_value_f64(ov, i + 1);
+                    HH(i + 2, j) = h2 - f * lane_value_f64(ov, i + 2);
+                    HH(i + 3, j) = h3 - f * lane_value_f64(ov, i + 3);
+                }
+                for (; i <= high; i++) HH(i, j) = HH(i, j) - f * lane_value_f64(ov, i);
             }
             __syncthreads();
             if (lane <= high) {  // H = H (I - u u^T/h), row i = lane
                 const int i = lane;
                 double f = 0.0;
-                for (int j = high; j >= m; j--) f = f + ort[j] * HH(i, j);
+                int j = high;
+                for (; j - 3 >= m; j -= 4) {
+                    const double h0 = HH(i, j), h1 = HH(i, j - 1), h2 = HH(i, j - 2), h3 = HH(i, j - 3);
+                    f = f + lane_value_f64(ov, j) * h0;
+                    f = f + lane_value_f64(ov, j - 1) * h1;
+                    f = f + lane_value_f64(ov, j - 2) * h2;
+                    f = f + lane_value_f64(ov, j - 3) * h3;
+                }
+                for (; j >= m; j--) f = f + lane_value_f64(ov, j) * HH(i, j);
                 f = f / h;
-                for (int j = m; j <= high; j++) HH(i, j) = HH(i, j) - f * ort[j];
+                j = m;
+                for (; j + 3 <= high; j += 4) {
+                    const double h0 = HH(i, j), h1 = HH(i, j + 1), h2 = HH(i, j + 2), h3 = HH(i, j + 3);
+                    HH(i, j) = h0 - f * lane_value_f64(ov, j);
+                    HH(i, j + 1) = h1 - f * lane_value_f64(ov, j + 1);
+                    HH(i, j + 2) = h2 - f * lane_value_f64(ov, j + 2);
+                    HH(i, j + 3) = h3 - f * lane_value_f64(ov, j + 3);
+                }
+                for (; j <= high; j++) HH(i, j) = HH(i, j) - f * lane_value_f64(ov, j);
             }
             __syncthreads();
             if (lane == 0) {
-                const double o2 = scale * ort[m];
-                ort[m] = o2;
-                ortm[m] = o2;
+                ortm[m] = scale * (om - g);
                 HH(m, m - 1) = scale * g;
             }
             __syncthreads();
