@@ -220,6 +220,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=16)
     ap.add_argument("--no-pnp", action="store_true", help="skip the auxiliary PnP-RANSAC leg (config 3)")
     ap.add_argument("--no-batch", action="store_true", help="skip the auxiliary many-query MFMA leg (row N4)")
+    ap.add_argument("--replicated", action="store_true",
+                    help="N > 1 only: every GPU holds the whole DB and serves its own stream of ticks (no collective; weak "
+                         "scaling) instead of the default 8-way row shard of BASELINE config 4")
     ap.add_argument("--force-sharded", action="store_true",
                     help="testing aid: run the sharded code path (scan_local -> RCCL all-gather -> merge) even with 1 rank")
     args = ap.parse_args()
@@ -234,6 +237,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     dist = None
+    replicated = args.replicated and world > 1
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -255,7 +259,8 @@ def main():
 
     global D
     D = args.dim
-    chip = capi.Chip(D, capacity_hint=total_rows, device=local_rank, shard_rank=rank, shard_count=world)
+    chip = capi.Chip(D, capacity_hint=total_rows, device=local_rank, shard_rank=0 if replicated else rank,
+                     shard_count=1 if replicated else world)
     info = chip.info()
     t_fill = time.perf_counter()
     chip.append_synthetic(total_rows, SEED, plants)
@@ -269,7 +274,7 @@ def main():
         chip.synchronize()
 
     results = []
-    if world == 1 and not args.force_sharded:
+    if (world == 1 and not args.force_sharded) or replicated:
         def run(tick_ls):
             out = []
             W = max(1, min(args.inflight, capi.CHIP_MAX_INFLIGHT - 1))
@@ -346,7 +351,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        local_rows = (args.rows + world - 1) // world
+        local_rows = args.rows if replicated else (args.rows + world - 1) // world
         alg_bytes = 4.0 * D * local_rows                       # one pass of the fp32 DB prefix (this rank's share)
         avg_s = scan_ms / 1e3 / max(1, n_launch)              # per-launch duration (what rocprofv3 --stats reports)
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
@@ -360,21 +365,22 @@ def main():
                 traffic = None
         out = {
             "metric": f"loop-queries/sec (ticks of 3 descriptors vs {D}-D x {fmt_rows(args.rows)} DB) [+ PnP-RANSAC hypotheses/sec in \"pnp\"]",
-            "value": args.steps / elapsed,
+            "value": (world if replicated else 1) * args.steps / elapsed,   # replicas each run `steps` ticks of their own
             "unit": "loop-queries/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if replicated else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (on-device integer-domain generator, seed 20190412, planted revisits)",
             "config": {"workload": f"{D}-D fp32 descriptors x {args.rows} keyframe DB, 3 queries/tick, top-{TOPK} + accept rule",
                        "db_rows": args.rows, "D": D, "queries_per_tick": 3, "topk": TOPK, "storage": "fp32 rows (verified-lossless narrowing of the f64 wire type), fp64 accumulate",
                        "loop_query": "one tick of Cerebro::descrip_N__dot__descrip_0_N = 3 descriptor queries + top-k + accept rule",
-                       "sharding": "single GPU" if world == 1 else f"row round-robin over {world} GPUs + RCCL all-gather of top-k",
+                       "sharding": "single GPU" if world == 1 else (f"{world} replicas of the whole DB, independent tick streams, no collective" if replicated
+                                                                   else f"row round-robin over {world} GPUs + RCCL all-gather of top-k"),
                        "descriptor_queries_per_s": 3 * args.steps / elapsed,
                        "db_fill_s": t_fill, "arch": info["arch"], "n_cus": info["n_cus"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
