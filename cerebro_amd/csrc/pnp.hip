@@ -178,7 +178,7 @@ constexpr int kPanel = 4;   // pivot columns factorised per panel of the blocked
 // dynamic LDS of pnp_build_solve (must match the carve-up at the top of the kernel)
 constexpr size_t kSolveLds = sizeof(double) * (kSampleMax * 8 + 9 + 9 + 27 + 27 + 81 + 90 + 100 + 36 + 60 + 4 + 27 * 27 +
                                                2 * 96 * kPanel * 2 + kPanel * 128 + 2 * kPanel * kPanel + 27 * kNC) +
-                             sizeof(int) * (16 + 32 + 32 + 4 + 2 * kPanel) + 64;
+                             sizeof(int) * (16 + 4 + 2 * kPanel) + 64;
 
 __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
 {
@@ -204,9 +204,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     double *Lsub = sm;          sm += 2 * kPanel * kPanel;        // [parity][c][c' < c]: multipliers among a panel's pivot rows
     double *Urows = sm;         sm += 27 * kNC;                   // pivot rows of steps 66..92 = rows of U needed by the back-substitution
     int *smp = reinterpret_cast<int *>(sm);                       // [16]
-    int *fy_key = smp + 16;                                        // sparse Fisher-Yates map (<= 32 entries)
-    int *fy_val = fy_key + 32;
-    int *flag = fy_val + 32;                                       // [4] : singular, spare
+    int *flag = smp + 16;                                          // [4] : singular, spare
     int *prow_s = flag + 4;                                        // [parity][kPanel] physical pivot rows of a panel
 
     const int tid = threadIdx.x;

@@ -22,32 +22,10 @@ __device__ __forceinline__ uint64_t rng_draw(uint64_t seed, uint32_t hyp, uint32
     return splitmix64_d(seed ^ ((uint64_t)hyp << 32) ^ (uint64_t)draw);
 }
 
-// theia::RandomSampler restated: partial Fisher-Yates over a VIRTUAL identity permutation of N (only the <= 2S touched
-// positions are materialised in fy_key/fy_val, LDS arrays of >= 2*kSampleMax ints).  Called by ONE lane.
-__device__ __forceinline__ void ransac_sample_sparse(uint64_t seed, int hyp, int N, int S, int *fy_key, int *fy_val, int *smp)
-{
-    int used = 0;
-    for (int i = 0; i < S; i++) {
-        const uint64_t x = rng_draw(seed, (uint32_t)hyp, (uint32_t)i);
-        const int j = i + (int)(x % (uint64_t)(N - i));
-        int vi = i, vj = j, pi = -1, pj = -1;
-        for (int e = 0; e < used; e++) {
-            if (fy_key[e] == i) { vi = fy_val[e]; pi = e; }
-            if (fy_key[e] == j) { vj = fy_val[e]; pj = e; }
-        }
-        if (pi < 0) { pi = used++; fy_key[pi] = i; }   // idx[i] <- vj ; idx[j] <- vi
-        fy_val[pi] = vj;
-        if (j != i) {
-            if (pj < 0) { pj = used++; fy_key[pj] = j; }
-            fy_val[pj] = vi;
-        }
-        smp[i] = vj;
-    }
-}
-
-// The same sampler executed by a WHOLE WAVE (identical draws, identical result): the S draws and their 64-bit modulo are
-// computed by lanes 0..S-1 at once, and the sparse permutation map lives in registers (lane e holds entry e) so that every
-// lookup is a __ballot + v_readlane instead of a serial scan of LDS.  Returns sample i in lane i (< S).
+// theia::RandomSampler restated: partial Fisher-Yates over a VIRTUAL identity permutation of N: step i swaps positions i and
+// j_i = i + draw_i % (N - i); only the <= 2S touched positions are materialised.  Executed by a WHOLE WAVE: the S draws and
+// their 64-bit modulo are computed by lanes 0..S-1 at once, and the sparse permutation map lives in registers (lane e holds
+// entry e) so that every lookup is a __ballot + v_readlane instead of a serial scan.  Returns sample i in lane i (< S).
 __device__ __forceinline__ int ransac_sample_wave(uint64_t seed, int hyp, int N, int S, int lane)
 {
     int jv = 0;
