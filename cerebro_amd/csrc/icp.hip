@@ -191,8 +191,7 @@ struct IcpState {
 
 static void icp_free(IcpState *st)
 {
-    (void)hipFree(st->A); (void)hipFree(st->B); (void)hipFree(st->T_out); (void)hipFree(st->cost);
-    (void)hipFree(st->nin); (void)hipFree(st->valid); (void)hipFree(st->mask);
+    (void)hipFree(st->A); (void)hipFree(st->B);   // T_out/cost/nin/valid/mask are device views of the pinned host buffers below
     (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid); (void)hipHostFree(st->h_mask);
     *st = IcpState();
 }
@@ -214,16 +213,17 @@ static int icp_reserve(Ctx *c, IcpState *st, int N, int H)
     icp_free(st);
     CHIP_HIP(c, hipMalloc(&st->A, sizeof(double) * 3 * (size_t)nN));
     CHIP_HIP(c, hipMalloc(&st->B, sizeof(double) * 3 * (size_t)nN));
-    CHIP_HIP(c, hipMalloc(&st->T_out, sizeof(double) * 16 * (size_t)nH));
-    CHIP_HIP(c, hipMalloc(&st->cost, sizeof(double) * (size_t)nH));
-    CHIP_HIP(c, hipMalloc(&st->nin, sizeof(int32_t) * (size_t)nH));
-    CHIP_HIP(c, hipMalloc(&st->valid, sizeof(int32_t) * (size_t)nH));
-    CHIP_HIP(c, hipMalloc(&st->mask, sizeof(unsigned long long) * (size_t)nH * nW));
+    // per-hypothesis results go straight to pinned, device-mapped host memory (as in pnp.hip): no D2H copies, one sync per call
     CHIP_HIP(c, hipHostMalloc(&st->h_cost, sizeof(double) * (size_t)nH, hipHostMallocDefault));
-    CHIP_HIP(c, hipHostMalloc(&st->h_T, sizeof(double) * 16, hipHostMallocDefault));
+    CHIP_HIP(c, hipHostMalloc(&st->h_T, sizeof(double) * 16 * (size_t)nH, hipHostMallocDefault));
     CHIP_HIP(c, hipHostMalloc(&st->h_nin, sizeof(int32_t) * (size_t)nH, hipHostMallocDefault));
     CHIP_HIP(c, hipHostMalloc(&st->h_valid, sizeof(int32_t) * (size_t)nH, hipHostMallocDefault));
-    CHIP_HIP(c, hipHostMalloc(&st->h_mask, sizeof(unsigned long long) * (size_t)nW, hipHostMallocDefault));
+    CHIP_HIP(c, hipHostMalloc(&st->h_mask, sizeof(unsigned long long) * (size_t)nH * nW, hipHostMallocDefault));
+    CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->cost, st->h_cost, 0));
+    CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->T_out, st->h_T, 0));
+    CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->nin, st->h_nin, 0));
+    CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->valid, st->h_valid, 0));
+    CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->mask, st->h_mask, 0));
     st->cap_N = nN; st->cap_H = nH; st->cap_words = nW;
     return CHIP_OK;
 }
@@ -266,22 +266,17 @@ extern "C" int chip_icp_ransac(chip_ctx *c, const double *A, const double *B, in
     a.mask_words = words; a.T_out = st->T_out; a.cost = st->cost; a.nin = st->nin; a.valid = st->valid; a.mask = st->mask;
     hipLaunchKernelGGL(icp_hyp_score, dim3(H), dim3(64), 0, s, a);
     CHIP_HIP(c, hipGetLastError());
-    CHIP_HIP(c, hipMemcpyAsync(st->h_cost, st->cost, sizeof(double) * (size_t)H, hipMemcpyDeviceToHost, s));
-    CHIP_HIP(c, hipMemcpyAsync(st->h_nin, st->nin, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, s));
-    CHIP_HIP(c, hipMemcpyAsync(st->h_valid, st->valid, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, s));
     CHIP_HIP(c, hipStreamSynchronize(s));
     double best_cost = DBL_MAX;
     int32_t n_models = 0, num_it = 0;
     const int32_t best_h = ransac_select(p, N, H, st->h_valid, st->h_cost, st->h_nin, &num_it, &n_models, &best_cost);
     int32_t nin = 0;
     if (best_h >= 0) {
-        CHIP_HIP(c, hipMemcpyAsync(st->h_T, st->T_out + 16 * (size_t)best_h, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
-        CHIP_HIP(c, hipMemcpyAsync(st->h_mask, st->mask + (size_t)best_h * words, sizeof(unsigned long long) * (size_t)words, hipMemcpyDeviceToHost, s));
-        CHIP_HIP(c, hipStreamSynchronize(s));
-        std::memcpy(T_colmajor, st->h_T, sizeof(double) * 16);
+        std::memcpy(T_colmajor, st->h_T + 16 * (size_t)best_h, sizeof(double) * 16);
         nin = st->h_nin[best_h];
+        const unsigned long long *hm = st->h_mask + (size_t)best_h * words;
         if (inlier_mask)
-            for (int i = 0; i < N; i++) inlier_mask[i] = (uint8_t)((st->h_mask[i >> 6] >> (i & 63)) & 1ull);
+            for (int i = 0; i < N; i++) inlier_mask[i] = (uint8_t)((hm[i >> 6] >> (i & 63)) & 1ull);
         const double ratio = (double)nin / (double)N;
         *confidence = (float)(1.0 - std::pow(1.0 - std::pow(ratio, (double)S), (double)num_it));  // summary.confidence (:121)
     } else {

@@ -1066,15 +1066,17 @@ struct PnpState {
     // device scratch, grown on demand
     double *X = nullptr, *uv = nullptr;
     int32_t cap_N = 0;
-    double *Sg = nullptr, *Tg = nullptr, *T_out = nullptr, *cost = nullptr;
-    int32_t *sample = nullptr, *ok = nullptr, *nin = nullptr, *valid = nullptr, *nsol = nullptr;
-    unsigned long long *mask = nullptr;
+    double *Sg = nullptr, *Tg = nullptr;
+    int32_t *sample = nullptr, *ok = nullptr;
     int32_t cap_H = 0, cap_words = 0;
-    // pinned host mirrors
-    double *h_cost = nullptr, *h_T = nullptr;
+    // Per-hypothesis results live in pinned, device-mapped HOST memory: pnp_eig_score stores them straight across PCIe (a few
+    // hundred KB per call, posted while the kernel runs), so a call needs no D2H copy and a single stream synchronisation.
+    double *h_cost = nullptr, *h_T = nullptr;            // host views
     int32_t *h_nin = nullptr, *h_valid = nullptr, *h_nsol = nullptr;
     unsigned long long *h_mask = nullptr;
-    int32_t hcap_P = 0, hcap_words = 0;
+    double *cost = nullptr, *T_out = nullptr;            // device views of the same allocations
+    int32_t *nin = nullptr, *valid = nullptr, *nsol = nullptr;
+    unsigned long long *mask = nullptr;
 };
 
 int pnp_create(Ctx *c)
@@ -1094,9 +1096,8 @@ int pnp_create(Ctx *c)
 static void pnp_free_dev(PnpState *st)
 {
     (void)hipFree(st->X); (void)hipFree(st->uv);
-    (void)hipFree(st->Sg); (void)hipFree(st->Tg); (void)hipFree(st->T_out); (void)hipFree(st->cost);
-    (void)hipFree(st->sample); (void)hipFree(st->ok); (void)hipFree(st->nin); (void)hipFree(st->valid); (void)hipFree(st->nsol);
-    (void)hipFree(st->mask);
+    (void)hipFree(st->Sg); (void)hipFree(st->Tg);
+    (void)hipFree(st->sample); (void)hipFree(st->ok);
     (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid);
     (void)hipHostFree(st->h_nsol); (void)hipHostFree(st->h_mask);
 }
@@ -1122,34 +1123,31 @@ static int pnp_reserve(Ctx *c, PnpState *st, int N, int H, int words, int P)
     }
     if (H > st->cap_H || words > st->cap_words) {
         const int nh = H > st->cap_H ? H : st->cap_H, nw = words > st->cap_words ? words : st->cap_words;
-        (void)hipFree(st->Sg); (void)hipFree(st->Tg); (void)hipFree(st->T_out); (void)hipFree(st->cost);
-        (void)hipFree(st->sample); (void)hipFree(st->ok); (void)hipFree(st->nin); (void)hipFree(st->valid); (void)hipFree(st->nsol);
-        (void)hipFree(st->mask);
-        (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid);
+        (void)hipFree(st->Sg); (void)hipFree(st->Tg); (void)hipFree(st->sample); (void)hipFree(st->ok);
+        (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid);
+        (void)hipHostFree(st->h_nsol); (void)hipHostFree(st->h_mask);
+        st->Sg = st->Tg = nullptr; st->sample = st->ok = nullptr;
+        st->h_cost = st->h_T = nullptr; st->h_nin = st->h_valid = st->h_nsol = nullptr; st->h_mask = nullptr;
         st->cap_H = st->cap_words = 0;
         CHIP_HIP(c, hipMalloc(&st->Sg, sizeof(double) * 729 * (size_t)nh));
         CHIP_HIP(c, hipMalloc(&st->Tg, sizeof(double) * 27 * (size_t)nh));
-        CHIP_HIP(c, hipMalloc(&st->T_out, sizeof(double) * 16 * (size_t)nh));
-        CHIP_HIP(c, hipMalloc(&st->cost, sizeof(double) * (size_t)nh));
         CHIP_HIP(c, hipMalloc(&st->sample, sizeof(int32_t) * kSampleMax * (size_t)nh));
         CHIP_HIP(c, hipMalloc(&st->ok, sizeof(int32_t) * (size_t)nh));
-        CHIP_HIP(c, hipMalloc(&st->nin, sizeof(int32_t) * (size_t)nh));
-        CHIP_HIP(c, hipMalloc(&st->valid, sizeof(int32_t) * (size_t)nh));
-        CHIP_HIP(c, hipMalloc(&st->nsol, sizeof(int32_t) * (size_t)nh));
-        CHIP_HIP(c, hipMalloc(&st->mask, sizeof(unsigned long long) * (size_t)nh * nw));
         CHIP_HIP(c, hipHostMalloc(&st->h_cost, sizeof(double) * (size_t)nh, hipHostMallocDefault));
+        CHIP_HIP(c, hipHostMalloc(&st->h_T, sizeof(double) * 16 * (size_t)nh, hipHostMallocDefault));
         CHIP_HIP(c, hipHostMalloc(&st->h_nin, sizeof(int32_t) * (size_t)nh, hipHostMallocDefault));
         CHIP_HIP(c, hipHostMalloc(&st->h_valid, sizeof(int32_t) * (size_t)nh, hipHostMallocDefault));
+        CHIP_HIP(c, hipHostMalloc(&st->h_nsol, sizeof(int32_t) * (size_t)nh, hipHostMallocDefault));
+        CHIP_HIP(c, hipHostMalloc(&st->h_mask, sizeof(unsigned long long) * (size_t)nh * nw, hipHostMallocDefault));
+        CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->cost, st->h_cost, 0));
+        CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->T_out, st->h_T, 0));
+        CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->nin, st->h_nin, 0));
+        CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->valid, st->h_valid, 0));
+        CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->nsol, st->h_nsol, 0));
+        CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->mask, st->h_mask, 0));
         st->cap_H = nh; st->cap_words = nw;
     }
-    if (P > st->hcap_P || words > st->hcap_words) {
-        const int np = P > st->hcap_P ? P : st->hcap_P, nw = words > st->hcap_words ? words : st->hcap_words;
-        (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_mask);
-        st->hcap_P = st->hcap_words = 0;
-        CHIP_HIP(c, hipHostMalloc(&st->h_T, sizeof(double) * 16 * (size_t)np, hipHostMallocDefault));
-        CHIP_HIP(c, hipHostMalloc(&st->h_mask, sizeof(unsigned long long) * (size_t)nw * np, hipHostMallocDefault));
-        st->hcap_P = np; st->hcap_words = nw;
-    }
+    (void)P;
     return CHIP_OK;
 }
 
@@ -1192,35 +1190,24 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
     hipLaunchKernelGGL(pnp_eig_score, dim3(P * H), dim3(64), 0, s, ea);
     CHIP_HIP(c, hipGetLastError());
 
-    const size_t HT = (size_t)P * H;
-    CHIP_HIP(c, hipMemcpyAsync(st->h_cost, st->cost, sizeof(double) * HT, hipMemcpyDeviceToHost, s));
-    CHIP_HIP(c, hipMemcpyAsync(st->h_nin, st->nin, sizeof(int32_t) * HT, hipMemcpyDeviceToHost, s));
-    CHIP_HIP(c, hipMemcpyAsync(st->h_valid, st->valid, sizeof(int32_t) * HT, hipMemcpyDeviceToHost, s));
-    CHIP_HIP(c, hipStreamSynchronize(s));
+    CHIP_HIP(c, hipStreamSynchronize(s));   // every per-hypothesis result is in host memory now
 
     // K7: theia::Ransac::Estimate's sequential rule replayed over the per-hypothesis results
     int32_t best_h[kPnpMaxBatch], num_it[kPnpMaxBatch], n_models[kPnpMaxBatch];
     double best_cost[kPnpMaxBatch];
-    bool any = false;
     for (int i = 0; i < P; i++) {
         best_cost[i] = DBL_MAX; n_models[i] = 0; num_it[i] = 0;
         const size_t o = (size_t)i * H;
         best_h[i] = ransac_select(p, N[i], H, st->h_valid + o, st->h_cost + o, st->h_nin + o, &num_it[i], &n_models[i], &best_cost[i]);
-        if (best_h[i] >= 0) {
-            any = true;
-            CHIP_HIP(c, hipMemcpyAsync(st->h_T + 16 * (size_t)i, st->T_out + 16 * (o + best_h[i]), sizeof(double) * 16, hipMemcpyDeviceToHost, s));
-            CHIP_HIP(c, hipMemcpyAsync(st->h_mask + (size_t)i * words, st->mask + (o + best_h[i]) * words, sizeof(unsigned long long) * (size_t)words, hipMemcpyDeviceToHost, s));
-        }
     }
-    if (any) CHIP_HIP(c, hipStreamSynchronize(s));
     for (int i = 0; i < P; i++) {
         double *T = T_colmajor + 16 * (size_t)i;
         uint8_t *im = inlier_mask ? inlier_mask[i] : nullptr;
         int32_t nin = 0;
         if (best_h[i] >= 0) {
-            std::memcpy(T, st->h_T + 16 * (size_t)i, sizeof(double) * 16);
+            std::memcpy(T, st->h_T + 16 * ((size_t)i * H + best_h[i]), sizeof(double) * 16);
             nin = st->h_nin[(size_t)i * H + best_h[i]];
-            const unsigned long long *hm = st->h_mask + (size_t)i * words;
+            const unsigned long long *hm = st->h_mask + ((size_t)i * H + best_h[i]) * words;
             if (im)
                 for (int k = 0; k < N[i]; k++) im[k] = (uint8_t)((hm[k >> 6] >> (k & 63)) & 1ull);
             const double ratio = (double)nin / (double)N[i];
