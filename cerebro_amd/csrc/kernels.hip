@@ -24,7 +24,24 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // scan -> per-wave register top-K -> per-block LDS merge -> one sorted partial list per workgroup in global memory.
 // The cross-workgroup merge (+ accept decision) is K2 on the ctx stream, behind an event, so that it overlaps the
 // NEXT tick's scan (a fused last-workgroup merge was measured to serialise ~28 us per tick).
-template <int NQ, int U, bool FULL, bool NT, int R>
+// One 16-byte streaming load of a DB row chunk.  POLICY 1 (production) = the non-temporal hint; 0 = plain; 2..5 = other
+// gfx950 cache-policy bit combinations, reachable only through CHIP_SCAN_VARIANT in tuning builds.
+template <int POLICY>
+__device__ __forceinline__ f32x4 stream_load(const f32x4 *p)
+{
+    if constexpr (POLICY == 0) return *p;
+    else if constexpr (POLICY == 1) return __builtin_nontemporal_load(p);
+    else {
+        f32x4 v;
+        if constexpr (POLICY == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+        else if constexpr (POLICY == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+        else if constexpr (POLICY == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 nt" : "=v"(v) : "v"(p) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+        return v;
+    }
+}
+
+template <int NQ, int U, bool FULL, int NT, int R>
 __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -74,9 +91,16 @@ __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
                     const int e = base + u * 256 + e0;
                     if (FULL || e < D) {
                         const f32x4 *p = reinterpret_cast<const f32x4 *>(row[rr] + e);
-                        v[rr][u] = NT ? __builtin_nontemporal_load(p) : *p;
+                        v[rr][u] = stream_load<NT>(p);
                     }
                 }
+            }
+            if constexpr (NT >= 2) {   // inline-asm loads: the compiler does not track them
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int rr = 0; rr < R; rr++)
+#pragma unroll
+                    for (int u = 0; u < U; u++) asm volatile("" : "+v"(v[rr][u]));
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -176,7 +200,7 @@ __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
     }
 }
 
-template <int NQ, int U, bool FULL, bool NT, int R>
+template <int NQ, int U, bool FULL, int NT, int R>
 static int launch_scan_k(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds, int block)
 {
     if (lds > 65536) CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_scan_topk<NQ, U, FULL, NT, R>),
@@ -186,7 +210,7 @@ static int launch_scan_k(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, siz
     return CHIP_OK;
 }
 
-template <int NQ, int U, bool NT, int R>
+template <int NQ, int U, int NT, int R>
 static int launch_scan_t(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds, int block)
 {
     return a.D % (256 * U) == 0 ? launch_scan_k<NQ, U, true, NT, R>(c, s, a, grid, lds, block)
@@ -199,16 +223,20 @@ static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, siz
 {
 #ifdef CHIP_SCAN_TUNING_VARIANTS
     switch (c->scan_variant) {
-        case 1: return launch_scan_t<NQ, 4, true, 1>(c, s, a, grid, lds, block);
-        case 2: return launch_scan_t<NQ, 16, true, 1>(c, s, a, grid, lds, block);
-        case 3: return launch_scan_t<NQ, 8, false, 1>(c, s, a, grid, lds, block);
-        case 4: return launch_scan_t<NQ, 4, true, 2>(c, s, a, grid, lds, block);
-        case 5: return launch_scan_t<NQ, 8, true, 2>(c, s, a, grid, lds, block);
-        case 6: return launch_scan_t<NQ, 4, false, 2>(c, s, a, grid, lds, block);
+        case 1: return launch_scan_t<NQ, 4, 1, 1>(c, s, a, grid, lds, block);
+        case 2: return launch_scan_t<NQ, 16, 1, 1>(c, s, a, grid, lds, block);
+        case 3: return launch_scan_t<NQ, 8, 0, 1>(c, s, a, grid, lds, block);
+        case 4: return launch_scan_t<NQ, 4, 1, 2>(c, s, a, grid, lds, block);
+        case 5: return launch_scan_t<NQ, 8, 1, 2>(c, s, a, grid, lds, block);
+        case 6: return launch_scan_t<NQ, 4, 0, 2>(c, s, a, grid, lds, block);
+        case 7: return launch_scan_t<NQ, 8, 2, 1>(c, s, a, grid, lds, block);
+        case 8: return launch_scan_t<NQ, 8, 3, 1>(c, s, a, grid, lds, block);
+        case 9: return launch_scan_t<NQ, 8, 4, 1>(c, s, a, grid, lds, block);
+        case 10: return launch_scan_t<NQ, 8, 5, 1>(c, s, a, grid, lds, block);
         default: break;
     }
 #endif
-    return launch_scan_t<NQ, 8, true, 1>(c, s, a, grid, lds, block);
+    return launch_scan_t<NQ, 8, 1, 1>(c, s, a, grid, lds, block);
 }
 
 // Workgroup shape of K1.  The nq query descriptors sit in LDS (nq*D*4 bytes per workgroup), so the shape follows D:
