@@ -1,4 +1,4 @@
-"""world_size-2 (and 3) CPU test of the sharded tick plumbing over the gloo backend: row->rank map, per-shard lists
+"""world_size-2 (and 3, and 8 = BASELINE config 4) CPU test of the sharded tick plumbing over the gloo backend: row->rank map, per-shard lists
 with GLOBAL indices, all-gather layout, merge order (score desc, index desc) and the accept rule -- against the
 unsharded oracle.  The device calls (chip_scan_local / chip_merge_decide) are played by an oracle-backed stand-in,
 which is legitimate here because this test covers the HOST orchestration; the kernels themselves are covered by
@@ -118,7 +118,7 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_tick_over_gloo(world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
