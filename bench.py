@@ -244,8 +244,16 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # BENCH_DIST_BACKEND=gloo is a functional-test aid for a 1-GPU box: the ranks then share device 0 (RCCL refuses two
+        # ranks on one device) and exchange through gloo; the measured figure is then not an N-GPU number.
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -379,6 +387,7 @@ def main():
             "config": {"workload": f"{D}-D fp32 descriptors x {args.rows} keyframe DB, 3 queries/tick, top-{TOPK} + accept rule",
                        "db_rows": args.rows, "D": D, "queries_per_tick": 3, "topk": TOPK, "storage": "fp32 rows (verified-lossless narrowing of the f64 wire type), fp64 accumulate",
                        "loop_query": "one tick of Cerebro::descrip_N__dot__descrip_0_N = 3 descriptor queries + top-k + accept rule",
+                       "dist_backend": os.environ.get("BENCH_DIST_BACKEND", "nccl") if world > 1 else None,
                        "sharding": "single GPU" if world == 1 else (f"{world} replicas of the whole DB, independent tick streams, no collective" if replicated
                                                                    else f"row round-robin over {world} GPUs + RCCL all-gather of top-k"),
                        "descriptor_queries_per_s": 3 * args.steps / elapsed,
