@@ -372,7 +372,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": f"loop-queries/sec (ticks of 3 descriptors vs {D}-D x {fmt_rows(args.rows)} DB) [+ PnP-RANSAC hypotheses/sec in \"pnp\"]",
+            "metric": f"loop-queries/sec (ticks of 3 descriptors vs {D}-D x {fmt_rows(args.rows)} DB)",   # same string at every N; PnP-RANSAC hypotheses/sec: see "pnp" (N = 1)
             "value": (world if replicated else 1) * args.steps / elapsed,   # replicas each run `steps` ticks of their own
             "unit": "loop-queries/s",
             "n_gpus": world,
