@@ -19,7 +19,7 @@ ORC_SRCS   := $(wildcard oracle/*.c)
 all: lib oracle host
 lib: $(LIBDIR)/libcerebro_hip.so
 oracle: oracle/_build/liboracle.so
-host: $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay
+host: $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay $(LIBDIR)/minimal_loop_detector
 
 $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/chip_internal.h $(CSRC)/ransac_common.h $(CSRC)/topk_merge.h include/cerebro_hip.h
 	@mkdir -p $(LIBDIR)
@@ -40,6 +40,10 @@ $(LIBDIR)/cerebro_replay: $(HOSTDIR)/cerebro_replay.cc $(LIBDIR)/libcerebro_host
 oracle/_build/liboracle.so: $(ORC_SRCS) oracle/cerebro_oracle.h
 	@mkdir -p oracle/_build
 	$(CC) $(ORCFLAGS) -shared $(ORC_SRCS) -o $@ -lm
+
+# ---- plain-C-ABI example (the INTEGRATION.md call sequence without ROS / Eigen) ----
+$(LIBDIR)/minimal_loop_detector: examples/minimal_loop_detector.cc include/cerebro_hip.h $(LIBDIR)/libcerebro_hip.so
+	$(CXX) -O2 -std=c++17 -Wall -Wextra -Iinclude $< -o $@ -L$(LIBDIR) -lcerebro_hip -Wl,-rpath,'$$ORIGIN'
 
 clean:
 	rm -rf $(LIBDIR) oracle/_build

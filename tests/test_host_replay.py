@@ -202,3 +202,18 @@ def test_policy_replay_matches_oracle(tmp_path, policy, step):
     want = [x for l in ticks for x in orc.tick(l)]
     assert len(want) >= 3
     assert [(g["global_a"], g["global_b"], g["score"]) for g in got] == want      # indices and float scores bit-exact
+
+
+# ------------------------------------------------------------------ the INTEGRATION.md call sequence as a plain C-ABI program
+def test_example_program_is_built_against_the_c_abi_only():
+    exe = LIB / "minimal_loop_detector"
+    assert exe.exists()
+    out = subprocess.run(["ldd", str(exe)], capture_output=True, text=True).stdout
+    assert "libcerebro_hip.so" in out and "libcerebro_host" not in out and "not found" not in out
+
+
+@pytest.mark.gpu
+def test_example_program_detects_the_revisit_and_recovers_the_pose():
+    r = subprocess.run([str(LIB / "minimal_loop_detector")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "loop candidate" in r.stdout and "PnP:" in r.stdout
