@@ -2,10 +2,12 @@
 // /root/reference/src/DlsPnpWithRansac.cpp:192-240, i.e. theia::Ransac over the DlsPnpWithRansac estimator of
 // src/DlsPnpWithRansac.h:42-100).  All hypotheses of a call are generated and scored in parallel:
 //
-//   K4+K5a  pnp_build_solve   one 512-thread workgroup per hypothesis (LDS ~45 KB, 2-3 per CU): counter-based sampler,
-//                             DLS cost matrix -> three Cayley cubics -> degree-7 Macaulay matrix [D|C] (93x120) held in
-//                             REGISTERS (24 rows x 1 column per thread) -> LU with partial pivoting (DPP wave max +
-//                             logical-position tie rule; only column k / pivot row / multipliers cross LDS)
+//   K4+K5a  pnp_build_solve   one 448-thread workgroup per hypothesis (LDS ~50 KB, 128 VGPRs: 2 per CU): wave-parallel
+//                             counter-based sampler, DLS cost matrix -> three Cayley cubics -> degree-7 Macaulay matrix
+//                             [D|C] (93x120) held in the REGISTERS of waves 0..5 (31 rows x 1 column per thread) ->
+//                             blocked LU with partial pivoting and lookahead: wave 6 factorises the next 4-column panel
+//                             (DPP wave max + logical-position tie rule, readlane broadcasts) while waves 0..5 apply the
+//                             previous panel; only panel columns / pivot rows / multipliers cross LDS
 //                             -> 27x27 action matrix S = A - B D^-1 C.
 //   K5b+K6  pnp_eig_score     one WAVE per hypothesis: Householder Hessenberg + Francis double-shift QR with
 //                             accumulated transformations (matrices in LDS, lanes over independent rows/columns),
@@ -16,8 +18,8 @@
 //
 // Numerics: fp64, -ffp-contract=off, IEEE divide/sqrt; every sum runs in the order DESIGN.md 5 fixes (the same
 // order as the CPU oracle), lanes only parallelise over independent outputs, so poses and inlier masks are
-// reproducible bit for bit.  Neither HBM nor MFMA bound: ~1.3 MFLOP and ~100 KB of LDS-resident state per
-// hypothesis, latency bound.
+// reproducible bit for bit.  Neither HBM nor MFMA bound: ~1.3 MFLOP per hypothesis, VALU issue utilisation 5-8 %
+// (profiles/r01_pnp_pmc.md): latency bound.  Up to kPnpMaxBatch problems share one pair of launches.
 #include "ransac_common.h"
 #include <cfloat>
 #include <cmath>
