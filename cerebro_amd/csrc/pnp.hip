@@ -869,7 +869,11 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                     qm = HH(mm + 1, mm + 1) - zz - rr - ss;
                     rm = HH(mm + 2, mm + 1);
                     ss = fabs(pm) + fabs(qm) + fabs(rm);
-                    pm = pm / ss; qm = qm / ss; rm = rm / ss;
+                    {   // exact power-of-two scaling instead of EISPACK's division by |p|+|q|+|r| (see oracle/pnp_ransac.c)
+                        int e2;
+                        (void)frexp(ss, &e2);
+                        pm = ldexp(pm, -e2); qm = ldexp(qm, -e2); rm = ldexp(rm, -e2);
+                    }
                     if (mm == l) pass = true;
                     else pass = fabs(HH(mm, mm - 1)) * (fabs(qm) + fabs(rm)) <
                                 eps * (fabs(pm) * (fabs(HH(mm - 1, mm - 1)) + fabs(zz) + fabs(HH(mm + 1, mm + 1))));
@@ -893,22 +897,23 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             double fp = 0.0, fq = 0.0, fr = 0.0;
             for (int k = m; k <= n - 1; k++) {
                 const bool notlast = (k != n - 1);
+                int ex = 0;
                 if (k != m) {
                     if (fwd) { p = fp; q = fq; r = fr; }
                     else { p = HH(k, k - 1); q = HH(k + 1, k - 1); r = notlast ? HH(k + 2, k - 1) : 0.0; }
                     fwd = false;
                     x = fabs(p) + fabs(q) + fabs(r);
                     if (x == 0.0) continue;
-                    // p/x, q/x, r/x: the operands are wave-uniform, so the three IEEE divisions are issued as ONE vector
-                    // division (lanes 0,1,2) and read back -- same quotients, a third of the instructions
-                    const double quo = ((lane == 0) ? p : ((lane == 1) ? q : r)) / x;
-                    p = lane_value_f64(quo, 0); q = lane_value_f64(quo, 1); r = lane_value_f64(quo, 2);
+                    // overflow protection by an exact power-of-two scale 2^-ex, |p|+|q|+|r| = f * 2^ex (three v_ldexp instead of
+                    // the division chain EISPACK has here; the oracle defines it the same way)
+                    (void)frexp(x, &ex);
+                    p = ldexp(p, -ex); q = ldexp(q, -ex); r = ldexp(r, -ex);
                 }
                 fwd = false;
                 s = sqrt(p * p + q * q + r * r);
                 if (p < 0) s = -s;
                 if (s != 0.0) {
-                    const double hkk1 = (k != m) ? -s * x : ((l != m) ? -HH(k, k - 1) : 0.0);
+                    const double hkk1 = (k != m) ? ldexp(-s, ex) : ((l != m) ? -HH(k, k - 1) : 0.0);
                     const bool wr_sub = (k != m) || (l != m);
                     p = p + s;
                     {   // x = p/s, y = q/s, z = r/s, q = q/p, r = r/p as one vector division over lanes 0..4

@@ -468,8 +468,11 @@ static int francis_qr(double H[EN][EN], double V[EN][EN], double wr[EN], double 
                 p = (r * s - w) / H[m + 1][m] + H[m][m + 1];
                 q = H[m + 1][m + 1] - z - r - s;
                 r = H[m + 2][m + 1];
+                /* EISPACK divides (p,q,r) by |p|+|q|+|r| purely as overflow protection; here the scale is the power of two
+                 * 2^e with |p|+|q|+|r| = f * 2^e, f in [0.5,1): the scaling is then exact (no rounding) and costs three
+                 * exponent adjustments instead of three divisions on the critical path of every step. */
                 s = fabs(p) + fabs(q) + fabs(r);
-                p = p / s; q = q / s; r = r / s;
+                { int e2; (void)frexp(s, &e2); p = ldexp(p, -e2); q = ldexp(q, -e2); r = ldexp(r, -e2); }
                 if (m == l) break;
                 if (fabs(H[m][m - 1]) * (fabs(q) + fabs(r)) <
                     eps * (fabs(p) * (fabs(H[m - 1][m - 1]) + fabs(z) + fabs(H[m + 1][m + 1])))) break;
@@ -478,17 +481,19 @@ static int francis_qr(double H[EN][EN], double V[EN][EN], double wr[EN], double 
             for (int i = m + 2; i <= n; i++) { H[i][i - 2] = 0.0; if (i > m + 2) H[i][i - 3] = 0.0; }
             for (int k = m; k <= n - 1; k++) { /* double QR step on rows l..n, columns m..n */
                 int notlast = (k != n - 1);
+                int ex = 0;
                 dbg_ksteps++;
                 if (k != m) {
                     p = H[k][k - 1]; q = H[k + 1][k - 1]; r = notlast ? H[k + 2][k - 1] : 0.0;
                     x = fabs(p) + fabs(q) + fabs(r);
                     if (x == 0.0) continue;
-                    p = p / x; q = q / x; r = r / x;
+                    (void)frexp(x, &ex);                 /* exact power-of-two scaling, see above */
+                    p = ldexp(p, -ex); q = ldexp(q, -ex); r = ldexp(r, -ex);
                 }
                 s = sqrt(p * p + q * q + r * r);
                 if (p < 0) s = -s;
                 if (s != 0.0) {
-                    if (k != m) H[k][k - 1] = -s * x;
+                    if (k != m) H[k][k - 1] = ldexp(-s, ex);
                     else if (l != m) H[k][k - 1] = -H[k][k - 1];
                     p = p + s;
                     x = p / s; y = q / s; z = r / s;
