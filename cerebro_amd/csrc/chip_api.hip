@@ -164,6 +164,7 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
     c->scan_blocks_per_cu = env_int("CHIP_SCAN_BPC", 2);
     if (c->scan_blocks_per_cu < 1) c->scan_blocks_per_cu = 1;
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);
+    c->scan_reserve = env_int("CHIP_SCAN_RESERVE", 0);
     c->max_grid = 512;  // K2 (one 512-thread workgroup) keeps one partial list per thread
     {
         const int pr = env_int("CHIP_SCAN_STREAM_PRIORITY", 0);   // tuning only: 0 = default class, 1 = highest, -1 = lowest

@@ -114,6 +114,7 @@ struct Ctx {
     // --- scan tuning (resolved at create; CHIP_SCAN_* env overrides for A/B runs) ---
     int32_t scan_block = 0;       // 0 = auto
     int32_t scan_blocks_per_cu = 2;
+    int32_t scan_reserve = 0;
     int32_t scan_variant = 0;
 
     // --- profiling ---
