@@ -115,6 +115,8 @@ _SIGS = {
     "chip_icp_params_default": (None, [C.POINTER(RansacParams)]),
     "chip_icp_ransac": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(RansacParams), _P, C.POINTER(C.c_float), _P,
                                   C.POINTER(RansacSummary)]),
+    "chip_icp_ransac_enqueue": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(RansacParams)]),
+    "chip_icp_ransac_collect": (C.c_int, [_P, _P, C.POINTER(C.c_float), _P, C.POINTER(RansacSummary)]),
     "chip_get_info": (C.c_int, [_P, C.POINTER(Info)]),
     "chip_profile_enable": (C.c_int, [_P, C.c_int32]),
     "chip_profile_reset": (C.c_int, [_P]),
@@ -381,6 +383,24 @@ class Chip:
                      summary=dict(n_iterations=summ[i].n_iterations, n_inliers=summ[i].n_inliers,
                                   best_hypothesis=summ[i].best_hypothesis, n_models=summ[i].n_models,
                                   best_cost=summ[i].best_cost)) for i in range(P)]
+
+    def icp_ransac_enqueue(self, A: np.ndarray, B: np.ndarray, params: RansacParams | None = None):
+        """start an ICP estimation on the ctx's ICP stream (returns at once); fetch it with icp_ransac_collect(N)"""
+        A = np.ascontiguousarray(A, dtype=np.float64).reshape(-1, 3)
+        B = np.ascontiguousarray(B, dtype=np.float64).reshape(-1, 3)
+        p = params or default_icp_params()
+        self._chk(self.lib.chip_icp_ransac_enqueue(self.h, _ptr(A), _ptr(B), A.shape[0], C.byref(p)), "chip_icp_ransac_enqueue")
+        return A.shape[0]
+
+    def icp_ransac_collect(self, N: int):
+        T = np.empty(16, dtype=np.float64)
+        conf = C.c_float()
+        mask = np.zeros(max(N, 1), dtype=np.uint8)
+        summ = RansacSummary()
+        self._chk(self.lib.chip_icp_ransac_collect(self.h, _ptr(T), C.byref(conf), _ptr(mask), C.byref(summ)), "chip_icp_ransac_collect")
+        return dict(status=0, confidence=float(conf.value), T=T.reshape(4, 4).T.copy(), mask=mask[:N].copy(),
+                    summary=dict(n_iterations=summ.n_iterations, n_inliers=summ.n_inliers, best_hypothesis=summ.best_hypothesis,
+                                 n_models=summ.n_models, best_cost=summ.best_cost))
 
     def icp_ransac(self, A: np.ndarray, B: np.ndarray, params: RansacParams | None = None):
         A = np.ascontiguousarray(A, dtype=np.float64).reshape(-1, 3)

@@ -77,6 +77,7 @@ struct Ctx {
     std::mutex append_mu;                // serialises appenders
     std::mutex query_mu;                 // serialises queriers (scratch buffers are per ctx)
     std::mutex pnp_mu;
+    std::mutex icp_mu;            // ICP has its own stream and lock: it may run underneath a PnP call
 
     // --- streams ---
     hipStream_t s_query = nullptr, s_append = nullptr, s_pnp = nullptr;

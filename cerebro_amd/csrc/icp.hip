@@ -187,19 +187,26 @@ struct IcpState {
     double *h_cost = nullptr, *h_T = nullptr;
     int32_t *h_nin = nullptr, *h_valid = nullptr;
     unsigned long long *h_mask = nullptr;
+    hipStream_t stream = nullptr;      // the ICP stream (not the PnP stream: the two estimations may overlap)
+    bool pending = false;              // an enqueued estimation awaits chip_icp_ransac_collect
+    int32_t pend_N = 0, pend_H = 0;
+    chip_ransac_params pend_params{};
 };
 
 static void icp_free(IcpState *st)
 {
     (void)hipFree(st->A); (void)hipFree(st->B);   // T_out/cost/nin/valid/mask are device views of the pinned host buffers below
     (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid); (void)hipHostFree(st->h_mask);
+    const hipStream_t keep = st->stream;   // buffers are regrown, the stream lives as long as the ctx
     *st = IcpState();
+    st->stream = keep;
 }
 
 void icp_destroy(Ctx *c)
 {
     IcpState *st = static_cast<IcpState *>(c->icp_state);
     if (!st) return;
+    if (st->stream) { (void)hipStreamSynchronize(st->stream); (void)hipStreamDestroy(st->stream); st->stream = nullptr; }
     icp_free(st);
     delete st;
     c->icp_state = nullptr;
@@ -240,25 +247,25 @@ extern "C" void chip_icp_params_default(chip_ransac_params *p)
     p->sample_size = 10;    // DlsPnpWithRansac.h:118
 }
 
-extern "C" int chip_icp_ransac(chip_ctx *c, const double *A, const double *B, int32_t N, const chip_ransac_params *p,
-                               double T_colmajor[16], float *confidence, uint8_t *inlier_mask, chip_ransac_summary *summary)
+// The estimation is split in two so that it can run underneath something else (its kernel is tiny and the PnP kernels leave
+// the GPU 92-95 % idle): enqueue = H2D of the points + the kernel on the ICP stream, no synchronisation; collect = wait, replay
+// theia's selection rule, fetch the winner.  chip_icp_ransac is enqueue + collect.
+static int icp_enqueue_locked(chip_ctx *c, const double *A, const double *B, int32_t N, const chip_ransac_params *p)
 {
-    if (!c || !A || !B || !p || !T_colmajor || !confidence) return CHIP_ERR_INVALID_ARG;
-    if (N < 20) return CHIP_ERR_TOO_FEW_POINTS;  // DlsPnpWithRansac.cpp:19-22
-    const int32_t S = p->sample_size;
-    if (S < 3 || S > kSampleMax || S > N || p->n_hypotheses < 0 || p->max_iterations < 1) return CHIP_ERR_UNSUPPORTED;
-    std::lock_guard<std::mutex> lk(c->pnp_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
     if (!c->icp_state) {
         c->icp_state = new (std::nothrow) IcpState();
         if (!c->icp_state) return CHIP_ERR_OOM;
     }
     IcpState *st = static_cast<IcpState *>(c->icp_state);
+    if (st->pending) return CHIP_ERR_BUSY;
+    if (!st->stream) CHIP_HIP(c, hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
+    const int32_t S = p->sample_size;
     const int H = ransac_initial_iterations(p);
     int rc = icp_reserve(c, st, N, H);
     if (rc != CHIP_OK) return rc;
     const int words = (N + 63) / 64;
-    hipStream_t s = c->s_pnp;
+    hipStream_t s = st->stream;
     CHIP_HIP(c, hipMemcpyAsync(st->A, A, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, s));
     CHIP_HIP(c, hipMemcpyAsync(st->B, B, sizeof(double) * 3 * (size_t)N, hipMemcpyHostToDevice, s));
     IcpArgs a;
@@ -266,7 +273,21 @@ extern "C" int chip_icp_ransac(chip_ctx *c, const double *A, const double *B, in
     a.mask_words = words; a.T_out = st->T_out; a.cost = st->cost; a.nin = st->nin; a.valid = st->valid; a.mask = st->mask;
     hipLaunchKernelGGL(icp_hyp_score, dim3(H), dim3(64), 0, s, a);
     CHIP_HIP(c, hipGetLastError());
-    CHIP_HIP(c, hipStreamSynchronize(s));
+    st->pending = true;
+    st->pend_N = N; st->pend_H = H; st->pend_params = *p;
+    return CHIP_OK;
+}
+
+static int icp_collect_locked(chip_ctx *c, double T_colmajor[16], float *confidence, uint8_t *inlier_mask, chip_ransac_summary *summary)
+{
+    IcpState *st = static_cast<IcpState *>(c->icp_state);
+    if (!st || !st->pending) return CHIP_ERR_BUSY;
+    CHIP_HIP(c, hipSetDevice(c->device));
+    CHIP_HIP(c, hipStreamSynchronize(st->stream));
+    st->pending = false;
+    const chip_ransac_params *p = &st->pend_params;
+    const int32_t N = st->pend_N, S = p->sample_size;
+    const int H = st->pend_H, words = (N + 63) / 64;
     double best_cost = DBL_MAX;
     int32_t n_models = 0, num_it = 0;
     const int32_t best_h = ransac_select(p, N, H, st->h_valid, st->h_cost, st->h_nin, &num_it, &n_models, &best_cost);
@@ -292,4 +313,41 @@ extern "C" int chip_icp_ransac(chip_ctx *c, const double *A, const double *B, in
         summary->best_cost = best_h >= 0 ? best_cost : INFINITY;
     }
     return CHIP_OK;
+}
+
+static int icp_check_args(const double *A, const double *B, int32_t N, const chip_ransac_params *p)
+{
+    if (!A || !B || !p) return CHIP_ERR_INVALID_ARG;
+    if (N < 20) return CHIP_ERR_TOO_FEW_POINTS;  // DlsPnpWithRansac.cpp:19-22
+    const int32_t S = p->sample_size;
+    if (S < 3 || S > kSampleMax || S > N || p->n_hypotheses < 0 || p->max_iterations < 1) return CHIP_ERR_UNSUPPORTED;
+    return CHIP_OK;
+}
+
+extern "C" int chip_icp_ransac_enqueue(chip_ctx *c, const double *A, const double *B, int32_t N, const chip_ransac_params *p)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    const int rc = icp_check_args(A, B, N, p);
+    if (rc != CHIP_OK) return rc;
+    std::lock_guard<std::mutex> lk(c->icp_mu);
+    return icp_enqueue_locked(c, A, B, N, p);
+}
+
+extern "C" int chip_icp_ransac_collect(chip_ctx *c, double T_colmajor[16], float *confidence, uint8_t *inlier_mask, chip_ransac_summary *summary)
+{
+    if (!c || !T_colmajor || !confidence) return CHIP_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->icp_mu);
+    return icp_collect_locked(c, T_colmajor, confidence, inlier_mask, summary);
+}
+
+extern "C" int chip_icp_ransac(chip_ctx *c, const double *A, const double *B, int32_t N, const chip_ransac_params *p,
+                               double T_colmajor[16], float *confidence, uint8_t *inlier_mask, chip_ransac_summary *summary)
+{
+    if (!c || !T_colmajor || !confidence) return CHIP_ERR_INVALID_ARG;
+    int rc = icp_check_args(A, B, N, p);
+    if (rc != CHIP_OK) return rc;
+    std::lock_guard<std::mutex> lk(c->icp_mu);
+    rc = icp_enqueue_locked(c, A, B, N, p);
+    if (rc != CHIP_OK) return rc;
+    return icp_collect_locked(c, T_colmajor, confidence, inlier_mask, summary);
 }

@@ -365,9 +365,12 @@ bool compute_three_way_pose(chip_ctx *ctx, const PosePairInput &in, ProcessedLoo
     chip_icp_params_default(&pi);
     if (seed) { pp.seed = seed; pi.seed = seed ^ 0x9E3779B97F4A7C15ull; }
     std::array<double, 16> op1{}, op2_a_T_b{}, op2{}, icp{};
-    std::string m3;
-    // Cerebro.cpp:1518 PNP(a->b) and :1572 PNP(b->a) are independent: both go into one pair of launches (seeds seed, seed+1).
-    float g1 = -1.f, g2 = -1.f;
+    // The three estimations of an image pair are independent.  P3P_ICP (:1629) is enqueued first on the ICP stream; the two PNP
+    // calls (:1518 a->b, :1572 b->a; seeds seed, seed+1) share one pair of launches; the ICP result is collected afterwards --
+    // its kernel has long finished underneath the PnP kernels.
+    float g1 = -1.f, g2 = -1.f, g3 = -1.f;
+    const bool icp_ok = in.uv_X.size() >= 20 && in.uv_X.size() == in.uvd_Y.size() &&
+                        chip_icp_ransac_enqueue(ctx, &in.uv_X[0][0], &in.uvd_Y[0][0], (int32_t)in.uv_X.size(), &pi) == CHIP_OK;
     if (in.world_point_uv.size() >= 20 && in.world_point_uv_d.size() >= 20 && in.world_point_uv.size() == in.feature_position_uv_d.size() &&
         in.world_point_uv_d.size() == in.feature_position_uv.size()) {   // the < 20 guard of PNP (DlsPnpWithRansac.cpp:136-139)
         const double *Xs[2] = {&in.world_point_uv[0][0], &in.world_point_uv_d[0][0]};
@@ -383,7 +386,10 @@ bool compute_three_way_pose(chip_ctx *ctx, const PosePairInput &in, ProcessedLoo
         }
     }
     matrix4_inverse_rigid(op2_a_T_b.data(), op2.data());                                                                          // :1582
-    const float g3 = StaticTheiaPoseComputeICP::P3P_ICP(ctx, in.uv_X, in.uvd_Y, icp.data(), m3, &pi);                               // :1629
+    if (icp_ok) {
+        float c3 = 0.f;
+        if (chip_icp_ransac_collect(ctx, icp.data(), &c3, nullptr, nullptr) == CHIP_OK) g3 = c3;                                   // :1629
+    }
     for (int i = 0; i < 16; i++)  // :1678  op != op  <=> any NaN
         if (op1[i] != op1[i] || op2[i] != op2[i] || icp[i] != icp[i]) return false;
     if (g1 < 0 || g2 < 0 || g3 < 0) return false;  // a too-small set leaves the pose untouched in the reference; treat as no pose

@@ -233,6 +233,15 @@ void chip_icp_params_default(chip_ransac_params *p);
 int chip_icp_ransac(chip_ctx *ctx, const double *A, const double *B, int32_t N, const chip_ransac_params *p,
                     double T_colmajor[16], float *confidence, uint8_t *inlier_mask /* N bytes, may be NULL */,
                     chip_ransac_summary *summary /* may be NULL */);
+/* The same estimation in two halves, so that it can run underneath something else -- the loop-candidate consumer computes
+ * PNP(a->b), PNP(b->a) and P3P_ICP for one image pair (src/Cerebro.cpp:1518,1572,1629), and the ICP kernel is tiny:
+ *   chip_icp_ransac_enqueue : copies A, B (the call returns once they are staged) and launches on the ctx's ICP stream;
+ *   chip_icp_ransac_collect : waits for it and delivers exactly what chip_icp_ransac would have returned.
+ * One estimation may be pending per ctx (a second enqueue, or a collect without enqueue: CHIP_ERR_BUSY).                 */
+int chip_icp_ransac_enqueue(chip_ctx *ctx, const double *A, const double *B, int32_t N, const chip_ransac_params *p);
+int chip_icp_ransac_collect(chip_ctx *ctx, double T_colmajor[16], float *confidence, uint8_t *inlier_mask /* may be NULL */,
+                            chip_ransac_summary *summary /* may be NULL */);
+
 
 /* ------------------------------------------------------------------------------------------ introspection */
 typedef struct {

@@ -61,3 +61,25 @@ def test_scale_gate_and_edges():
         Ap = A.copy(); Ap[:, 2] = 1.0                              # coplanar source points (rank-2 branch)
         Bp = Ap @ T[:3, :3].T + T[:3, 3]
         check(chip, Ap, Bp, seed=4, n_hypotheses=32)
+
+
+def test_enqueue_collect_equals_the_blocking_call_and_overlaps_pnp():
+    import np_mirror_pnp as M
+    A, B, T, inl = make_icp_scene(N=400, outlier_frac=0.25, noise=0.02, seed=11)
+    X, uv, Tp, _ = M.make_scene(N=300, outlier_frac=0.2, noise_px=0.5, seed=5)
+    with capi.Chip(256) as chip:
+        p = capi.default_icp_params(); p.seed = 77
+        want = chip.icp_ransac(A, B, p)
+        n = chip.icp_ransac_enqueue(A, B, p)
+        with pytest.raises(capi.ChipError):                      # one estimation may be pending
+            chip.icp_ransac_enqueue(A, B, p)
+        pp = capi.default_ransac_params(); pp.seed = 9
+        g = chip.pnp_ransac(X, uv, pp)                           # runs while the ICP kernel is in flight on its own stream
+        got = chip.icp_ransac_collect(n)
+        assert got["summary"] == want["summary"] and got["confidence"] == want["confidence"]
+        assert np.array_equal(got["T"].view(np.uint64), want["T"].view(np.uint64)) and np.array_equal(got["mask"], want["mask"])
+        o = O.pnp_ransac(X, uv, O.ransac_params(seed=9))
+        assert np.array_equal(g["T"].view(np.uint64), o["T"].view(np.uint64))
+        with pytest.raises(capi.ChipError):                      # nothing pending any more
+            chip.icp_ransac_collect(n)
+        assert chip.icp_ransac(A, B, p)["summary"] == want["summary"]
