@@ -1071,7 +1071,8 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
 struct PnpState {
     PnpTables *tab_dev = nullptr;
     // device scratch, grown on demand
-    double *X = nullptr, *uv = nullptr;
+    double *X = nullptr, *uv = nullptr;   // device: one allocation, [X of all problems | uv of all problems]
+    double *h_in = nullptr;               // pinned staging of the same layout: one DMA per call instead of 2 pageable copies per problem
     int32_t cap_N = 0;
     double *Sg = nullptr, *Tg = nullptr;
     int32_t *sample = nullptr, *ok = nullptr;
@@ -1102,7 +1103,7 @@ int pnp_create(Ctx *c)
 
 static void pnp_free_dev(PnpState *st)
 {
-    (void)hipFree(st->X); (void)hipFree(st->uv);
+    (void)hipFree(st->X); (void)hipHostFree(st->h_in);   // uv lives inside the X allocation
     (void)hipFree(st->Sg); (void)hipFree(st->Tg);
     (void)hipFree(st->sample); (void)hipFree(st->ok);
     (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid);
@@ -1122,10 +1123,10 @@ void pnp_destroy(Ctx *c)
 static int pnp_reserve(Ctx *c, PnpState *st, int N, int H, int words, int P)
 {
     if (N > st->cap_N) {
-        (void)hipFree(st->X); (void)hipFree(st->uv);
-        st->X = st->uv = nullptr; st->cap_N = 0;
-        CHIP_HIP(c, hipMalloc(&st->X, sizeof(double) * 3 * (size_t)N));
-        CHIP_HIP(c, hipMalloc(&st->uv, sizeof(double) * 2 * (size_t)N));
+        (void)hipFree(st->X); (void)hipHostFree(st->h_in);
+        st->X = st->uv = st->h_in = nullptr; st->cap_N = 0;
+        CHIP_HIP(c, hipMalloc(&st->X, sizeof(double) * 5 * (size_t)N));
+        CHIP_HIP(c, hipHostMalloc(&st->h_in, sizeof(double) * 5 * (size_t)N, hipHostMallocDefault));
         st->cap_N = N;
     }
     if (H > st->cap_H || words > st->cap_words) {
@@ -1175,15 +1176,17 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
     EigArgs ea;
     std::memset(&sa, 0, sizeof sa);
     std::memset(&ea, 0, sizeof ea);
+    st->uv = st->X + 3 * (size_t)Ntot;
     for (int i = 0, off = 0; i < P; off += N[i], i++) {
-        CHIP_HIP(c, hipMemcpyAsync(st->X + 3 * (size_t)off, X[i], sizeof(double) * 3 * (size_t)N[i], hipMemcpyHostToDevice, s));
-        CHIP_HIP(c, hipMemcpyAsync(st->uv + 2 * (size_t)off, uv[i], sizeof(double) * 2 * (size_t)N[i], hipMemcpyHostToDevice, s));
+        std::memcpy(st->h_in + 3 * (size_t)off, X[i], sizeof(double) * 3 * (size_t)N[i]);
+        std::memcpy(st->h_in + 3 * (size_t)Ntot + 2 * (size_t)off, uv[i], sizeof(double) * 2 * (size_t)N[i]);
         PnpProblem pr;
         pr.X = st->X + 3 * (size_t)off; pr.uv = st->uv + 2 * (size_t)off; pr.N = N[i]; pr.pad_ = 0;
         pr.seed = seeds ? seeds[i] : p->seed;
         sa.prob[i] = pr;
         ea.prob[i] = pr;
     }
+    CHIP_HIP(c, hipMemcpyAsync(st->X, st->h_in, sizeof(double) * 5 * (size_t)Ntot, hipMemcpyHostToDevice, s));
     sa.H = H; sa.S = S; sa.tab = st->tab_dev;
     sa.Sg = st->Sg; sa.Tg = st->Tg; sa.sample = st->sample; sa.ok = st->ok;
     const size_t lds = kSolveLds;
