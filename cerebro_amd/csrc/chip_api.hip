@@ -143,6 +143,9 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
     if (shift < 6) shift = 6;
     c->seg_shift = shift;
     c->seg_rows = 1ll << shift;
+    // The querier reads segs[] without c->mu (row_ptr_host) while the appender may open a new segment: reserve the whole
+    // table (32 KiB) so that push_back never reallocates -- entries below the published length are immutable.
+    c->segs.reserve(kMaxSegs);
 
     CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_query, hipStreamNonBlocking));
     CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_append, hipStreamNonBlocking));
@@ -250,6 +253,7 @@ static int enqueue_scan_merge(Ctx *c, int64_t k, const float *const *q, int nq, 
     if (rc != CHIP_OK) return rc;
     if (e1) CHIP_HIP(c, hipEventRecord(e1, s_scan));
     CHIP_HIP(c, hipEventRecord(c->ev_scan[b], s_scan));
+    if (c->ring_dev) c->last_scan_ev[s_scan == c->s_scan2 ? 1 : 0] = c->ev_scan[b];   // caller holds ring_mu (RingGuard)
     CHIP_HIP(c, hipStreamWaitEvent(c->s_query, c->ev_scan[b], 0));
 
     MergeArgs m;
@@ -267,6 +271,16 @@ static int enqueue_scan_merge(Ctx *c, int64_t k, const float *const *q, int nq, 
     return CHIP_OK;
 }
 
+// Sharded ctx: the query rows of a scan are read from the replicated ring, which the appender overwrites in place.  A
+// querier holds ring_mu from the residency check until the scan's completion event is recorded (RingGuard); the appender
+// announces the length its call will reach (rows_pending) and picks up the newest scan events under the same lock before it
+// touches the ring, and its ring writes wait for those scans.  So a scan either was validated against the post-append
+// length, or is ordered before the ring writes.
+struct RingGuard {
+    std::unique_lock<std::mutex> lk;
+    explicit RingGuard(Ctx *c) : lk(c->ring_mu, std::defer_lock) { if (c->ring_dev) lk.lock(); }
+};
+
 // Pointers of the query rows (device).  Single GPU: straight into the DB; sharded: the replicated ring.
 static int query_row_ptrs(Ctx *c, const int64_t *rows, int nq, int64_t n_global, const float **q)
 {
@@ -281,7 +295,9 @@ static int query_row_ptrs(Ctx *c, const int64_t *rows, int nq, int64_t n_global,
         if (c->nranks == 1) {
             q[i] = row_ptr_host(c, g);
         } else {
-            if (g < total - CHIP_RING_ROWS) return CHIP_ERR_RANGE;  // no longer in the replicated ring
+            // no longer in the replicated ring -- counting the rows of an append that is in flight right now
+            const int64_t horizon = c->rows_pending > total ? c->rows_pending : total;
+            if (g < horizon - CHIP_RING_ROWS) return CHIP_ERR_RANGE;
             q[i] = c->ring_dev + (g % CHIP_RING_ROWS) * (int64_t)c->D;
         }
     }
@@ -289,6 +305,9 @@ static int query_row_ptrs(Ctx *c, const int64_t *rows, int nq, int64_t n_global,
 }
 
 // Host part of the tick (Cerebro.cpp:960-966, :1019-1022, :1098).  Returns CHIP_TICK_* in *status.
+// last_l is NOT written here: the caller commits it (c->last_l = l) once the tick has actually been enqueued (or at once
+// for TOO_SHORT), so a failed enqueue leaves the state as the reference's loop would (it only reaches :1098 at the end of an
+// executed pass).
 static int tick_prepare(Ctx *c, int64_t l, const chip_dot_params *p, int32_t *status, int64_t *k_out)
 {
     int64_t n;
@@ -301,7 +320,6 @@ static int tick_prepare(Ctx *c, int64_t l, const chip_dot_params *p, int32_t *st
     if (l < 3) return CHIP_ERR_RANGE;  // needs descriptors l-1, l-2, l-3 (:987-989)
     const int64_t k = l - p->lag;      // :1019
     *k_out = k;
-    c->last_l = l;                     // :1098
     *status = (k > p->min_k) ? CHIP_TICK_SCANNED : CHIP_TICK_TOO_SHORT;  // :1022
     return CHIP_OK;
 }
@@ -322,6 +340,7 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
     int rc = tick_prepare(c, l, p, &status, &k);
     if (rc != CHIP_OK) return rc;
     if (status != CHIP_TICK_SCANNED) {
+        if (status == CHIP_TICK_TOO_SHORT) c->last_l = l;   // :1098 (the else-branch of :1022 still ends the pass)
         fill_immediate(s.host, status);
         s.immediate = true;
         s.in_flight = true;
@@ -329,11 +348,13 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
     }
     const int64_t rows[3] = {l - 1, l - 2, l - 3};  // v, vm, vmm (:987-989)
     const float *q[3];
+    RingGuard rg(c);
     rc = query_row_ptrs(c, rows, 3, l, q);
     if (rc != CHIP_OK) return rc;
     rc = enqueue_scan_merge(c, k, q, 3, CHIP_DEFAULT_TOPK, l, p, nullptr, s.dev, true);
     if (rc != CHIP_OK) return rc;
     CHIP_HIP(c, hipEventRecord(s.done, c->s_query));
+    c->last_l = l;                     // :1098
     s.immediate = false;
     s.in_flight = true;
     return CHIP_OK;
@@ -400,6 +421,15 @@ static int append_impl(Ctx *c, const T *desc, int64_t n, uint32_t flags, int64_t
     if ((bad & 1u) && !(flags & CHIP_APPEND_ALLOW_ROUNDING)) return CHIP_ERR_NOT_F32;
 
     if (c->ring_dev) {  // sharded: mirror the newest rows into the replicated ring (DB store is idempotent)
+        hipEvent_t ev[2];
+        {
+            std::lock_guard<std::mutex> rl(c->ring_mu);
+            c->rows_pending = first + n;        // queriers now validate ring residency against the length after this call
+            ev[0] = c->last_scan_ev[0];
+            ev[1] = c->last_scan_ev[1];
+        }
+        for (hipEvent_t e : ev)                 // scans already enqueued read their queries before the ring is overwritten
+            if (e) CHIP_HIP(c, hipStreamWaitEvent(c->s_append, e, 0));
         const int64_t m = n < CHIP_RING_ROWS ? n : CHIP_RING_ROWS;
         rc = pass(n - m, m, true);
         if (rc != CHIP_OK) return rc;
@@ -547,6 +577,17 @@ int chip_db_append_synthetic(chip_ctx *c, int64_t n, uint64_t seed,
         CHIP_HIP(c, hipMemcpyAsync(ps, plant_src, n_plant * sizeof(int64_t), hipMemcpyHostToDevice, c->s_append));
         CHIP_HIP(c, hipMemcpyAsync(pk, plant_kind, n_plant * sizeof(int32_t), hipMemcpyHostToDevice, c->s_append));
     }
+    if (c->ring_dev) {   // same ordering against in-flight scans as append_impl
+        hipEvent_t ev[2];
+        {
+            std::lock_guard<std::mutex> rl(c->ring_mu);
+            c->rows_pending = first + n;
+            ev[0] = c->last_scan_ev[0];
+            ev[1] = c->last_scan_ev[1];
+        }
+        for (hipEvent_t e : ev)
+            if (e) (void)hipStreamWaitEvent(c->s_append, e, 0);
+    }
     rc = launch_synth(c, c->s_append, first, n, seed, pd, ps, pk, n_plant);
     hipError_t e = hipStreamSynchronize(c->s_append);
     if (pd) (void)hipFree(pd);
@@ -584,6 +625,7 @@ int chip_query_rows(chip_ctx *c, int64_t k, const int64_t *query_rows, int32_t n
     std::lock_guard<std::mutex> qlk(c->query_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
     const float *q[CHIP_MAX_NQ];
+    RingGuard rg(c);
     rc = query_row_ptrs(c, query_rows, nq, n, q);
     if (rc != CHIP_OK) return rc;
     rc = enqueue_scan_merge(c, k, q, nq, topk, 0, nullptr, c->topk_dev, nullptr);
@@ -638,8 +680,18 @@ int chip_loop_tick_collect(chip_ctx *c, int32_t slot, chip_tick_result *out)
     return tick_collect_slot(c, c->slots[slot], out);
 }
 
-int64_t chip_loop_last_l(const chip_ctx *c) { return c ? c->last_l : CHIP_ERR_INVALID_ARG; }
-void chip_loop_reset(chip_ctx *c) { if (c) c->last_l = 0; }
+int64_t chip_loop_last_l(const chip_ctx *c)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    return c->last_l;
+}
+void chip_loop_reset(chip_ctx *c)
+{
+    if (!c) return;
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    c->last_l = 0;
+}
 
 int chip_scan_local(chip_ctx *c, int64_t l, const chip_dot_params *p, int32_t topk, void *dev_out, int32_t *status)
 {
@@ -649,15 +701,19 @@ int chip_scan_local(chip_ctx *c, int64_t l, const chip_dot_params *p, int32_t to
     CHIP_HIP(c, hipSetDevice(c->device));
     int64_t k = 0;
     int rc = tick_prepare(c, l, p, status, &k);
+    if (rc == CHIP_OK && *status == CHIP_TICK_TOO_SHORT) c->last_l = l;
     if (rc != CHIP_OK || *status != CHIP_TICK_SCANNED) return rc;
     const int64_t rows[3] = {l - 1, l - 2, l - 3};
     const float *q[3];
+    RingGuard rg(c);
     rc = query_row_ptrs(c, rows, 3, l, q);
     if (rc != CHIP_OK) return rc;
     // scan on s_scan, then (behind an event) the local merge on the ctx stream writes this rank's 3 x topk list to
     // dev_out: everything the caller enqueues next on the ctx stream (the all-gather) is ordered after it, while the
     // next tick's scan is free to start as soon as this scan ends.
-    return enqueue_scan_merge(c, k, q, 3, topk, l, nullptr, (chip_topk_entry *)dev_out, nullptr, true);
+    rc = enqueue_scan_merge(c, k, q, 3, topk, l, nullptr, (chip_topk_entry *)dev_out, nullptr, true);
+    if (rc == CHIP_OK) c->last_l = l;  // :1098
+    return rc;
 }
 
 static int merge_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, const void *dev_gathered, int32_t n_lists, int32_t topk, Slot &s)

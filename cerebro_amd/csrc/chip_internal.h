@@ -43,7 +43,6 @@ struct Ctx;
 int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid);
 int launch_merge(Ctx *c, hipStream_t s, const MergeArgs &a, int nq);
 int scan_grid_for(const Ctx *c, int64_t n_rows, int nq);
-int scan_configure(Ctx *c);  // one-time function attributes (dynamic LDS size)
 int launch_narrow_f64(Ctx *c, hipStream_t s, const double *src, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring);
 int launch_copy_f32(Ctx *c, hipStream_t s, const float *src, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring);
 int launch_synth(Ctx *c, hipStream_t s, int64_t first_global, int64_t n, uint64_t seed,
@@ -75,7 +74,10 @@ struct Ctx {
     int64_t lossy_rows = 0;
     mutable std::mutex mu;               // guards rows_*, segs growth
     std::mutex append_mu;                // serialises appenders
-    std::mutex query_mu;                 // serialises queriers (scratch buffers are per ctx)
+    mutable std::mutex query_mu;         // serialises queriers (scratch buffers are per ctx); guards last_l
+    std::mutex ring_mu;                  // sharded: ring residency check .. scan event  vs  the appender's ring writes
+    int64_t rows_pending = 0;            // length an in-flight append will publish (ring_mu)
+    hipEvent_t last_scan_ev[2] = {};     // newest scan per scan stream (ring_mu)
     std::mutex pnp_mu;
     std::mutex icp_mu;            // ICP has its own stream and lock: it may run underneath a PnP call
 

@@ -500,6 +500,4 @@ int launch_synth(Ctx *c, hipStream_t s, int64_t first_global, int64_t n, uint64_
     return CHIP_OK;
 }
 
-int scan_configure(Ctx *) { return CHIP_OK; }
-
 }  // namespace chip

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <sstream>
 #include <thread>
+#include <unordered_map>
 
 namespace cerebro_hip {
 
@@ -216,10 +217,13 @@ std::string Cerebro::foundLoops_as_JSON() const
         std::lock_guard<std::mutex> lk(m_wholeImageComputedList);
         stamps = wholeImageComputedList;
     }
+    // stamp -> first row carrying it (one pass; a 1M-row DB made the former linear search per loop quadratic)
+    std::unordered_map<uint64_t, long> first_row;
+    first_row.reserve(stamps.size());
+    for (size_t i = 0; i < stamps.size(); i++) first_row.emplace(((uint64_t)stamps[i].sec << 32) | stamps[i].nsec, (long)i);
     auto index_of = [&](const Time &t) {
-        for (size_t i = 0; i < stamps.size(); i++)
-            if (stamps[i] == t) return (long)i;
-        return -1L;
+        auto it = first_row.find(((uint64_t)t.sec << 32) | t.nsec);
+        return it == first_row.end() ? -1L : it->second;
     };
     std::ostringstream o;
     o.precision(17);

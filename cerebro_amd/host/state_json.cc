@@ -1,6 +1,7 @@
 // state_json.cc -- minimal, dependency-free JSON walk that materialises only what the descriptor DB needs.
 #include "state_json.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <charconv>
@@ -12,9 +13,13 @@
 namespace cerebro_hip {
 namespace {
 
+constexpr int kMaxDepth = 64;          // nesting cap of skipped values (DataManager's state.json nests 4 deep)
+constexpr int64_t kMaxDescriptor = 10240;  // == the largest D chip_create accepts (4 queries x D floats in 160 KiB of LDS)
+
 struct Cur {
     const char *p, *end;
     std::string err;
+    int depth = 0;
     bool fail(const char *m) { if (err.empty()) err = m; return false; }
     void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
     bool lit(const char *s) { size_t n = std::strlen(s); if ((size_t)(end - p) >= n && std::memcmp(p, s, n) == 0) { p += n; return true; } return false; }
@@ -61,9 +66,17 @@ bool parse_string(Cur &c, std::string *out)
 
 bool skip_value(Cur &c);
 
+struct DepthGuard {
+    Cur &c;
+    explicit DepthGuard(Cur &cc) : c(cc) { c.depth++; }
+    ~DepthGuard() { c.depth--; }
+};
+
 bool skip_container(Cur &c, char open, char close)
 {
     (void)open;
+    DepthGuard g(c);
+    if (c.depth > kMaxDepth) return c.fail("nesting too deep");
     c.p++;
     c.ws();
     if (c.p < c.end && *c.p == close) { c.p++; return true; }
@@ -238,6 +251,8 @@ bool parse_node(Cur &c, StateDescriptors &out, std::vector<DataSpan> &spans)
     out.n_nodes++;
     if (have_desc && available != 0) {   // DataManager::loadStateFromDisk only restores it when the flag is set
         if (!have_stamp) return c.fail("node with descriptor but no stampNSec");
+        if (sp.rows > kMaxDescriptor || sp.cols > kMaxDescriptor || sp.rows * sp.cols > kMaxDescriptor)
+            return c.fail("wholeImageDescriptor: rows*cols out of range");
         const int D = (int)(sp.rows * sp.cols);
         if (out.D == 0) out.D = D;
         if (D != out.D) return c.fail("descriptor size differs between nodes");
@@ -290,6 +305,10 @@ bool parse_state_json(const std::string &text, StateDescriptors &out)
     }
     if (c.err.empty() && !seen) c.err = "no DataNodes array";
     if (c.err.empty() && !spans.empty()) {
+        // The reference rebuilds wholeImageComputedList by iterating the time-sorted data_map (Cerebro.cpp:145-149), so row
+        // order is time order whatever the order of the array in the file (stable: equal stamps keep file order).
+        std::stable_sort(spans.begin(), spans.end(), [](const DataSpan &a, const DataSpan &b) { return a.stamp < b.stamp; });
+        for (size_t i = 0; i < spans.size(); i++) out.stampNSec[i] = spans[i].stamp;
         // second pass: number conversion, descriptors split evenly over the threads
         const size_t n = spans.size(), D = (size_t)out.D;
         out.desc.resize(n * D);

@@ -8,6 +8,7 @@ import pytest
 
 from cerebro_amd import capi
 
+pytestmark = pytest.mark.needs_hip_build   # uses libcerebro_hip.so / the host binaries (conftest skips these without hipcc)
 ROOT = Path(__file__).resolve().parent.parent
 
 

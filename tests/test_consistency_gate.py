@@ -11,6 +11,7 @@ import pytest
 
 import np_mirror_pnp as M
 
+pytestmark = pytest.mark.needs_hip_build   # uses libcerebro_hip.so / the host binaries (conftest skips these without hipcc)
 ROOT = Path(__file__).resolve().parent.parent
 REPLAY = ROOT / "cerebro_amd" / "lib" / "cerebro_replay"
 

@@ -10,6 +10,7 @@ import pytest
 import oracle_lib
 import scenarios
 
+pytestmark = pytest.mark.needs_hip_build   # uses libcerebro_hip.so / the host binaries (conftest skips these without hipcc)
 ROOT = Path(__file__).resolve().parent.parent
 LIB = ROOT / "cerebro_amd" / "lib"
 
@@ -162,6 +163,29 @@ def test_state_json_number_conversion_edge_cases(tmp_path):
                                     for i in range(N)]})
     rc, got = _parse_only(tmp_path, doc)
     assert rc == 0 and np.array_equal(got, vals2)
+
+
+def test_state_json_untrusted_input(tmp_path):
+    """The loader does not trust the file: nodes come back in time order whatever the order of the array (the reference
+    iterates the time-sorted data_map, Cerebro.cpp:145-149), absurd rows*cols and runaway nesting are errors, not crashes."""
+    D = 4
+    rows = {30: [3.0] * D, 10: [1.0] * D, 20: [2.0] * D, 15: [1.5] * D}
+    doc = json.dumps({"DataNodes": [{"stampNSec": s, "wholeImageDescriptor": {"rows": D, "cols": 1, "data": "\n".join(map(repr, v))}}
+                                    for s, v in rows.items()]})
+    (tmp_path / "t.json").write_text(doc)
+    r = subprocess.run([str(LIB / "cerebro_replay"), "--parse-only", str(tmp_path / "t.json"), str(tmp_path / "t.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = (tmp_path / "t.bin").read_bytes()
+    Dg, n = struct.unpack_from("<IQ", raw, 0)
+    assert list(np.frombuffer(raw, dtype=np.uint64, count=n, offset=12)) == [10, 15, 20, 30]
+    assert np.frombuffer(raw, dtype=np.float64, count=n * Dg, offset=12 + 8 * n).reshape(n, Dg)[:, 0].tolist() == [1.0, 1.5, 2.0, 3.0]
+    for rows_, cols_ in ((1 << 31, 2), (3_000_000_000, 3_000_000_000), (10241, 1), (4096, 4096)):
+        rc, err = _parse_only(tmp_path, json.dumps({"DataNodes": [{"stampNSec": 7, "wholeImageDescriptor": {"rows": rows_, "cols": cols_, "data": "1"}}]}))
+        assert rc == 6 and "out of range" in err, (rows_, cols_, err)
+    rc, err = _parse_only(tmp_path, '{"junk": ' + "[" * 100000 + "]" * 100000 + ', "DataNodes": []}')
+    assert rc == 6 and "nesting" in err
+    rc, got = _parse_only(tmp_path, '{"junk": ' + "[" * 60 + "]" * 60 + ', "DataNodes": []}')
+    assert rc == 0
 
 
 @pytest.mark.gpu
