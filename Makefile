@@ -1,7 +1,8 @@
 # Build of the MI355X loop-detection core (gfx950 only) and of the CPU oracle (test infrastructure).
 #   make            -> cerebro_amd/lib/libcerebro_hip.so  + oracle/_build/liboracle.so
 #   make lib / make oracle / make clean
-HIPCC      ?= /opt/rocm/bin/hipcc
+ROCM       ?= /opt/rocm
+HIPCC      ?= $(ROCM)/bin/hipcc
 ARCH       ?= gfx950
 # -ffp-contract=off: the PnP kernels must round exactly like the oracle (no FMA contraction);
 # the scan kernel uses explicit fma() where the product is exact.
@@ -12,7 +13,7 @@ ORCFLAGS   ?= -O2 -mfma -ffp-contract=off -fopenmp -fPIC -Wall -Wextra
 
 LIBDIR     := cerebro_amd/lib
 CSRC       := cerebro_amd/csrc
-HIP_SRCS   := $(CSRC)/kernels.hip $(CSRC)/chip_api.hip $(CSRC)/pnp.hip $(CSRC)/icp.hip $(CSRC)/batch.hip
+HIP_SRCS   := $(CSRC)/kernels.hip $(CSRC)/chip_api.hip $(CSRC)/chip_multi.hip $(CSRC)/pnp.hip $(CSRC)/icp.hip $(CSRC)/batch.hip
 HIP_OBJS   := $(HIP_SRCS:$(CSRC)/%.hip=$(LIBDIR)/%.o)
 ORC_SRCS   := $(wildcard oracle/*.c)
 
@@ -26,7 +27,7 @@ $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/chip_internal.h $(CSRC)/ransac_common.h $(C
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIBDIR)/libcerebro_hip.so: $(HIP_OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -L$(ROCM)/lib -lrccl -lpthread
 
 # ---- ROS-free C++ host side (mirror of the Cerebro / StaticTheiaPoseCompute::PNP surface) + replay harness ----
 HOSTDIR    := cerebro_amd/host

@@ -26,6 +26,7 @@ CHIP_ERR_RANGE = -7
 CHIP_ERR_UNSUPPORTED = -8
 CHIP_ERR_TOO_FEW_POINTS = -9
 CHIP_ERR_BUSY = -10
+CHIP_ERR_COMM = -11
 
 CHIP_MAX_TOPK = 16
 CHIP_MAX_NQ = 4
@@ -33,6 +34,11 @@ CHIP_DEFAULT_TOPK = 8
 CHIP_RING_ROWS = 4096
 CHIP_MAX_INFLIGHT = 64
 CHIP_APPEND_ALLOW_ROUNDING = 1
+CHIP_CREATE_STORE_F32 = 1
+CHIP_CREATE_STORE_F64 = 2
+CHIP_MULTI_EXCHANGE_COPY = 4
+CHIP_COMM_ID_BYTES = 128
+CHIP_EXCHANGE_NONE, CHIP_EXCHANGE_RCCL, CHIP_EXCHANGE_COPY = 0, 1, 2
 
 CHIP_TICK_SKIPPED, CHIP_TICK_TOO_SHORT, CHIP_TICK_SCANNED = 0, 1, 2
 
@@ -77,7 +83,8 @@ class Info(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("D", C.c_int32), ("device", C.c_int32), ("shard_rank", C.c_int32),
                 ("shard_count", C.c_int32), ("n_cus", C.c_int32), ("rows_global", C.c_int64),
                 ("rows_local", C.c_int64), ("capacity_local", C.c_int64), ("lossy_rows", C.c_int64),
-                ("arch", C.c_char * 32)]
+                ("arch", C.c_char * 32), ("storage_bytes", C.c_int32), ("n_devices", C.c_int32), ("exchange", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 # every symbol include/cerebro_hip.h declares: name -> (restype, argtypes)
@@ -86,7 +93,12 @@ _SIGS = {
     "chip_strerror": (C.c_char_p, [C.c_int]),
     "chip_abi_version": (C.c_int, []),
     "chip_last_hip_error": (C.c_int, [_P, C.POINTER(C.c_char_p)]),
+    "chip_last_comm_error": (C.c_int, [_P, C.POINTER(C.c_char_p)]),
     "chip_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "chip_create_ex": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_uint32]),
+    "chip_create_multi": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int64, _P, C.c_int32, C.c_uint32]),
+    "chip_comm_unique_id": (C.c_int, [_P]),
+    "chip_comm_init_rank": (C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     "chip_destroy": (None, [_P]),
     "chip_set_stream": (C.c_int, [_P, _P]),
     "chip_reset_stream": (C.c_int, [_P]),
@@ -95,9 +107,12 @@ _SIGS = {
     "chip_db_append_f32": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "chip_db_size": (C.c_int64, [_P]),
     "chip_db_read_rows_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "chip_db_read_rows_f64": (C.c_int, [_P, _P, C.c_int64, _P]),
     "chip_db_append_synthetic": (C.c_int, [_P, C.c_int64, C.c_uint64, _P, _P, _P, C.c_int64]),
     "chip_query_rows": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
     "chip_query_vectors_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
+    "chip_query_vectors_f64": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
+    "chip_query_scores": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "chip_query_batch_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
     "chip_dot_params_default": (None, [C.POINTER(DotParams)]),
     "chip_loop_tick": (C.c_int, [_P, C.c_int64, C.POINTER(DotParams), C.POINTER(TickResult)]),
@@ -187,18 +202,46 @@ def default_icp_params() -> RansacParams:
     return p
 
 
-class Chip:
-    """Thin RAII wrapper over a chip_ctx (one per process per GPU)."""
+def comm_unique_id() -> bytes:
+    """chip_comm_unique_id: 128 bytes rank 0 hands to every rank (any transport) before chip_comm_init_rank"""
+    buf = C.create_string_buffer(CHIP_COMM_ID_BYTES)
+    st = load_library().chip_comm_unique_id(buf)
+    if st != CHIP_OK:
+        raise ChipError(st, "chip_comm_unique_id")
+    return buf.raw
 
-    def __init__(self, D: int, capacity_hint: int = 0, device: int = 0, shard_rank: int = 0, shard_count: int = 1):
+
+class Chip:
+    """Thin RAII wrapper over a chip_ctx.  storage: None = decided by the data (chip_create), "f32" / "f64" = chip_create_ex.
+    devices=[...] makes ONE ctx over several GPUs of this process (chip_create_multi); copy_exchange forces the device-copy
+    exchange instead of RCCL (implied when a device is named twice)."""
+
+    def __init__(self, D: int, capacity_hint: int = 0, device: int = 0, shard_rank: int = 0, shard_count: int = 1,
+                 storage: str | None = None, devices=None, copy_exchange: bool = False):
         self.lib = load_library()
         self.D = int(D)
         self.shard_rank, self.shard_count = shard_rank, shard_count
+        flags = {None: 0, "f32": CHIP_CREATE_STORE_F32, "f64": CHIP_CREATE_STORE_F64}[storage]
         h = C.c_void_p()
-        st = self.lib.chip_create(C.byref(h), D, capacity_hint, device, shard_rank, shard_count)
+        if devices is not None:
+            dev = np.ascontiguousarray(devices, dtype=np.int32)
+            st = self.lib.chip_create_multi(C.byref(h), D, capacity_hint, _ptr(dev), dev.size,
+                                            flags | (CHIP_MULTI_EXCHANGE_COPY if copy_exchange else 0))
+            where = "chip_create_multi"
+        elif flags:
+            st = self.lib.chip_create_ex(C.byref(h), D, capacity_hint, device, shard_rank, shard_count, flags)
+            where = "chip_create_ex"
+        else:
+            st = self.lib.chip_create(C.byref(h), D, capacity_hint, device, shard_rank, shard_count)
+            where = "chip_create"
         if st != CHIP_OK:
-            raise ChipError(st, "chip_create")
+            raise ChipError(st, where)
         self.h = h
+
+    def comm_init_rank(self, unique_id: bytes, n_ranks: int, rank: int):
+        """attach an RCCL communicator to this sharded ctx (one process per GPU); afterwards loop_tick* work on it"""
+        assert len(unique_id) == CHIP_COMM_ID_BYTES
+        self._chk(self.lib.chip_comm_init_rank(self.h, C.c_char_p(unique_id), n_ranks, rank), "chip_comm_init_rank")
 
     # -- lifecycle
     def close(self):
@@ -221,6 +264,9 @@ class Chip:
     def _chk(self, st: int, where: str):
         if st != CHIP_OK:
             txt = C.c_char_p()
+            if st == CHIP_ERR_COMM:
+                r = self.lib.chip_last_comm_error(self.h, C.byref(txt))
+                raise ChipError(st, where, f"ncclResult {r}: {txt.value.decode() if txt.value else ''}")
             hip = self.lib.chip_last_hip_error(self.h, C.byref(txt)) if st in (CHIP_ERR_HIP, CHIP_ERR_OOM) else 0
             raise ChipError(st, where, f"hipError {hip}: {txt.value.decode() if txt.value else ''}" if hip else "")
 
@@ -269,7 +315,27 @@ class Chip:
         self._chk(self.lib.chip_db_read_rows_f32(self.h, _ptr(rows), rows.size, _ptr(out)), "chip_db_read_rows_f32")
         return out
 
+    def read_rows_f64(self, rows) -> np.ndarray:
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.empty((rows.size, self.D), dtype=np.float64)
+        self._chk(self.lib.chip_db_read_rows_f64(self.h, _ptr(rows), rows.size, _ptr(out)), "chip_db_read_rows_f64")
+        return out
+
     # -- queries
+    def query_scores(self, k: int, row: int) -> np.ndarray:
+        """the whole score vector u = v^T M[:, :k] of one query row (Cerebro.cpp:1026)"""
+        u = np.full(max(k, 1), np.nan, dtype=np.float64)
+        self._chk(self.lib.chip_query_scores(self.h, k, row, _ptr(u)), "chip_query_scores")
+        return u[:k]
+
+    def query_vectors_f64(self, k: int, q: np.ndarray, topk: int = CHIP_DEFAULT_TOPK):
+        q = np.ascontiguousarray(q, dtype=np.float64).reshape(-1, self.D)
+        nq = q.shape[0]
+        sc = np.empty((nq, topk), dtype=np.float64)
+        ix = np.empty((nq, topk), dtype=np.int64)
+        self._chk(self.lib.chip_query_vectors_f64(self.h, k, _ptr(q), nq, topk, _ptr(sc), _ptr(ix)), "chip_query_vectors_f64")
+        return sc, ix
+
     def query_rows(self, k: int, rows, topk: int = CHIP_DEFAULT_TOPK):
         rows = np.ascontiguousarray(rows, dtype=np.int64)
         nq = rows.size

@@ -244,6 +244,7 @@ extern "C" int chip_query_batch_f32(chip_ctx *c, int64_t k, const float *queries
 {
     if (!c || !queries || Q < 1) return CHIP_ERR_INVALID_ARG;
     if (topk < 1 || topk > CHIP_MAX_TOPK || c->D % 32 != 0) return CHIP_ERR_UNSUPPORTED;
+    if (c->group || c->elem != 4) return CHIP_ERR_UNSUPPORTED;   // fp32 GEMM over float rows of one device (faiss casts to float, Cerebro.cpp:422)
     int64_t n_global;
     {
         std::lock_guard<std::mutex> lk(c->mu);
@@ -293,7 +294,7 @@ extern "C" int chip_query_batch_f32(chip_ctx *c, int64_t k, const float *queries
     CHIP_HIP(c, hipMemcpyAsync(st->Q, queries, sizeof(float) * (size_t)Q * D, hipMemcpyHostToDevice, s));
 
     BatchArgs a;
-    a.seg_table = c->seg_table_dev; a.seg_shift = c->seg_shift; a.seg_mask = c->seg_rows - 1;
+    a.seg_table = reinterpret_cast<const float *const *>(c->seg_table_dev); a.seg_shift = c->seg_shift; a.seg_mask = c->seg_rows - 1;
     a.n_rows = n_rows; a.D = D; a.Q = st->Q; a.Qpad = Qpad; a.K = topk; a.rows_per_part = rows_per_part;
     a.idx_mul = c->nranks; a.idx_add = c->nranks == 1 ? 0 : c->rank; a.partial = st->partial;
     const int KCsel = 32;   // measured: KC=64 (66 KiB LDS) halves residency and drops 111 -> 88 TFLOP/s at Q=256

@@ -1,6 +1,10 @@
 // chip_api.hip -- C-ABI entry points of libcerebro_hip.so (see include/cerebro_hip.h for the contract and
 // the reference lines each entry point replaces).  Host-side C++ over the HIP runtime; no torch, no CPU
 // fallback: every compute entry point runs HIP kernels or fails with a CHIP_ERR_* status.
+//
+// This file holds the single-device context.  chip_multi.hip builds on its building blocks (declared in
+// chip_internal.h): the in-library exchange of per-shard top-k lists over RCCL, and group contexts that drive the
+// GPUs of one node from one process.  Entry points dispatch on ctx->group.
 #include "chip_internal.h"
 #include <cmath>
 #include <cstdlib>
@@ -25,6 +29,7 @@ const char *chip_strerror(int status)
         case CHIP_ERR_UNSUPPORTED: return "unsupported configuration";
         case CHIP_ERR_TOO_FEW_POINTS: return "fewer than 20 correspondences";
         case CHIP_ERR_BUSY: return "async slot busy or empty";
+        case CHIP_ERR_COMM: return "RCCL error (see chip_last_comm_error)";
     }
     return "unknown status";
 }
@@ -34,8 +39,9 @@ int chip_abi_version(void) { return CHIP_ABI_VERSION; }
 int chip_last_hip_error(const chip_ctx *ctx, const char **text)
 {
     if (!ctx) return (int)hipErrorInvalidValue;
-    if (text) *text = hipGetErrorString(ctx->last_hip);
-    return (int)ctx->last_hip;
+    const Ctx *c = ctx->group ? group_root(const_cast<chip_ctx *>(ctx)) : ctx;
+    if (text) *text = hipGetErrorString(c->last_hip);
+    return (int)c->last_hip;
 }
 
 void chip_dot_params_default(chip_dot_params *p)
@@ -66,7 +72,9 @@ void chip_ransac_params_default(chip_ransac_params *p)
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------ internals
-static int env_int(const char *name, int dflt)
+namespace chip {
+
+int env_int(const char *name, int dflt)
 {
     const char *v = std::getenv(name);
     return v && *v ? std::atoi(v) : dflt;
@@ -79,8 +87,8 @@ static int ensure_capacity(Ctx *c, int64_t local_rows)
     if (need > kMaxSegs) return CHIP_ERR_OOM;
     bool grew = false;
     while ((int64_t)c->segs.size() < need) {
-        float *p = nullptr;
-        CHIP_HIP(c, hipMalloc(&p, (size_t)c->seg_rows * c->D * sizeof(float)));
+        void *p = nullptr;
+        CHIP_HIP(c, hipMalloc(&p, (size_t)c->seg_rows * c->D * c->elem));
         {
             std::lock_guard<std::mutex> lk(c->mu);
             c->segs.push_back(p);
@@ -88,21 +96,51 @@ static int ensure_capacity(Ctx *c, int64_t local_rows)
         grew = true;
     }
     if (grew) {
-        CHIP_HIP(c, hipMemcpyAsync(c->seg_table_dev, c->segs.data(), c->segs.size() * sizeof(float *), hipMemcpyHostToDevice, c->s_append));
+        CHIP_HIP(c, hipMemcpyAsync(c->seg_table_dev, c->segs.data(), c->segs.size() * sizeof(void *), hipMemcpyHostToDevice, c->s_append));
         CHIP_HIP(c, hipStreamSynchronize(c->s_append));
     }
     return CHIP_OK;
 }
 
-static void destroy_ctx(chip_ctx *c)
+// (Re)allocate everything whose size depends on the storage type.  Only ever called on an EMPTY DB (create, or the automatic
+// switch to double rows on the first append), with the append lock held or before the ctx is published.
+static int configure_storage(Ctx *c, int elem)
+{
+    for (void *p : c->segs) (void)hipFree(p);
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->segs.clear();
+    }
+    if (c->ring_dev) { (void)hipFree(c->ring_dev); c->ring_dev = nullptr; }
+    if (c->qvec_dev) { (void)hipFree(c->qvec_dev); c->qvec_dev = nullptr; }
+    c->elem = elem;
+    // segment geometry: power-of-two rows, ~512 MiB (float rows) / ~1 GiB (double rows) each
+    int64_t rows = kSegBytesTarget / ((int64_t)c->D * 4);
+    int shift = 0;
+    while ((2ll << shift) <= rows) shift++;
+    if (shift < 6) shift = 6;
+    c->seg_shift = shift;
+    c->seg_rows = 1ll << shift;
+    CHIP_HIP(c, hipMemset(c->seg_table_dev, 0, kMaxSegs * sizeof(void *)));
+    if (c->nranks > 1) {
+        CHIP_HIP(c, hipMalloc(&c->ring_dev, (size_t)CHIP_RING_ROWS * c->D * elem));
+        CHIP_HIP(c, hipMemset(c->ring_dev, 0, (size_t)CHIP_RING_ROWS * c->D * elem));
+    }
+    CHIP_HIP(c, hipMalloc(&c->qvec_dev, (size_t)CHIP_MAX_NQ * c->D * elem));
+    return CHIP_OK;
+}
+
+void ctx_destroy(chip_ctx *c)
 {
     if (!c) return;
+    if (c->group) { group_destroy(c); delete c; return; }
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    exchange_destroy(c);
     pnp_destroy(c);
     icp_destroy(c);
     batch_destroy(c);
-    for (float *p : c->segs) (void)hipFree(p);
+    for (void *p : c->segs) (void)hipFree(p);
     if (c->seg_table_dev) (void)hipFree(c->seg_table_dev);
     if (c->ring_dev) (void)hipFree(c->ring_dev);
     if (c->stage_dev) (void)hipFree(c->stage_dev);
@@ -117,6 +155,7 @@ static void destroy_ctx(chip_ctx *c)
     if (c->s_scan2) (void)hipStreamDestroy(c->s_scan2);
     if (c->topk_host) (void)hipHostFree(c->topk_host);
     if (c->qvec_dev) (void)hipFree(c->qvec_dev);
+    if (c->scores_dev) (void)hipFree(c->scores_dev);
     for (Slot &s : c->slots) {
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.host) (void)hipHostFree(s.host);
@@ -128,7 +167,7 @@ static void destroy_ctx(chip_ctx *c)
     delete c;
 }
 
-static int create_impl(chip_ctx *c, int64_t capacity_hint)
+static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
 {
     hipDeviceProp_t prop;
     CHIP_HIP(c, hipGetDeviceProperties(&prop, c->device));
@@ -136,13 +175,6 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
     std::strncpy(c->arch, prop.gcnArchName, sizeof(c->arch) - 1);
     if (std::strncmp(c->arch, "gfx950", 6) != 0 && !std::getenv("CHIP_ALLOW_ANY_ARCH")) return CHIP_ERR_NO_DEVICE;
 
-    // segment geometry: power-of-two rows, ~512 MiB each
-    int64_t rows = kSegBytesTarget / ((int64_t)c->D * 4);
-    int shift = 0;
-    while ((2ll << shift) <= rows) shift++;
-    if (shift < 6) shift = 6;
-    c->seg_shift = shift;
-    c->seg_rows = 1ll << shift;
     // The querier reads segs[] without c->mu (row_ptr_host) while the appender may open a new segment: reserve the whole
     // table (32 KiB) so that push_back never reallocates -- entries below the published length are immutable.
     c->segs.reserve(kMaxSegs);
@@ -150,12 +182,9 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
     CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_query, hipStreamNonBlocking));
     CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_append, hipStreamNonBlocking));
     CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_pnp, hipStreamNonBlocking));
-    CHIP_HIP(c, hipMalloc(&c->seg_table_dev, kMaxSegs * sizeof(float *)));
-    CHIP_HIP(c, hipMemset(c->seg_table_dev, 0, kMaxSegs * sizeof(float *)));
-    if (c->nranks > 1) {
-        CHIP_HIP(c, hipMalloc(&c->ring_dev, (size_t)CHIP_RING_ROWS * c->D * sizeof(float)));
-        CHIP_HIP(c, hipMemset(c->ring_dev, 0, (size_t)CHIP_RING_ROWS * c->D * sizeof(float)));
-    }
+    CHIP_HIP(c, hipMalloc(&c->seg_table_dev, kMaxSegs * sizeof(void *)));
+    int rc = configure_storage(c, elem);
+    if (rc != CHIP_OK) return rc;
     c->stage_bytes = 64ull << 20;
     if (c->stage_bytes < (size_t)c->D * 8 * 64) c->stage_bytes = (size_t)c->D * 8 * 64;
     CHIP_HIP(c, hipMalloc(&c->stage_dev, c->stage_bytes));
@@ -167,7 +196,8 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
     c->scan_blocks_per_cu = env_int("CHIP_SCAN_BPC", 2);
     if (c->scan_blocks_per_cu < 1) c->scan_blocks_per_cu = 1;
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);
-    c->scan_reserve = env_int("CHIP_SCAN_RESERVE", 0);
+    // a sharded ctx gets three small kernels per tick through its ctx stream underneath the scans: keep slots free for them
+    c->scan_reserve = env_int("CHIP_SCAN_RESERVE", c->nranks > 1 ? 4 : 0);
     c->max_grid = 512;  // K2 (one 512-thread workgroup) keeps one partial list per thread
     {
         const int pr = env_int("CHIP_SCAN_STREAM_PRIORITY", 0);   // tuning only: 0 = default class, 1 = highest, -1 = lowest
@@ -186,15 +216,15 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
     }
     CHIP_HIP(c, hipHostMalloc(&c->topk_host, (size_t)CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry), hipHostMallocDefault));
     CHIP_HIP(c, hipHostGetDevicePointer((void **)&c->topk_dev, c->topk_host, 0));
-    CHIP_HIP(c, hipMalloc(&c->qvec_dev, (size_t)CHIP_MAX_NQ * c->D * sizeof(float)));
     for (Slot &s : c->slots) {
         CHIP_HIP(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         // pinned + mapped: the deciding workgroup stores the record here directly, no D2H copy kernel per tick
         CHIP_HIP(c, hipHostMalloc(&s.host, sizeof(chip_tick_result), hipHostMallocDefault));
         CHIP_HIP(c, hipHostGetDevicePointer((void **)&s.dev, s.host, 0));
     }
-    int rc = pnp_create(c);
+    rc = pnp_create(c);
     if (rc != CHIP_OK) return rc;
+    c->cap_hint = capacity_hint;
     if (capacity_hint > 0) {
         std::lock_guard<std::mutex> lk(c->append_mu);
         rc = ensure_capacity(c, local_count(c, capacity_hint));
@@ -203,12 +233,39 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint)
     return CHIP_OK;
 }
 
+int ctx_create(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device, int32_t shard_rank, int32_t shard_count, uint32_t flags)
+{
+    if (!out) return CHIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (D <= 0 || shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count || capacity_hint < 0) return CHIP_ERR_INVALID_ARG;
+    const uint32_t store = flags & kCreateStoreMask;
+    if (store == kCreateStoreMask) return CHIP_ERR_INVALID_ARG;
+    if (D % 4 != 0 || (size_t)D * 4 * CHIP_MAX_NQ > 160 * 1024) return CHIP_ERR_UNSUPPORTED;
+    // double rows: the three queries of a tick (3 x D x 8 B) must fit the 160 KiB of LDS
+    if (store == CHIP_CREATE_STORE_F64 && (size_t)D * 8 * 3 > 160 * 1024) return CHIP_ERR_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CHIP_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return CHIP_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return CHIP_ERR_NO_DEVICE;
+    chip_ctx *c = new (std::nothrow) chip_ctx();
+    if (!c) return CHIP_ERR_OOM;
+    c->D = D;
+    c->device = device;
+    c->rank = shard_rank;
+    c->nranks = shard_count;
+    c->store_auto = store == 0;
+    int rc = create_impl(c, capacity_hint, store == CHIP_CREATE_STORE_F64 ? 8 : 4);
+    if (rc != CHIP_OK) { ctx_destroy(c); return rc; }
+    *out = c;
+    return CHIP_OK;
+}
+
 // Enqueue K1 (scan + per-workgroup top-k, on s_scan) and K2 (cross-workgroup merge [+ accept decision], on the ctx
 // stream behind an event) for nq queries over the global prefix [0,k).  out (device or pinned host, optional) gets
 // [nq][K]; res (optional) the decision record of Cerebro.cpp:1056.  Consecutive calls pipeline: scans run back to
 // back on s_scan while the previous merge (and whatever the caller enqueues after it on the ctx stream) proceeds.
-static int enqueue_scan_merge(Ctx *c, int64_t k, const float *const *q, int nq, int K, int64_t l,
-                              const chip_dot_params *p, chip_topk_entry *out, chip_tick_result *res, bool tick = false)
+int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, int64_t l,
+                       const chip_dot_params *p, chip_topk_entry *out, chip_tick_result *res, bool tick)
 {
     const int b = (int)(c->n_enqueued++ % Ctx::kRing);
     // Ticks (queries already resident) over a short prefix alternate between two scan streams so that the ramp-down of
@@ -216,7 +273,7 @@ static int enqueue_scan_merge(Ctx *c, int64_t k, const float *const *q, int nq, 
     // 125k 317 -> 308, 500k 1191 -> 1157; at 1M the gain is < 1 %, and launches that overlap would no longer have a
     // meaningful per-launch duration for the roofline, so long scans and profiled runs stay on one stream).  Anything that
     // uploads its queries on s_scan first stays on s_scan.
-    const bool short_scan = (double)local_count(c, k) * c->D * sizeof(float) <= 8.0 * 1024 * 1024 * 1024;
+    const bool short_scan = (double)local_count(c, k) * c->D * c->elem <= 8.0 * 1024 * 1024 * 1024;
     hipStream_t s_scan = (tick && short_scan && !c->prof_on && c->s_scan2 && (c->n_enqueued & 1)) ? c->s_scan2 : c->s_scan;
     ScanArgs a;
     a.seg_table = c->seg_table_dev;
@@ -246,7 +303,7 @@ static int enqueue_scan_merge(Ctx *c, int64_t k, const float *const *q, int nq, 
         e0 = c->prof_ev[c->prof_used];
         e1 = c->prof_ev[c->prof_used + 1];
         c->prof_used += 2;
-        c->prof_bytes_last = (double)a.n_rows * c->D * 4.0;
+        c->prof_bytes_last = (double)a.n_rows * c->D * c->elem;
         CHIP_HIP(c, hipEventRecord(e0, s_scan));
     }
     int rc = launch_scan(c, s_scan, a, nq, grid);
@@ -271,18 +328,13 @@ static int enqueue_scan_merge(Ctx *c, int64_t k, const float *const *q, int nq, 
     return CHIP_OK;
 }
 
+// Pointers of the query rows (device).  Single GPU: straight into the DB; sharded: the replicated ring.
 // Sharded ctx: the query rows of a scan are read from the replicated ring, which the appender overwrites in place.  A
 // querier holds ring_mu from the residency check until the scan's completion event is recorded (RingGuard); the appender
 // announces the length its call will reach (rows_pending) and picks up the newest scan events under the same lock before it
 // touches the ring, and its ring writes wait for those scans.  So a scan either was validated against the post-append
 // length, or is ordered before the ring writes.
-struct RingGuard {
-    std::unique_lock<std::mutex> lk;
-    explicit RingGuard(Ctx *c) : lk(c->ring_mu, std::defer_lock) { if (c->ring_dev) lk.lock(); }
-};
-
-// Pointers of the query rows (device).  Single GPU: straight into the DB; sharded: the replicated ring.
-static int query_row_ptrs(Ctx *c, const int64_t *rows, int nq, int64_t n_global, const float **q)
+int query_row_ptrs(Ctx *c, const int64_t *rows, int nq, int64_t n_global, const void **q)
 {
     int64_t total;
     {
@@ -298,25 +350,48 @@ static int query_row_ptrs(Ctx *c, const int64_t *rows, int nq, int64_t n_global,
             // no longer in the replicated ring -- counting the rows of an append that is in flight right now
             const int64_t horizon = c->rows_pending > total ? c->rows_pending : total;
             if (g < horizon - CHIP_RING_ROWS) return CHIP_ERR_RANGE;
-            q[i] = c->ring_dev + (g % CHIP_RING_ROWS) * (int64_t)c->D;
+            q[i] = ring_ptr(c, g);
         }
     }
     return CHIP_OK;
 }
 
-// Host part of the tick (Cerebro.cpp:960-966, :1019-1022, :1098).  Returns CHIP_TICK_* in *status.
-// last_l is NOT written here: the caller commits it (c->last_l = l) once the tick has actually been enqueued (or at once
-// for TOO_SHORT), so a failed enqueue leaves the state as the reference's loop would (it only reaches :1098 at the end of an
-// executed pass).
-static int tick_prepare(Ctx *c, int64_t l, const chip_dot_params *p, int32_t *status, int64_t *k_out)
+// External query vectors -> qvec_dev in the storage type, on the scan stream: K1 reads them there (the previous synchronous
+// call has fully drained, so no WAR hazard).  float <-> double conversion of a few rows is done on the host: widening is
+// exact; narrowing double queries for a float DB must be lossless ((double)(float)x == x) or the call fails.
+int upload_query_vectors(Ctx *c, const void *queries, int src_elem, int nq, const void **q)
 {
-    int64_t n;
-    {
-        std::lock_guard<std::mutex> lk(c->mu);
-        n = c->rows_global;
+    const size_t n = (size_t)nq * c->D;
+    if (src_elem == c->elem) {
+        CHIP_HIP(c, hipMemcpyAsync(c->qvec_dev, queries, n * c->elem, hipMemcpyHostToDevice, c->s_scan));
+    } else {
+        c->qconv.resize(n * c->elem);
+        if (c->elem == 8) {
+            double *d = reinterpret_cast<double *>(c->qconv.data());
+            const float *s = static_cast<const float *>(queries);
+            for (size_t i = 0; i < n; i++) d[i] = (double)s[i];
+        } else {
+            float *d = reinterpret_cast<float *>(c->qconv.data());
+            const double *s = static_cast<const double *>(queries);
+            for (size_t i = 0; i < n; i++) {
+                d[i] = (float)s[i];
+                if (!((double)d[i] == s[i])) return std::isfinite(s[i]) ? CHIP_ERR_NOT_F32 : CHIP_ERR_NONFINITE;
+            }
+        }
+        CHIP_HIP(c, hipMemcpyAsync(c->qvec_dev, c->qconv.data(), n * c->elem, hipMemcpyHostToDevice, c->s_scan));
+        CHIP_HIP(c, hipStreamSynchronize(c->s_scan));   // qconv is pageable and reused
     }
+    for (int i = 0; i < nq; i++) q[i] = static_cast<char *>(c->qvec_dev) + (size_t)i * c->D * c->elem;
+    return CHIP_OK;
+}
+
+// Host part of the tick (Cerebro.cpp:960-966, :1019-1022).  Returns CHIP_TICK_* in *status.  last_l is NOT written here:
+// the caller commits it once the tick has actually been enqueued (or at once for TOO_SHORT), so a failed enqueue leaves the
+// state as the reference's loop would (it only reaches :1098 at the end of an executed pass).
+int tick_prepare(int64_t n, int64_t last_l, int64_t l, const chip_dot_params *p, int32_t *status, int64_t *k_out)
+{
     if (l < 0 || l > n) return CHIP_ERR_RANGE;
-    if (l - c->last_l < p->min_new) { *status = CHIP_TICK_SKIPPED; return CHIP_OK; }  // :962-966, last_l untouched
+    if (l - last_l < p->min_new) { *status = CHIP_TICK_SKIPPED; return CHIP_OK; }  // :962-966, last_l untouched
     if (l < 3) return CHIP_ERR_RANGE;  // needs descriptors l-1, l-2, l-3 (:987-989)
     const int64_t k = l - p->lag;      // :1019
     *k_out = k;
@@ -324,7 +399,7 @@ static int tick_prepare(Ctx *c, int64_t l, const chip_dot_params *p, int32_t *st
     return CHIP_OK;
 }
 
-static void fill_immediate(chip_tick_result *r, int32_t status)
+void fill_immediate(chip_tick_result *r, int32_t status)
 {
     std::memset(r, 0, sizeof *r);
     r->status = status;
@@ -332,12 +407,18 @@ static void fill_immediate(chip_tick_result *r, int32_t status)
     for (int q = 0; q < 3; q++) { r->argmax[q] = -1; r->maxv[q] = -INFINITY; }
 }
 
+static int64_t published_rows(const Ctx *c)
+{
+    std::lock_guard<std::mutex> lk(c->mu);
+    return c->rows_global;
+}
+
 static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &s)
 {
     if (s.in_flight) return CHIP_ERR_BUSY;
     int32_t status = 0;
     int64_t k = 0;
-    int rc = tick_prepare(c, l, p, &status, &k);
+    int rc = tick_prepare(published_rows(c), c->last_l, l, p, &status, &k);
     if (rc != CHIP_OK) return rc;
     if (status != CHIP_TICK_SCANNED) {
         if (status == CHIP_TICK_TOO_SHORT) c->last_l = l;   // :1098 (the else-branch of :1022 still ends the pass)
@@ -346,21 +427,26 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
         s.in_flight = true;
         return CHIP_OK;
     }
-    const int64_t rows[3] = {l - 1, l - 2, l - 3};  // v, vm, vmm (:987-989)
-    const float *q[3];
-    RingGuard rg(c);
-    rc = query_row_ptrs(c, rows, 3, l, q);
-    if (rc != CHIP_OK) return rc;
-    rc = enqueue_scan_merge(c, k, q, 3, CHIP_DEFAULT_TOPK, l, p, nullptr, s.dev, true);
-    if (rc != CHIP_OK) return rc;
-    CHIP_HIP(c, hipEventRecord(s.done, c->s_query));
+    if (c->xchg) {   // sharded ctx with its exchange inside the library: scan -> local merge -> all-gather -> merge + decision
+        rc = xchg_tick_enqueue(c, l, k, p, s);
+        if (rc != CHIP_OK) return rc;
+    } else {
+        const int64_t rows[3] = {l - 1, l - 2, l - 3};  // v, vm, vmm (:987-989)
+        const void *q[3];
+        RingGuard rg(c);
+        rc = query_row_ptrs(c, rows, 3, l, q);
+        if (rc != CHIP_OK) return rc;
+        rc = enqueue_scan_merge(c, k, q, 3, CHIP_DEFAULT_TOPK, l, p, nullptr, s.dev, true);
+        if (rc != CHIP_OK) return rc;
+        CHIP_HIP(c, hipEventRecord(s.done, c->s_query));
+        s.immediate = false;
+        s.in_flight = true;
+    }
     c->last_l = l;                     // :1098
-    s.immediate = false;
-    s.in_flight = true;
     return CHIP_OK;
 }
 
-static int tick_collect_slot(Ctx *c, Slot &s, chip_tick_result *out)
+int tick_collect_slot(Ctx *c, Slot &s, chip_tick_result *out)
 {
     if (!s.in_flight) return CHIP_ERR_BUSY;
     if (!s.immediate) CHIP_HIP(c, hipEventSynchronize(s.done));
@@ -369,7 +455,7 @@ static int tick_collect_slot(Ctx *c, Slot &s, chip_tick_result *out)
     return CHIP_OK;
 }
 
-static int sync_topk_out(Ctx *c, int nq, int K, double *scores, int64_t *idx)
+int sync_topk_out(Ctx *c, int nq, int K, double *scores, int64_t *idx)
 {
     CHIP_HIP(c, hipStreamSynchronize(c->s_query));  // the last block stored the list into pinned host memory
     for (int i = 0; i < nq * K; i++) {
@@ -379,17 +465,28 @@ static int sync_topk_out(Ctx *c, int nq, int K, double *scores, int64_t *idx)
     return CHIP_OK;
 }
 
-template <typename T>
-static int append_impl(Ctx *c, const T *desc, int64_t n, uint32_t flags, int64_t *first_index, bool is_f64)
+// Announce an append to queriers of a sharded ctx and order its ring writes behind the scans already enqueued.
+static int ring_begin_append(Ctx *c, int64_t new_total)
+{
+    if (!c->ring_dev) return CHIP_OK;
+    hipEvent_t ev[2];
+    {
+        std::lock_guard<std::mutex> rl(c->ring_mu);
+        c->rows_pending = new_total;        // queriers now validate ring residency against the length after this call
+        ev[0] = c->last_scan_ev[0];
+        ev[1] = c->last_scan_ev[1];
+    }
+    for (hipEvent_t e : ev)                 // scans already enqueued read their queries before the ring is overwritten
+        if (e) CHIP_HIP(c, hipStreamWaitEvent(c->s_append, e, 0));
+    return CHIP_OK;
+}
+
+int ctx_append(Ctx *c, const void *desc, int src_elem, int64_t n, uint32_t flags, int64_t *first_index)
 {
     if (!c || !desc || n < 0) return CHIP_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> alk(c->append_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
-    int64_t first;
-    {
-        std::lock_guard<std::mutex> lk(c->mu);
-        first = c->rows_global;
-    }
+    const int64_t first = published_rows(c);
     if (first_index) *first_index = first;
     if (n == 0) return CHIP_OK;
     int rc = ensure_capacity(c, local_count(c, first + n));
@@ -397,39 +494,45 @@ static int append_impl(Ctx *c, const T *desc, int64_t n, uint32_t flags, int64_t
 
     // Upload rows [from, from+count) of this call in staging-sized chunks and run K3 on them.
     auto pass = [&](int64_t from, int64_t count, bool ring) -> int {
-        const int64_t chunk_rows = (int64_t)(c->stage_bytes / ((size_t)c->D * sizeof(T)));
+        const int64_t chunk_rows = (int64_t)(c->stage_bytes / ((size_t)c->D * src_elem));
         for (int64_t off = from; off < from + count; off += chunk_rows) {
             const int64_t m = (from + count - off) < chunk_rows ? (from + count - off) : chunk_rows;
-            CHIP_HIP(c, hipMemcpyAsync(c->stage_dev, desc + off * c->D, (size_t)m * c->D * sizeof(T), hipMemcpyHostToDevice, c->s_append));
-            const int r = is_f64 ? launch_narrow_f64(c, c->s_append, (const double *)c->stage_dev, m, first + off, c->flags_dev, ring)
-                                 : launch_copy_f32(c, c->s_append, (const float *)c->stage_dev, m, first + off, c->flags_dev, ring);
+            CHIP_HIP(c, hipMemcpyAsync(c->stage_dev, static_cast<const char *>(desc) + (size_t)off * c->D * src_elem, (size_t)m * c->D * src_elem,
+                                       hipMemcpyHostToDevice, c->s_append));
+            const int r = launch_store_rows(c, c->s_append, c->stage_dev, src_elem, m, first + off, c->flags_dev, ring);
             if (r != CHIP_OK) return r;
             // the staging buffer is reused by the next chunk: stream order serialises copy -> kernel -> copy
         }
         return CHIP_OK;
     };
     // pass 1 writes the DB only (rows past the published length are invisible); the ring is updated after validation
-    *c->flags_host = 0;
-    CHIP_HIP(c, hipMemsetAsync(c->flags_dev, 0, sizeof(uint32_t), c->s_append));
-    rc = pass(0, n, false);
-    if (rc != CHIP_OK) return rc;
-    CHIP_HIP(c, hipMemcpyAsync(c->flags_host, c->flags_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->s_append));
-    CHIP_HIP(c, hipStreamSynchronize(c->s_append));
-
-    const uint32_t bad = *c->flags_host;
-    if (bad & 2u) return CHIP_ERR_NONFINITE;
-    if ((bad & 1u) && !(flags & CHIP_APPEND_ALLOW_ROUNDING)) return CHIP_ERR_NOT_F32;
+    uint32_t bad = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        *c->flags_host = 0;
+        CHIP_HIP(c, hipMemsetAsync(c->flags_dev, 0, sizeof(uint32_t), c->s_append));
+        rc = pass(0, n, false);
+        if (rc != CHIP_OK) return rc;
+        CHIP_HIP(c, hipMemcpyAsync(c->flags_host, c->flags_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->s_append));
+        CHIP_HIP(c, hipStreamSynchronize(c->s_append));
+        bad = *c->flags_host;
+        if (bad & 2u) return CHIP_ERR_NONFINITE;
+        if (!(bad & 1u) || (flags & CHIP_APPEND_ALLOW_ROUNDING)) break;
+        // Genuinely float64 descriptors (e.g. ReljaNetVLAD's numpy WPCA output, whole_image_desc_compute_server.py:148-149):
+        // an undecided, still EMPTY DB becomes a double-row DB -- as the reference's MatrixXd M (Cerebro.cpp:946) -- and the
+        // rows are stored again, unrounded.  Anything else keeps the lossless-narrowing contract and fails.
+        if (attempt == 0 && c->store_auto && first == 0 && (size_t)c->D * 8 * 3 <= 160 * 1024) {
+            rc = configure_storage(c, 8);
+            if (rc != CHIP_OK) return rc;
+            rc = ensure_capacity(c, local_count(c, c->cap_hint > n ? c->cap_hint : n));
+            if (rc != CHIP_OK) return rc;
+            continue;
+        }
+        return CHIP_ERR_NOT_F32;
+    }
 
     if (c->ring_dev) {  // sharded: mirror the newest rows into the replicated ring (DB store is idempotent)
-        hipEvent_t ev[2];
-        {
-            std::lock_guard<std::mutex> rl(c->ring_mu);
-            c->rows_pending = first + n;        // queriers now validate ring residency against the length after this call
-            ev[0] = c->last_scan_ev[0];
-            ev[1] = c->last_scan_ev[1];
-        }
-        for (hipEvent_t e : ev)                 // scans already enqueued read their queries before the ring is overwritten
-            if (e) CHIP_HIP(c, hipStreamWaitEvent(c->s_append, e, 0));
+        rc = ring_begin_append(c, first + n);
+        if (rc != CHIP_OK) return rc;
         const int64_t m = n < CHIP_RING_ROWS ? n : CHIP_RING_ROWS;
         rc = pass(n - m, m, true);
         if (rc != CHIP_OK) return rc;
@@ -440,125 +543,17 @@ static int append_impl(Ctx *c, const T *desc, int64_t n, uint32_t flags, int64_t
         c->rows_global = first + n;
         c->rows_local = local_count(c, c->rows_global);
         if (bad & 1u) c->lossy_rows += n;  // upper bound: rows of this call
+        c->store_auto = false;             // the storage type is final once the DB holds a row
     }
     return CHIP_OK;
 }
 
-extern "C" {
-
-// ------------------------------------------------------------------------------------------------ lifecycle
-int chip_create(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device, int32_t shard_rank, int32_t shard_count)
-{
-    if (!out) return CHIP_ERR_INVALID_ARG;
-    *out = nullptr;
-    if (D <= 0 || shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count || capacity_hint < 0) return CHIP_ERR_INVALID_ARG;
-    if (D % 4 != 0 || (size_t)D * 4 * CHIP_MAX_NQ > 160 * 1024) return CHIP_ERR_UNSUPPORTED;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CHIP_ERR_NO_DEVICE;
-    if (device < 0 || device >= ndev) return CHIP_ERR_NO_DEVICE;
-    if (hipSetDevice(device) != hipSuccess) return CHIP_ERR_NO_DEVICE;
-    chip_ctx *c = new (std::nothrow) chip_ctx();
-    if (!c) return CHIP_ERR_OOM;
-    c->D = D;
-    c->device = device;
-    c->rank = shard_rank;
-    c->nranks = shard_count;
-    int rc = create_impl(c, capacity_hint);
-    if (rc != CHIP_OK) { destroy_ctx(c); return rc; }
-    *out = c;
-    return CHIP_OK;
-}
-
-void chip_destroy(chip_ctx *ctx) { destroy_ctx(ctx); }
-
-int chip_set_stream(chip_ctx *c, void *hip_stream)
-{
-    if (!c) return CHIP_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(c->query_mu);
-    CHIP_HIP(c, hipSetDevice(c->device));
-    CHIP_HIP(c, hipStreamSynchronize(c->s_query));
-    if (c->own_query_stream) CHIP_HIP(c, hipStreamDestroy(c->s_query));
-    c->s_query = (hipStream_t)hip_stream;   // may be 0: HIP's null stream is a valid external stream
-    c->own_query_stream = false;
-    return CHIP_OK;
-}
-
-int chip_reset_stream(chip_ctx *c)
-{
-    if (!c) return CHIP_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(c->query_mu);
-    CHIP_HIP(c, hipSetDevice(c->device));
-    if (c->own_query_stream) return CHIP_OK;
-    CHIP_HIP(c, hipStreamSynchronize(c->s_query));
-    CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_query, hipStreamNonBlocking));
-    c->own_query_stream = true;
-    return CHIP_OK;
-}
-
-int chip_synchronize(chip_ctx *c)
-{
-    if (!c) return CHIP_ERR_INVALID_ARG;
-    CHIP_HIP(c, hipSetDevice(c->device));
-    CHIP_HIP(c, hipStreamSynchronize(c->s_append));
-    CHIP_HIP(c, hipStreamSynchronize(c->s_scan));
-    if (c->s_scan2) CHIP_HIP(c, hipStreamSynchronize(c->s_scan2));
-    CHIP_HIP(c, hipStreamSynchronize(c->s_query));
-    CHIP_HIP(c, hipStreamSynchronize(c->s_pnp));
-    return CHIP_OK;
-}
-
-// ------------------------------------------------------------------------------------------------ append
-int chip_db_append_f64(chip_ctx *c, const double *desc, int64_t n, uint32_t flags, int64_t *first_index)
-{
-    return append_impl<double>(c, desc, n, flags, first_index, true);
-}
-
-int chip_db_append_f32(chip_ctx *c, const float *desc, int64_t n, int64_t *first_index)
-{
-    return append_impl<float>(c, desc, n, 0, first_index, false);
-}
-
-int64_t chip_db_size(const chip_ctx *c)
-{
-    if (!c) return CHIP_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(c->mu);
-    return c->rows_global;
-}
-
-int chip_db_read_rows_f32(chip_ctx *c, const int64_t *rows, int64_t n, float *out)
-{
-    if (!c || !rows || !out || n < 0) return CHIP_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> qlk(c->query_mu);
-    CHIP_HIP(c, hipSetDevice(c->device));
-    int64_t total;
-    {
-        std::lock_guard<std::mutex> lk(c->mu);
-        total = c->rows_global;
-    }
-    for (int64_t i = 0; i < n; i++) {
-        const int64_t g = rows[i];
-        if (g < 0 || g >= total) return CHIP_ERR_RANGE;
-        const float *src;
-        if (owns_row(c, g)) src = row_ptr_host(c, local_of(c, g));
-        else if (g >= total - CHIP_RING_ROWS) src = c->ring_dev + (g % CHIP_RING_ROWS) * (int64_t)c->D;
-        else return CHIP_ERR_RANGE;
-        CHIP_HIP(c, hipMemcpyAsync(out + i * c->D, src, (size_t)c->D * sizeof(float), hipMemcpyDeviceToHost, c->s_query));
-    }
-    CHIP_HIP(c, hipStreamSynchronize(c->s_query));
-    return CHIP_OK;
-}
-
-int chip_db_append_synthetic(chip_ctx *c, int64_t n, uint64_t seed,
-                             const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant)
+int ctx_append_synthetic(Ctx *c, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant)
 {
     if (!c || n < 0 || n_plant < 0 || (n_plant > 0 && (!plant_dst || !plant_src || !plant_kind))) return CHIP_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> alk(c->append_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
-    int64_t first;
-    {
-        std::lock_guard<std::mutex> lk(c->mu);
-        first = c->rows_global;
-    }
+    const int64_t first = published_rows(c);
     for (int64_t i = 0; i < n_plant; i++) {
         if (plant_dst[i] < first || plant_dst[i] >= first + n || plant_src[i] < 0) return CHIP_ERR_RANGE;
         if (i > 0 && plant_dst[i] <= plant_dst[i - 1]) return CHIP_ERR_INVALID_ARG;
@@ -577,18 +572,8 @@ int chip_db_append_synthetic(chip_ctx *c, int64_t n, uint64_t seed,
         CHIP_HIP(c, hipMemcpyAsync(ps, plant_src, n_plant * sizeof(int64_t), hipMemcpyHostToDevice, c->s_append));
         CHIP_HIP(c, hipMemcpyAsync(pk, plant_kind, n_plant * sizeof(int32_t), hipMemcpyHostToDevice, c->s_append));
     }
-    if (c->ring_dev) {   // same ordering against in-flight scans as append_impl
-        hipEvent_t ev[2];
-        {
-            std::lock_guard<std::mutex> rl(c->ring_mu);
-            c->rows_pending = first + n;
-            ev[0] = c->last_scan_ev[0];
-            ev[1] = c->last_scan_ev[1];
-        }
-        for (hipEvent_t e : ev)
-            if (e) (void)hipStreamWaitEvent(c->s_append, e, 0);
-    }
-    rc = launch_synth(c, c->s_append, first, n, seed, pd, ps, pk, n_plant);
+    rc = ring_begin_append(c, first + n);   // same ordering against in-flight scans as ctx_append
+    if (rc == CHIP_OK) rc = launch_synth(c, c->s_append, first, n, seed, pd, ps, pk, n_plant);
     hipError_t e = hipStreamSynchronize(c->s_append);
     if (pd) (void)hipFree(pd);
     if (ps) (void)hipFree(ps);
@@ -599,124 +584,47 @@ int chip_db_append_synthetic(chip_ctx *c, int64_t n, uint64_t seed,
         std::lock_guard<std::mutex> lk(c->mu);
         c->rows_global = first + n;
         c->rows_local = local_count(c, c->rows_global);
+        c->store_auto = false;
     }
     return CHIP_OK;
 }
 
-// ------------------------------------------------------------------------------------------------ queries
-static int check_query_args(chip_ctx *c, int64_t k, int32_t nq, int32_t topk, int64_t *n_global)
+// one row (storage type) to host memory, asynchronously on the ctx stream
+int ctx_read_row(Ctx *c, int64_t g, int64_t total, void *out)
 {
-    if (!c) return CHIP_ERR_INVALID_ARG;
-    if (nq < 1 || nq > CHIP_MAX_NQ || topk < 1 || topk > CHIP_MAX_TOPK) return CHIP_ERR_UNSUPPORTED;
-    {
-        std::lock_guard<std::mutex> lk(c->mu);
-        *n_global = c->rows_global;
-    }
-    if (k < 0 || k > *n_global) return CHIP_ERR_RANGE;
+    const void *src;
+    if (owns_row(c, g)) src = row_ptr_host(c, local_of(c, g));
+    else if (c->ring_dev && g >= total - CHIP_RING_ROWS) src = ring_ptr(c, g);
+    else return CHIP_ERR_RANGE;
+    CHIP_HIP(c, hipMemcpyAsync(out, src, (size_t)c->D * c->elem, hipMemcpyDeviceToHost, c->s_query));
     return CHIP_OK;
 }
 
-int chip_query_rows(chip_ctx *c, int64_t k, const int64_t *query_rows, int32_t nq, int32_t topk, double *scores, int64_t *idx)
+static int read_rows(chip_ctx *c, const int64_t *rows, int64_t n, void *out, int out_elem)
 {
-    int64_t n = 0;
-    int rc = check_query_args(c, k, nq, topk, &n);
-    if (rc != CHIP_OK) return rc;
-    if (!query_rows) return CHIP_ERR_INVALID_ARG;
+    if (!c || !rows || !out || n < 0) return CHIP_ERR_INVALID_ARG;
+    if (c->group) return group_read_rows(c, rows, n, out, out_elem);
     std::lock_guard<std::mutex> qlk(c->query_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
-    const float *q[CHIP_MAX_NQ];
-    RingGuard rg(c);
-    rc = query_row_ptrs(c, query_rows, nq, n, q);
-    if (rc != CHIP_OK) return rc;
-    rc = enqueue_scan_merge(c, k, q, nq, topk, 0, nullptr, c->topk_dev, nullptr);
-    if (rc != CHIP_OK) return rc;
-    return sync_topk_out(c, nq, topk, scores, idx);
+    if (out_elem < c->elem) return CHIP_ERR_NOT_F32;   // double rows do not fit a float buffer: chip_db_read_rows_f64
+    const int64_t total = published_rows(c);
+    const bool conv = out_elem != c->elem;             // float rows into a double buffer: widen on the host
+    std::vector<float> tmp;
+    if (conv) tmp.resize((size_t)n * c->D);
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t g = rows[i];
+        if (g < 0 || g >= total) return CHIP_ERR_RANGE;
+        void *dst = conv ? (void *)(tmp.data() + (size_t)i * c->D) : (void *)(static_cast<char *>(out) + (size_t)i * c->D * out_elem);
+        const int rc = ctx_read_row(c, g, total, dst);
+        if (rc != CHIP_OK) return rc;
+    }
+    CHIP_HIP(c, hipStreamSynchronize(c->s_query));
+    if (conv)
+        for (size_t i = 0; i < tmp.size(); i++) static_cast<double *>(out)[i] = (double)tmp[i];
+    return CHIP_OK;
 }
 
-int chip_query_vectors_f32(chip_ctx *c, int64_t k, const float *queries, int32_t nq, int32_t topk, double *scores, int64_t *idx)
-{
-    int64_t n = 0;
-    int rc = check_query_args(c, k, nq, topk, &n);
-    if (rc != CHIP_OK) return rc;
-    if (!queries) return CHIP_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> qlk(c->query_mu);
-    CHIP_HIP(c, hipSetDevice(c->device));
-    // on the scan stream: K1 reads qvec_dev there (the previous synchronous call has fully drained, so no WAR hazard)
-    CHIP_HIP(c, hipMemcpyAsync(c->qvec_dev, queries, (size_t)nq * c->D * sizeof(float), hipMemcpyHostToDevice, c->s_scan));
-    const float *q[CHIP_MAX_NQ];
-    for (int i = 0; i < nq; i++) q[i] = c->qvec_dev + (size_t)i * c->D;
-    rc = enqueue_scan_merge(c, k, q, nq, topk, 0, nullptr, c->topk_dev, nullptr);
-    if (rc != CHIP_OK) return rc;
-    return sync_topk_out(c, nq, topk, scores, idx);
-}
-
-// ------------------------------------------------------------------------------------------------ tick
-int chip_loop_tick(chip_ctx *c, int64_t l, const chip_dot_params *p, chip_tick_result *out)
-{
-    if (!c || !p || !out) return CHIP_ERR_INVALID_ARG;
-    if (c->nranks != 1) return CHIP_ERR_UNSUPPORTED;  // sharded ctx: chip_scan_local + chip_merge_decide
-    std::lock_guard<std::mutex> qlk(c->query_mu);
-    CHIP_HIP(c, hipSetDevice(c->device));
-    Slot &s = c->slots[CHIP_MAX_INFLIGHT - 1];
-    int rc = tick_enqueue_slot(c, l, p, s);
-    if (rc != CHIP_OK) return rc;
-    return tick_collect_slot(c, s, out);
-}
-
-int chip_loop_tick_enqueue(chip_ctx *c, int64_t l, const chip_dot_params *p, int32_t slot)
-{
-    if (!c || !p || slot < 0 || slot >= CHIP_MAX_INFLIGHT - 1) return CHIP_ERR_INVALID_ARG;
-    if (c->nranks != 1) return CHIP_ERR_UNSUPPORTED;
-    std::lock_guard<std::mutex> qlk(c->query_mu);
-    CHIP_HIP(c, hipSetDevice(c->device));
-    return tick_enqueue_slot(c, l, p, c->slots[slot]);
-}
-
-int chip_loop_tick_collect(chip_ctx *c, int32_t slot, chip_tick_result *out)
-{
-    if (!c || !out || slot < 0 || slot >= CHIP_MAX_INFLIGHT - 1) return CHIP_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> qlk(c->query_mu);
-    CHIP_HIP(c, hipSetDevice(c->device));
-    return tick_collect_slot(c, c->slots[slot], out);
-}
-
-int64_t chip_loop_last_l(const chip_ctx *c)
-{
-    if (!c) return CHIP_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> qlk(c->query_mu);
-    return c->last_l;
-}
-void chip_loop_reset(chip_ctx *c)
-{
-    if (!c) return;
-    std::lock_guard<std::mutex> qlk(c->query_mu);
-    c->last_l = 0;
-}
-
-int chip_scan_local(chip_ctx *c, int64_t l, const chip_dot_params *p, int32_t topk, void *dev_out, int32_t *status)
-{
-    if (!c || !p || !dev_out || !status) return CHIP_ERR_INVALID_ARG;
-    if (topk < 1 || topk > CHIP_MAX_TOPK) return CHIP_ERR_UNSUPPORTED;
-    std::lock_guard<std::mutex> qlk(c->query_mu);
-    CHIP_HIP(c, hipSetDevice(c->device));
-    int64_t k = 0;
-    int rc = tick_prepare(c, l, p, status, &k);
-    if (rc == CHIP_OK && *status == CHIP_TICK_TOO_SHORT) c->last_l = l;
-    if (rc != CHIP_OK || *status != CHIP_TICK_SCANNED) return rc;
-    const int64_t rows[3] = {l - 1, l - 2, l - 3};
-    const float *q[3];
-    RingGuard rg(c);
-    rc = query_row_ptrs(c, rows, 3, l, q);
-    if (rc != CHIP_OK) return rc;
-    // scan on s_scan, then (behind an event) the local merge on the ctx stream writes this rank's 3 x topk list to
-    // dev_out: everything the caller enqueues next on the ctx stream (the all-gather) is ordered after it, while the
-    // next tick's scan is free to start as soon as this scan ends.
-    rc = enqueue_scan_merge(c, k, q, 3, topk, l, nullptr, (chip_topk_entry *)dev_out, nullptr, true);
-    if (rc == CHIP_OK) c->last_l = l;  // :1098
-    return rc;
-}
-
-static int merge_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, const void *dev_gathered, int32_t n_lists, int32_t topk, Slot &s)
+int merge_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, const void *dev_gathered, int32_t n_lists, int32_t topk, Slot &s)
 {
     if (s.in_flight) return CHIP_ERR_BUSY;
     MergeArgs m;
@@ -736,10 +644,287 @@ static int merge_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, const
     return CHIP_OK;
 }
 
+// merge of gathered [n_lists][nq][K] lists into out[nq][K] on the ctx stream, no decision
+int merge_enqueue_out(Ctx *c, const void *dev_gathered, int32_t n_lists, int nq, int32_t topk, chip_topk_entry *out)
+{
+    MergeArgs m;
+    m.in = (const chip_topk_entry *)dev_gathered;
+    m.n_lists = n_lists;
+    m.K = topk;
+    m.out = out;
+    m.result = nullptr;
+    m.l = 0;
+    m.locality = 0;
+    m.thresh = 0.0;
+    return launch_merge(c, c->s_query, m, nq);
+}
+
+// All scores of one query over this ctx's share of the prefix [0,k): u_global[local * mul + add] = score (host buffer).
+int ctx_scores_local(Ctx *c, int64_t k, const void *q, double *u_global, int64_t mul, int64_t add)
+{
+    const int64_t n_rows = local_count(c, k);
+    if (n_rows == 0) return CHIP_OK;
+    if (n_rows > c->scores_cap) {
+        if (c->scores_dev) { (void)hipFree(c->scores_dev); c->scores_dev = nullptr; c->scores_cap = 0; }
+        const int64_t cap = n_rows + n_rows / 4 + 1024;
+        CHIP_HIP(c, hipMalloc(&c->scores_dev, (size_t)cap * sizeof(double)));
+        c->scores_cap = cap;
+    }
+    ScanArgs a;
+    a.seg_table = c->seg_table_dev;
+    a.seg_shift = c->seg_shift;
+    a.seg_mask = c->seg_rows - 1;
+    a.n_rows = n_rows;
+    a.D = c->D;
+    a.K = 1;
+    for (int i = 0; i < CHIP_MAX_NQ; i++) a.q[i] = i == 0 ? q : nullptr;
+    a.idx_mul = mul;
+    a.idx_add = add;
+    a.partial = nullptr;
+    int rc = launch_scores(c, c->s_scan, a, c->scores_dev);
+    if (rc != CHIP_OK) return rc;
+    if (mul == 1 && add == 0) {
+        CHIP_HIP(c, hipMemcpyAsync(u_global, c->scores_dev, (size_t)n_rows * sizeof(double), hipMemcpyDeviceToHost, c->s_scan));
+        CHIP_HIP(c, hipStreamSynchronize(c->s_scan));
+    } else {
+        std::vector<double> tmp((size_t)n_rows);
+        CHIP_HIP(c, hipMemcpyAsync(tmp.data(), c->scores_dev, (size_t)n_rows * sizeof(double), hipMemcpyDeviceToHost, c->s_scan));
+        CHIP_HIP(c, hipStreamSynchronize(c->s_scan));
+        for (int64_t r = 0; r < n_rows; r++) u_global[r * mul + add] = tmp[(size_t)r];
+    }
+    return CHIP_OK;
+}
+
+}  // namespace chip
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------------ lifecycle
+int chip_create(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device, int32_t shard_rank, int32_t shard_count)
+{
+    return ctx_create(out, D, capacity_hint, device, shard_rank, shard_count, 0);
+}
+
+int chip_create_ex(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device, int32_t shard_rank, int32_t shard_count, uint32_t flags)
+{
+    if (flags & ~kCreateStoreMask) return CHIP_ERR_INVALID_ARG;
+    return ctx_create(out, D, capacity_hint, device, shard_rank, shard_count, flags);
+}
+
+void chip_destroy(chip_ctx *ctx) { ctx_destroy(ctx); }
+
+int chip_set_stream(chip_ctx *c, void *hip_stream)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    if (c->group || c->xchg) return CHIP_ERR_UNSUPPORTED;   // the library owns the exchange and its stream ordering
+    std::lock_guard<std::mutex> lk(c->query_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    CHIP_HIP(c, hipStreamSynchronize(c->s_query));
+    if (c->own_query_stream) CHIP_HIP(c, hipStreamDestroy(c->s_query));
+    c->s_query = (hipStream_t)hip_stream;   // may be 0: HIP's null stream is a valid external stream
+    c->own_query_stream = false;
+    return CHIP_OK;
+}
+
+int chip_reset_stream(chip_ctx *c)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    if (c->group) return CHIP_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> lk(c->query_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    if (c->own_query_stream) return CHIP_OK;
+    CHIP_HIP(c, hipStreamSynchronize(c->s_query));
+    CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_query, hipStreamNonBlocking));
+    c->own_query_stream = true;
+    return CHIP_OK;
+}
+
+int chip_synchronize(chip_ctx *c)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    if (c->group) return group_synchronize(c);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    CHIP_HIP(c, hipStreamSynchronize(c->s_append));
+    CHIP_HIP(c, hipStreamSynchronize(c->s_scan));
+    if (c->s_scan2) CHIP_HIP(c, hipStreamSynchronize(c->s_scan2));
+    CHIP_HIP(c, hipStreamSynchronize(c->s_query));
+    CHIP_HIP(c, hipStreamSynchronize(c->s_pnp));
+    return CHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ append
+int chip_db_append_f64(chip_ctx *c, const double *desc, int64_t n, uint32_t flags, int64_t *first_index)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    return c->group ? group_append(c, desc, 8, n, flags, first_index) : ctx_append(c, desc, 8, n, flags, first_index);
+}
+
+int chip_db_append_f32(chip_ctx *c, const float *desc, int64_t n, int64_t *first_index)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    return c->group ? group_append(c, desc, 4, n, 0, first_index) : ctx_append(c, desc, 4, n, 0, first_index);
+}
+
+int64_t chip_db_size(const chip_ctx *c)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    return published_rows(c);
+}
+
+int chip_db_read_rows_f32(chip_ctx *c, const int64_t *rows, int64_t n, float *out) { return read_rows(c, rows, n, out, 4); }
+int chip_db_read_rows_f64(chip_ctx *c, const int64_t *rows, int64_t n, double *out) { return read_rows(c, rows, n, out, 8); }
+
+int chip_db_append_synthetic(chip_ctx *c, int64_t n, uint64_t seed,
+                             const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    return c->group ? group_append_synthetic(c, n, seed, plant_dst, plant_src, plant_kind, n_plant)
+                    : ctx_append_synthetic(c, n, seed, plant_dst, plant_src, plant_kind, n_plant);
+}
+
+// ------------------------------------------------------------------------------------------------ queries
+static int check_query_args(chip_ctx *c, int64_t k, int32_t nq, int32_t topk, int64_t *n_global)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    if (nq < 1 || nq > CHIP_MAX_NQ || topk < 1 || topk > CHIP_MAX_TOPK) return CHIP_ERR_UNSUPPORTED;
+    *n_global = published_rows(c);
+    if (k < 0 || k > *n_global) return CHIP_ERR_RANGE;
+    return CHIP_OK;
+}
+
+static int query_common(chip_ctx *c, int64_t k, const int64_t *query_rows, const void *vectors, int vec_elem, int32_t nq, int32_t topk,
+                        double *scores, int64_t *idx)
+{
+    int64_t n = 0;
+    int rc = check_query_args(c, k, nq, topk, &n);
+    if (rc != CHIP_OK) return rc;
+    if (!query_rows && !vectors) return CHIP_ERR_INVALID_ARG;
+    if (c->group) return group_query(c, k, query_rows, vectors, vec_elem, nq, topk, scores, idx);
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    const void *q[CHIP_MAX_NQ];
+    RingGuard rg(c);
+    rc = query_rows ? query_row_ptrs(c, query_rows, nq, n, q) : upload_query_vectors(c, vectors, vec_elem, nq, q);
+    if (rc != CHIP_OK) return rc;
+    if (c->xchg) return xchg_query(c, k, q, nq, topk, scores, idx);   // every rank must make the same call
+    rc = enqueue_scan_merge(c, k, q, nq, topk, 0, nullptr, c->topk_dev, nullptr, false);
+    if (rc != CHIP_OK) return rc;
+    return sync_topk_out(c, nq, topk, scores, idx);
+}
+
+int chip_query_rows(chip_ctx *c, int64_t k, const int64_t *query_rows, int32_t nq, int32_t topk, double *scores, int64_t *idx)
+{
+    if (!query_rows) return CHIP_ERR_INVALID_ARG;
+    return query_common(c, k, query_rows, nullptr, 0, nq, topk, scores, idx);
+}
+
+int chip_query_vectors_f32(chip_ctx *c, int64_t k, const float *queries, int32_t nq, int32_t topk, double *scores, int64_t *idx)
+{
+    if (!queries) return CHIP_ERR_INVALID_ARG;
+    return query_common(c, k, nullptr, queries, 4, nq, topk, scores, idx);
+}
+
+int chip_query_vectors_f64(chip_ctx *c, int64_t k, const double *queries, int32_t nq, int32_t topk, double *scores, int64_t *idx)
+{
+    if (!queries) return CHIP_ERR_INVALID_ARG;
+    return query_common(c, k, nullptr, queries, 8, nq, topk, scores, idx);
+}
+
+int chip_query_scores(chip_ctx *c, int64_t k, int64_t query_row, double *u)
+{
+    if (!c || !u) return CHIP_ERR_INVALID_ARG;
+    const int64_t n = published_rows(c);
+    if (k < 0 || k > n || query_row < 0 || query_row >= n) return CHIP_ERR_RANGE;
+    if (c->group) return group_scores(c, k, query_row, u);
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    const void *q[1];
+    RingGuard rg(c);
+    int rc = query_row_ptrs(c, &query_row, 1, n, q);
+    if (rc != CHIP_OK) return rc;
+    // a sharded ctx fills only the entries of the rows it owns (u[i], i % shard_count == shard_rank)
+    return ctx_scores_local(c, k, q[0], u, c->nranks, c->nranks == 1 ? 0 : c->rank);
+}
+
+// ------------------------------------------------------------------------------------------------ tick
+int chip_loop_tick(chip_ctx *c, int64_t l, const chip_dot_params *p, chip_tick_result *out)
+{
+    if (!c || !p || !out) return CHIP_ERR_INVALID_ARG;
+    if (c->group) {
+        const int rc = group_tick_enqueue(c, l, p, CHIP_MAX_INFLIGHT - 1);
+        return rc != CHIP_OK ? rc : group_tick_collect(c, CHIP_MAX_INFLIGHT - 1, out);
+    }
+    if (c->nranks != 1 && !c->xchg) return CHIP_ERR_UNSUPPORTED;  // host-driven exchange: chip_scan_local + chip_merge_decide
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    Slot &s = c->slots[CHIP_MAX_INFLIGHT - 1];
+    int rc = tick_enqueue_slot(c, l, p, s);
+    if (rc != CHIP_OK) return rc;
+    return tick_collect_slot(c, s, out);
+}
+
+int chip_loop_tick_enqueue(chip_ctx *c, int64_t l, const chip_dot_params *p, int32_t slot)
+{
+    if (!c || !p || slot < 0 || slot >= CHIP_MAX_INFLIGHT - 1) return CHIP_ERR_INVALID_ARG;
+    if (c->group) return group_tick_enqueue(c, l, p, slot);
+    if (c->nranks != 1 && !c->xchg) return CHIP_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    return tick_enqueue_slot(c, l, p, c->slots[slot]);
+}
+
+int chip_loop_tick_collect(chip_ctx *c, int32_t slot, chip_tick_result *out)
+{
+    if (!c || !out || slot < 0 || slot >= CHIP_MAX_INFLIGHT - 1) return CHIP_ERR_INVALID_ARG;
+    if (c->group) return group_tick_collect(c, slot, out);
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    return tick_collect_slot(c, c->slots[slot], out);
+}
+
+int64_t chip_loop_last_l(const chip_ctx *c)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    return c->last_l;
+}
+
+void chip_loop_reset(chip_ctx *c)
+{
+    if (!c) return;
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    c->last_l = 0;
+}
+
+int chip_scan_local(chip_ctx *c, int64_t l, const chip_dot_params *p, int32_t topk, void *dev_out, int32_t *status)
+{
+    if (!c || !p || !dev_out || !status) return CHIP_ERR_INVALID_ARG;
+    if (c->group) return CHIP_ERR_UNSUPPORTED;
+    if (topk < 1 || topk > CHIP_MAX_TOPK) return CHIP_ERR_UNSUPPORTED;
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    int64_t k = 0;
+    int rc = tick_prepare(published_rows(c), c->last_l, l, p, status, &k);
+    if (rc == CHIP_OK && *status == CHIP_TICK_TOO_SHORT) c->last_l = l;
+    if (rc != CHIP_OK || *status != CHIP_TICK_SCANNED) return rc;
+    const int64_t rows[3] = {l - 1, l - 2, l - 3};
+    const void *q[3];
+    RingGuard rg(c);
+    rc = query_row_ptrs(c, rows, 3, l, q);
+    if (rc != CHIP_OK) return rc;
+    // scan on s_scan, then (behind an event) the local merge on the ctx stream writes this rank's 3 x topk list to
+    // dev_out: everything the caller enqueues next on the ctx stream (the all-gather) is ordered after it, while the
+    // next tick's scan is free to start as soon as this scan ends.
+    rc = enqueue_scan_merge(c, k, q, 3, topk, l, nullptr, (chip_topk_entry *)dev_out, nullptr, true);
+    if (rc == CHIP_OK) c->last_l = l;  // :1098
+    return rc;
+}
+
 int chip_merge_decide(chip_ctx *c, int64_t l, const chip_dot_params *p, const void *dev_gathered, int32_t n_lists,
                       int32_t topk, chip_tick_result *out)
 {
     if (!c || !p || !dev_gathered || !out || n_lists < 1) return CHIP_ERR_INVALID_ARG;
+    if (c->group) return CHIP_ERR_UNSUPPORTED;
     if (topk < 1 || topk > CHIP_MAX_TOPK) return CHIP_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> qlk(c->query_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
@@ -753,6 +938,7 @@ int chip_merge_decide_enqueue(chip_ctx *c, int64_t l, const chip_dot_params *p, 
                               int32_t topk, int32_t slot)
 {
     if (!c || !p || !dev_gathered || n_lists < 1 || slot < 0 || slot >= CHIP_MAX_INFLIGHT - 1) return CHIP_ERR_INVALID_ARG;
+    if (c->group) return CHIP_ERR_UNSUPPORTED;
     if (topk < 1 || topk > CHIP_MAX_TOPK) return CHIP_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> qlk(c->query_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
@@ -764,24 +950,29 @@ int chip_get_info(const chip_ctx *c, chip_info *info)
 {
     if (!c || !info) return CHIP_ERR_INVALID_ARG;
     std::memset(info, 0, sizeof *info);
-    std::lock_guard<std::mutex> lk(c->mu);
+    const Ctx *r = c->group ? group_root(const_cast<chip_ctx *>(c)) : c;
+    std::lock_guard<std::mutex> lk(r->mu);
     info->abi_version = CHIP_ABI_VERSION;
-    info->D = c->D;
-    info->device = c->device;
-    info->shard_rank = c->rank;
-    info->shard_count = c->nranks;
-    info->n_cus = c->n_cus;
-    info->rows_global = c->rows_global;
-    info->rows_local = c->rows_local;
-    info->capacity_local = (int64_t)c->segs.size() * c->seg_rows;
-    info->lossy_rows = c->lossy_rows;
-    std::strncpy(info->arch, c->arch, sizeof(info->arch) - 1);
+    info->D = r->D;
+    info->device = r->device;
+    info->shard_rank = r->rank;
+    info->shard_count = r->nranks;
+    info->n_cus = r->n_cus;
+    info->rows_global = r->rows_global;
+    info->rows_local = r->rows_local;
+    info->capacity_local = (int64_t)r->segs.size() * r->seg_rows;
+    info->lossy_rows = r->lossy_rows;
+    std::strncpy(info->arch, r->arch, sizeof(info->arch) - 1);
+    info->storage_bytes = r->elem;
+    info->n_devices = c->group ? group_size(c) : 1;
+    info->exchange = c->group ? c->group_transport : (c->xchg ? CHIP_EXCHANGE_RCCL : CHIP_EXCHANGE_NONE);
     return CHIP_OK;
 }
 
 int chip_profile_enable(chip_ctx *c, int32_t on)
 {
     if (!c) return CHIP_ERR_INVALID_ARG;
+    if (c->group) return group_profile_enable(c, on);
     std::lock_guard<std::mutex> qlk(c->query_mu);
     c->prof_on = on != 0;
     return CHIP_OK;
@@ -790,6 +981,7 @@ int chip_profile_enable(chip_ctx *c, int32_t on)
 int chip_profile_reset(chip_ctx *c)
 {
     if (!c) return CHIP_ERR_INVALID_ARG;
+    if (c->group) c = static_cast<chip_ctx *>(group_root(c));
     std::lock_guard<std::mutex> qlk(c->query_mu);
     c->prof_used = 0;
     return CHIP_OK;
@@ -798,6 +990,11 @@ int chip_profile_reset(chip_ctx *c)
 int chip_profile_scan(chip_ctx *c, double *total_ms, int64_t *n_launches, double *bytes_per_launch_last, double *span_ms)
 {
     if (!c) return CHIP_ERR_INVALID_ARG;
+    if (c->group) {   // the root device's launches (every device scans its own 1/G of the prefix)
+        const int rc = group_synchronize(c);
+        if (rc != CHIP_OK) return rc;
+        c = static_cast<chip_ctx *>(group_root(c));
+    }
     std::lock_guard<std::mutex> qlk(c->query_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
     CHIP_HIP(c, hipStreamSynchronize(c->s_scan));

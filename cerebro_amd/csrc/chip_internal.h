@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <mutex>
+#include <condition_variable>
 #include <vector>
 #include "../../include/cerebro_hip.h"
 
@@ -15,13 +16,13 @@ constexpr int64_t kSegBytesTarget = 512ll << 20;  // ~512 MiB per DB segment
 
 // ---- launch argument blocks (passed by value; all members wave-uniform) ----
 struct ScanArgs {
-    const float *const *seg_table;  // device array of segment base pointers
+    const void *const *seg_table;   // device array of segment base pointers (rows of float or double: Ctx::elem)
     int32_t seg_shift;              // local row r lives in segment r >> seg_shift ...
     int64_t seg_mask;               // ... at row (r & seg_mask)
     int64_t n_rows;                 // local rows [0, n_rows) are scanned
     int32_t D;
     int32_t K;
-    const float *q[CHIP_MAX_NQ];    // query descriptors (device, fp32, D each, 16-B aligned)
+    const void *q[CHIP_MAX_NQ];     // query descriptors (device, storage type, D each, 16-B aligned)
     int64_t idx_mul, idx_add;       // global index = local * idx_mul + idx_add  (round-robin shard map)
     chip_topk_entry *partial;       // [gridDim.x][NQ][K]
 };
@@ -43,8 +44,8 @@ struct Ctx;
 int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid);
 int launch_merge(Ctx *c, hipStream_t s, const MergeArgs &a, int nq);
 int scan_grid_for(const Ctx *c, int64_t n_rows, int nq);
-int launch_narrow_f64(Ctx *c, hipStream_t s, const double *src, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring);
-int launch_copy_f32(Ctx *c, hipStream_t s, const float *src, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring);
+int launch_scores(Ctx *c, hipStream_t s, const ScanArgs &a, double *out_dev);   // K1s: all scores of one query, out[local row]
+int launch_store_rows(Ctx *c, hipStream_t s, const void *src, int src_elem, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring);
 int launch_synth(Ctx *c, hipStream_t s, int64_t first_global, int64_t n, uint64_t seed,
                  const int64_t *plant_dst_dev, const int64_t *plant_src_dev, const int32_t *plant_kind_dev, int64_t n_plant);
 
@@ -56,6 +57,9 @@ struct Slot {
     bool immediate = false;             // result already final on host (skipped / too short)
 };
 
+struct Exchange;   // chip_multi.hip: how a sharded ctx trades its per-shard top-k lists (RCCL communicator / device copies)
+struct Group;      // chip_multi.hip: a ctx made of G per-device sub-contexts driven from one process
+
 struct Ctx {
     int32_t D = 0;
     int32_t device = 0;
@@ -63,12 +67,17 @@ struct Ctx {
     int32_t n_cus = 0;
     char arch[32] = {0};
 
+    // --- storage type: 4 = float rows (default), 8 = double rows.  store_auto: still undecided -- the first append of a
+    //     descriptor that is not float32-representable into the EMPTY DB switches to double (chip_create semantics).
+    int32_t elem = 4;
+    bool store_auto = true;
+
     // --- DB storage: fixed-size segments, never moved once allocated ---
     int32_t seg_shift = 0;
     int64_t seg_rows = 0;
-    std::vector<float *> segs;           // host copy of the table
-    float **seg_table_dev = nullptr;     // device table [kMaxSegs]
-    float *ring_dev = nullptr;           // [CHIP_RING_ROWS][D]  most recent rows (all ranks)
+    std::vector<void *> segs;            // host copy of the table
+    void **seg_table_dev = nullptr;      // device table [kMaxSegs]
+    void *ring_dev = nullptr;            // [CHIP_RING_ROWS][D]  most recent rows (all ranks)
     int64_t rows_global = 0;             // published length (guarded by mu)
     int64_t rows_local = 0;
     int64_t lossy_rows = 0;
@@ -110,7 +119,18 @@ struct Ctx {
     chip_topk_entry *topk_dev = nullptr;      // [CHIP_MAX_NQ][CHIP_MAX_TOPK]
     chip_topk_entry *topk_host = nullptr;     // pinned, device-visible: the last block writes results straight here
 
-    float *qvec_dev = nullptr;                // [CHIP_MAX_NQ][D] external query vectors
+    void *qvec_dev = nullptr;                 // [CHIP_MAX_NQ][D] external query vectors (storage type)
+    double *scores_dev = nullptr;             // chip_query_scores scratch (grown on demand)
+    int64_t scores_cap = 0;
+
+    // --- sharded tick inside the library (chip_multi.hip) ---
+    std::vector<char> qconv;                  // host conversion scratch of external query vectors
+    int64_t cap_hint = 0;
+    int32_t group_transport = 0;              // CHIP_EXCHANGE_* of a group ctx
+    mutable int last_comm = 0;                // last ncclResult_t
+    Exchange *xchg = nullptr;                 // non-null: chip_loop_tick* work on this sharded ctx
+    Group *group = nullptr;                   // non-null: this ctx is a group of per-device sub-contexts
+    Ctx *parent = nullptr;                    // sub-context of a group
     Slot slots[CHIP_MAX_INFLIGHT];
     int64_t last_l = 0;
 
@@ -151,9 +171,57 @@ inline int64_t local_count(const Ctx *c, int64_t k) {
     if (c->nranks == 1) return k;
     return k > c->rank ? (k - c->rank + c->nranks - 1) / c->nranks : 0;
 }
-inline float *row_ptr_host(const Ctx *c, int64_t local) {
-    return c->segs[(size_t)(local >> c->seg_shift)] + (local & (c->seg_rows - 1)) * (int64_t)c->D;
+inline char *row_ptr_host(const Ctx *c, int64_t local) {
+    return static_cast<char *>(c->segs[(size_t)(local >> c->seg_shift)]) + (local & (c->seg_rows - 1)) * (int64_t)c->D * c->elem;
 }
+inline char *ring_ptr(const Ctx *c, int64_t g) {
+    return static_cast<char *>(c->ring_dev) + (g % CHIP_RING_ROWS) * (int64_t)c->D * c->elem;
+}
+
+// ---- chip_api.hip: single-ctx building blocks, shared with chip_multi.hip ----
+struct RingGuard {   // sharded ctx: residency check .. scan event recorded, vs the appender's ring writes (see query_row_ptrs)
+    std::unique_lock<std::mutex> lk;
+    explicit RingGuard(Ctx *c) : lk(c->ring_mu, std::defer_lock) { if (c->ring_dev) lk.lock(); }
+};
+int ctx_create(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device, int32_t rank, int32_t nranks, uint32_t flags);
+void ctx_destroy(chip_ctx *c);
+int ctx_append(Ctx *c, const void *desc, int src_elem, int64_t n, uint32_t flags, int64_t *first_index);
+int ctx_append_synthetic(Ctx *c, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant);
+int ctx_read_row(Ctx *c, int64_t g, int64_t total, void *out);          // one row, storage type, async on s_query
+int query_row_ptrs(Ctx *c, const int64_t *rows, int nq, int64_t n_global, const void **q);
+int upload_query_vectors(Ctx *c, const void *queries, int src_elem, int nq, const void **q);   // -> qvec_dev (on s_scan)
+int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, int64_t l, const chip_dot_params *p,
+                       chip_topk_entry *out, chip_tick_result *res, bool tick);
+int merge_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, const void *dev_gathered, int32_t n_lists, int32_t topk, Slot &s);
+int merge_enqueue_out(Ctx *c, const void *dev_gathered, int32_t n_lists, int nq, int32_t topk, chip_topk_entry *out);
+int tick_prepare(int64_t rows_global, int64_t last_l, int64_t l, const chip_dot_params *p, int32_t *status, int64_t *k_out);
+void fill_immediate(chip_tick_result *r, int32_t status);
+int tick_collect_slot(Ctx *c, Slot &s, chip_tick_result *out);
+int sync_topk_out(Ctx *c, int nq, int K, double *scores, int64_t *idx);
+int ctx_scores_local(Ctx *c, int64_t k, const void *q, double *u_global, int64_t stride_mul, int64_t stride_add);
+int env_int(const char *name, int dflt);
+constexpr uint32_t kCreateStoreMask = 3u;   // CHIP_CREATE_STORE_F32 | CHIP_CREATE_STORE_F64
+
+// ---- chip_multi.hip: exchange of per-shard lists inside the library (RCCL / device copies), groups of sub-contexts ----
+constexpr int kXRing = 64;                  // >= CHIP_MAX_INFLIGHT: list buffers of a tick are not reused while it is in flight
+constexpr int kListEntries = CHIP_MAX_NQ * CHIP_MAX_TOPK;
+void exchange_destroy(Ctx *c);
+void group_destroy(Ctx *c);
+// sharded ctx with an RCCL communicator attached (one process per GPU): scan -> local merge -> all-gather -> merge, all enqueued
+int xchg_tick_enqueue(Ctx *c, int64_t l, int64_t k, const chip_dot_params *p, Slot &s);
+int xchg_query(Ctx *c, int64_t k, const void *const *q, int nq, int K, double *scores, int64_t *idx);
+// group ctx (chip_create_multi): every entry point of the header that makes sense on a group
+int group_append(Ctx *gc, const void *desc, int src_elem, int64_t n, uint32_t flags, int64_t *first_index);
+int group_append_synthetic(Ctx *gc, int64_t n, uint64_t seed, const int64_t *pd, const int64_t *ps, const int32_t *pk, int64_t n_plant);
+int group_read_rows(Ctx *gc, const int64_t *rows, int64_t n, void *out, int out_elem);
+int group_tick_enqueue(Ctx *gc, int64_t l, const chip_dot_params *p, int32_t slot);
+int group_tick_collect(Ctx *gc, int32_t slot, chip_tick_result *out);
+int group_query(Ctx *gc, int64_t k, const int64_t *rows, const void *vectors, int vec_elem, int nq, int K, double *scores, int64_t *idx);
+int group_scores(Ctx *gc, int64_t k, int64_t query_row, double *u);
+int group_synchronize(Ctx *gc);
+int group_profile_enable(Ctx *gc, int on);
+Ctx *group_root(Ctx *gc);
+int group_size(const Ctx *gc);
 
 // pnp.hip
 int pnp_create(Ctx *c);

@@ -1,0 +1,527 @@
+// chip_multi.hip -- the multi-GPU side of libcerebro_hip.so, inside the C ABI (include/cerebro_hip.h, "multi-GPU inside
+// the library").  The descriptor DB is sharded by rows (row i on shard i % G); a tick is G local scans, a per-shard local
+// top-k, ONE exchange of 3 x topk (score, index) entries per shard, and the merge + accept decision of
+// src/Cerebro.cpp:1035-1056 over the G lists.  Two process layouts share the code:
+//   * Exchange on a sharded ctx (one process per GPU): an RCCL communicator attached with chip_comm_init_rank; the
+//     ncclAllGather is enqueued on the ctx stream between the local and the global merge, so that it overlaps the NEXT
+//     tick's scan (which runs on the ctx's scan streams) -- no host synchronisation inside a tick.
+//   * Group (one process, G GPUs: the shape of the reference, whose producer is one thread of one process,
+//     src/cerebro_node.cpp:499): G sub-contexts, one host worker thread per device, exchange over an ncclCommInitAll
+//     communicator or -- when devices repeat (a 1-GPU box running the G-way code path) or on request -- by device copies.
+// The payload is 384 B per shard per tick (topk 8): latency-bound, xGMI bandwidth is irrelevant.
+#include "chip_internal.h"
+#include <rccl/rccl.h>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <new>
+#include <thread>
+
+namespace chip {
+
+static_assert(sizeof(ncclUniqueId) == CHIP_COMM_ID_BYTES, "CHIP_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
+
+#define CHIP_NCCL(ctx, expr)                        \
+    do {                                            \
+        ncclResult_t _r = (expr);                   \
+        if (_r != ncclSuccess) {                    \
+            (ctx)->last_comm = (int)_r;             \
+            return CHIP_ERR_COMM;                   \
+        }                                           \
+    } while (0)
+
+// Per-shard list buffers.  A tick's buffers are picked by a running counter modulo kXRing (>= the number of ticks a caller
+// can keep in flight), so the buffers of tick i are not rewritten before its merge has run -- no backward dependencies
+// between the streams of different devices.
+struct Exchange {
+    ncclComm_t comm = nullptr;
+    int world = 1;
+    chip_topk_entry *local_ring = nullptr;      // [kXRing][kListEntries]          this shard's lists of a tick
+    chip_topk_entry *gathered_ring = nullptr;   // [kXRing][world][kListEntries]   all shards' lists ([world][nq][K] packed)
+    hipEvent_t ev_local[kXRing] = {};           // copy exchange: this shard's list of tick b is written
+    uint64_t n = 0;                             // ticks / queries exchanged so far (one-process-per-GPU layout)
+    chip_topk_entry *local(int b) const { return local_ring + (size_t)b * kListEntries; }
+    chip_topk_entry *gathered(int b) const { return gathered_ring + (size_t)b * world * kListEntries; }
+};
+
+static int exchange_create(Ctx *c, int world, bool need_gathered)
+{
+    Exchange *x = new (std::nothrow) Exchange();
+    if (!x) return CHIP_ERR_OOM;
+    c->xchg = x;
+    x->world = world;
+    CHIP_HIP(c, hipMalloc(&x->local_ring, sizeof(chip_topk_entry) * kXRing * kListEntries));
+    if (need_gathered) CHIP_HIP(c, hipMalloc(&x->gathered_ring, sizeof(chip_topk_entry) * kXRing * kListEntries * (size_t)world));
+    for (int i = 0; i < kXRing; i++) CHIP_HIP(c, hipEventCreateWithFlags(&x->ev_local[i], hipEventDisableTiming));
+    return CHIP_OK;
+}
+
+void exchange_destroy(Ctx *c)
+{
+    Exchange *x = c->xchg;
+    if (!x) return;
+    (void)hipSetDevice(c->device);
+    if (x->comm) (void)ncclCommDestroy(x->comm);
+    if (x->local_ring) (void)hipFree(x->local_ring);
+    if (x->gathered_ring) (void)hipFree(x->gathered_ring);
+    for (hipEvent_t e : x->ev_local)
+        if (e) (void)hipEventDestroy(e);
+    delete x;
+    c->xchg = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ one process per GPU
+// caller: tick_enqueue_slot (query_mu held, device current, tick_prepare said SCANNED)
+int xchg_tick_enqueue(Ctx *c, int64_t l, int64_t k, const chip_dot_params *p, Slot &s)
+{
+    Exchange *x = c->xchg;
+    const int K = CHIP_DEFAULT_TOPK;
+    const int64_t rows[3] = {l - 1, l - 2, l - 3};  // v, vm, vmm (Cerebro.cpp:987-989)
+    const void *q[3];
+    RingGuard rg(c);
+    int rc = query_row_ptrs(c, rows, 3, l, q);
+    if (rc != CHIP_OK) return rc;
+    const int b = (int)(x->n++ % kXRing);
+    rc = enqueue_scan_merge(c, k, q, 3, K, l, nullptr, x->local(b), nullptr, true);   // scan streams -> local merge on the ctx stream
+    if (rc != CHIP_OK) return rc;
+    CHIP_NCCL(c, ncclAllGather(x->local(b), x->gathered(b), sizeof(chip_topk_entry) * 3 * K, ncclChar, x->comm, c->s_query));
+    return merge_enqueue_slot(c, l, p, x->gathered(b), x->world, K, s);               // merge + decision (:1035-1056), every rank
+}
+
+int xchg_query(Ctx *c, int64_t k, const void *const *q, int nq, int K, double *scores, int64_t *idx)
+{
+    Exchange *x = c->xchg;
+    const int b = (int)(x->n++ % kXRing);
+    int rc = enqueue_scan_merge(c, k, q, nq, K, 0, nullptr, x->local(b), nullptr, false);
+    if (rc != CHIP_OK) return rc;
+    CHIP_NCCL(c, ncclAllGather(x->local(b), x->gathered(b), sizeof(chip_topk_entry) * nq * K, ncclChar, x->comm, c->s_query));
+    rc = merge_enqueue_out(c, x->gathered(b), x->world, nq, K, c->topk_dev);
+    if (rc != CHIP_OK) return rc;
+    return sync_topk_out(c, nq, K, scores, idx);
+}
+
+// ------------------------------------------------------------------------------------------------ group: workers
+// One host thread per sub-context: it makes that device current once and enqueues the device's share of every group call,
+// so the host cost of a tick (two launches, a few events, the collective) is paid G-wide in parallel instead of serially.
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has = false, done = false, quit = false;
+    int rc = 0;
+};
+
+struct Group {
+    std::vector<chip_ctx *> subs;
+    std::vector<Worker *> workers;     // workers[g] serves subs[g]; the calling thread serves subs[0] itself
+    std::vector<char> same_dev;        // subs[g] lives on the root's device
+    int transport = CHIP_EXCHANGE_COPY;
+    uint64_t n = 0;                    // ticks / queries exchanged so far
+};
+
+static void worker_main(Worker *w, int device)
+{
+    (void)hipSetDevice(device);
+    std::unique_lock<std::mutex> lk(w->m);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->has || w->quit; });
+        if (w->quit) return;
+        std::function<int()> job = std::move(w->job);
+        w->has = false;
+        lk.unlock();
+        const int rc = job();
+        lk.lock();
+        w->rc = rc;
+        w->done = true;
+        w->cv.notify_all();
+    }
+}
+
+// fn(g) for every sub-context, concurrently; first non-OK status wins
+static int run_all(Group *G, const std::function<int(int)> &fn)
+{
+    const int n = (int)G->subs.size();
+    for (int g = 1; g < n; g++) {
+        Worker *w = G->workers[g];
+        std::lock_guard<std::mutex> lk(w->m);
+        w->job = [&fn, g] { return fn(g); };
+        w->has = true;
+        w->done = false;
+        w->cv.notify_all();
+    }
+    int rc = fn(0);
+    for (int g = 1; g < n; g++) {
+        Worker *w = G->workers[g];
+        std::unique_lock<std::mutex> lk(w->m);
+        w->cv.wait(lk, [&] { return w->done; });
+        if (rc == CHIP_OK) rc = w->rc;
+    }
+    return rc;
+}
+
+Ctx *group_root(Ctx *gc) { return gc->group->subs[0]; }
+int group_size(const Ctx *gc) { return (int)gc->group->subs.size(); }
+
+void group_destroy(Ctx *gc)
+{
+    Group *G = gc->group;
+    if (!G) return;
+    for (Worker *w : G->workers) {
+        if (!w) continue;
+        {
+            std::lock_guard<std::mutex> lk(w->m);
+            w->quit = true;
+            w->cv.notify_all();
+        }
+        if (w->th.joinable()) w->th.join();
+        delete w;
+    }
+    // communicators first (ncclCommDestroy of an ncclCommInitAll clique wants all of them alive), then the contexts
+    for (chip_ctx *s : G->subs) exchange_destroy(s);
+    for (chip_ctx *s : G->subs) ctx_destroy(s);
+    delete G;
+    gc->group = nullptr;
+}
+
+static void mirror_state(Ctx *gc)
+{
+    Ctx *r = group_root(gc);
+    std::lock_guard<std::mutex> lk(gc->mu);
+    std::lock_guard<std::mutex> lk2(r->mu);
+    gc->rows_global = r->rows_global;
+    gc->elem = r->elem;
+    gc->store_auto = r->store_auto;
+}
+
+// ------------------------------------------------------------------------------------------------ group: DB
+int group_append(Ctx *gc, const void *desc, int src_elem, int64_t n, uint32_t flags, int64_t *first_index)
+{
+    if (!desc || n < 0) return CHIP_ERR_INVALID_ARG;
+    Group *G = gc->group;
+    std::lock_guard<std::mutex> alk(gc->append_mu);
+    // every device is fed the same stream and keeps the rows it owns (+ the replicated ring of the newest rows); the
+    // storage-type decision of an undecided DB depends on the data only, so all devices take it alike
+    std::vector<int64_t> first(G->subs.size(), -1);
+    const int rc = run_all(G, [&](int g) { return ctx_append(G->subs[g], desc, src_elem, n, flags, &first[(size_t)g]); });
+    if (first_index) *first_index = first[0];
+    mirror_state(gc);
+    return rc;
+}
+
+int group_append_synthetic(Ctx *gc, int64_t n, uint64_t seed, const int64_t *pd, const int64_t *ps, const int32_t *pk, int64_t n_plant)
+{
+    Group *G = gc->group;
+    std::lock_guard<std::mutex> alk(gc->append_mu);
+    const int rc = run_all(G, [&](int g) { return ctx_append_synthetic(G->subs[g], n, seed, pd, ps, pk, n_plant); });
+    mirror_state(gc);
+    return rc;
+}
+
+int group_read_rows(Ctx *gc, const int64_t *rows, int64_t n, void *out, int out_elem)
+{
+    Group *G = gc->group;
+    std::lock_guard<std::mutex> qlk(gc->query_mu);
+    const int elem = gc->elem, D = gc->D;
+    if (out_elem < elem) return CHIP_ERR_NOT_F32;
+    int64_t total;
+    {
+        std::lock_guard<std::mutex> lk(gc->mu);
+        total = gc->rows_global;
+    }
+    const bool conv = out_elem != elem;
+    std::vector<float> tmp;
+    if (conv) tmp.resize((size_t)n * D);
+    const int ng = (int)G->subs.size();
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t g = rows[i];
+        if (g < 0 || g >= total) return CHIP_ERR_RANGE;
+        Ctx *s = G->subs[(size_t)(g % ng)];
+        CHIP_HIP(s, hipSetDevice(s->device));
+        void *dst = conv ? (void *)(tmp.data() + (size_t)i * D) : (void *)(static_cast<char *>(out) + (size_t)i * D * out_elem);
+        const int rc = ctx_read_row(s, g, total, dst);
+        if (rc != CHIP_OK) return rc;
+    }
+    for (chip_ctx *s : G->subs) {
+        CHIP_HIP(s, hipSetDevice(s->device));
+        CHIP_HIP(s, hipStreamSynchronize(s->s_query));
+    }
+    if (conv)
+        for (size_t i = 0; i < tmp.size(); i++) static_cast<double *>(out)[i] = (double)tmp[i];
+    return CHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ group: scan + exchange
+// What one group scan needs: the prefix, the queries (rows of the DB or external vectors), K, and where the merged result
+// goes (a tick slot with the accept decision, or the root's pinned top-k buffer).
+struct GroupScan {
+    int64_t k = 0, l = 0;
+    int nq = 0, K = 0;
+    const int64_t *rows = nullptr;      // query rows, or ...
+    const void *vectors = nullptr;      // ... external vectors (host)
+    int vec_elem = 0;
+    int64_t n_global = 0;
+    const chip_dot_params *p = nullptr; // non-null: tick (decision into slot)
+    Slot *slot = nullptr;
+    bool tick = false;
+};
+
+// device g's share: local scan -> local top-k list -> (RCCL) all-gather [-> root: merge]
+static int sub_scan(Group *G, int g, const GroupScan &j, int b)
+{
+    Ctx *c = G->subs[(size_t)g];
+    Ctx *root = G->subs[0];
+    Exchange *x = c->xchg;
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    const void *q[CHIP_MAX_NQ];
+    RingGuard rg(c);
+    int rc = j.rows ? query_row_ptrs(c, j.rows, j.nq, j.n_global, q) : upload_query_vectors(c, j.vectors, j.vec_elem, j.nq, q);
+    if (rc != CHIP_OK) return rc;
+    const size_t list = (size_t)j.nq * j.K;
+    const bool direct = G->transport == CHIP_EXCHANGE_COPY && G->same_dev[(size_t)g];   // straight into the root's gather buffer
+    chip_topk_entry *dst = direct ? root->xchg->gathered(b) + (size_t)g * list : x->local(b);
+    rc = enqueue_scan_merge(c, j.k, q, j.nq, j.K, j.l, nullptr, dst, nullptr, j.tick);
+    if (rc != CHIP_OK) return rc;
+    if (G->transport == CHIP_EXCHANGE_RCCL) {
+        // one thread per device, each on its own communicator of the clique: the classic multi-threaded NCCL layout (no group call)
+        CHIP_NCCL(c, ncclAllGather(x->local(b), x->gathered(b), sizeof(chip_topk_entry) * list, ncclChar, x->comm, c->s_query));
+        if (g == 0) {
+            if (j.p) return merge_enqueue_slot(c, j.l, j.p, x->gathered(b), x->world, j.K, *j.slot);
+            return merge_enqueue_out(c, x->gathered(b), x->world, j.nq, j.K, c->topk_dev);
+        }
+    } else if (g != 0) {
+        CHIP_HIP(c, hipEventRecord(x->ev_local[b], c->s_query));
+    }
+    return CHIP_OK;
+}
+
+// copy exchange, root side (after every device has enqueued and recorded): wait for the lists, pull in those that live on
+// other devices, merge
+static int root_gather_merge(Group *G, const GroupScan &j, int b)
+{
+    Ctx *root = G->subs[0];
+    Exchange *rx = root->xchg;
+    CHIP_HIP(root, hipSetDevice(root->device));
+    const size_t list = (size_t)j.nq * j.K;
+    for (size_t g = 1; g < G->subs.size(); g++) {
+        Ctx *c = G->subs[g];
+        CHIP_HIP(root, hipStreamWaitEvent(root->s_query, c->xchg->ev_local[b], 0));
+        if (!G->same_dev[g])
+            CHIP_HIP(root, hipMemcpyPeerAsync(rx->gathered(b) + g * list, root->device, c->xchg->local(b), c->device,
+                                              sizeof(chip_topk_entry) * list, root->s_query));
+    }
+    if (j.p) return merge_enqueue_slot(root, j.l, j.p, rx->gathered(b), (int)G->subs.size(), j.K, *j.slot);
+    return merge_enqueue_out(root, rx->gathered(b), (int)G->subs.size(), j.nq, j.K, root->topk_dev);
+}
+
+static int group_scan(Group *G, const GroupScan &j)
+{
+    const int b = (int)(G->n++ % kXRing);
+    int rc = run_all(G, [&](int g) { return sub_scan(G, g, j, b); });
+    if (rc != CHIP_OK) return rc;
+    if (G->transport == CHIP_EXCHANGE_COPY) rc = root_gather_merge(G, j, b);
+    return rc;
+}
+
+int group_tick_enqueue(Ctx *gc, int64_t l, const chip_dot_params *p, int32_t slot)
+{
+    Group *G = gc->group;
+    Ctx *root = G->subs[0];
+    std::lock_guard<std::mutex> qlk(gc->query_mu);
+    Slot &s = root->slots[slot];
+    if (s.in_flight) return CHIP_ERR_BUSY;
+    int64_t n;
+    {
+        std::lock_guard<std::mutex> lk(gc->mu);
+        n = gc->rows_global;
+    }
+    int32_t status = 0;
+    int64_t k = 0;
+    int rc = tick_prepare(n, gc->last_l, l, p, &status, &k);
+    if (rc != CHIP_OK) return rc;
+    if (status != CHIP_TICK_SCANNED) {
+        if (status == CHIP_TICK_TOO_SHORT) gc->last_l = l;
+        fill_immediate(s.host, status);
+        s.immediate = true;
+        s.in_flight = true;
+        return CHIP_OK;
+    }
+    const int64_t rows[3] = {l - 1, l - 2, l - 3};  // v, vm, vmm (Cerebro.cpp:987-989)
+    GroupScan j;
+    j.k = k; j.l = l; j.nq = 3; j.K = CHIP_DEFAULT_TOPK; j.rows = rows; j.n_global = l; j.p = p; j.slot = &s; j.tick = true;
+    rc = group_scan(G, j);
+    if (rc != CHIP_OK) return rc;
+    gc->last_l = l;   // :1098
+    return CHIP_OK;
+}
+
+int group_tick_collect(Ctx *gc, int32_t slot, chip_tick_result *out)
+{
+    Ctx *root = group_root(gc);
+    std::lock_guard<std::mutex> qlk(gc->query_mu);
+    CHIP_HIP(root, hipSetDevice(root->device));
+    return tick_collect_slot(root, root->slots[slot], out);
+}
+
+int group_query(Ctx *gc, int64_t k, const int64_t *rows, const void *vectors, int vec_elem, int nq, int K, double *scores, int64_t *idx)
+{
+    Group *G = gc->group;
+    Ctx *root = G->subs[0];
+    std::lock_guard<std::mutex> qlk(gc->query_mu);
+    GroupScan j;
+    j.k = k; j.nq = nq; j.K = K; j.rows = rows; j.vectors = vectors; j.vec_elem = vec_elem;
+    {
+        std::lock_guard<std::mutex> lk(gc->mu);
+        j.n_global = gc->rows_global;
+    }
+    int rc = group_scan(G, j);
+    if (rc != CHIP_OK) return rc;
+    CHIP_HIP(root, hipSetDevice(root->device));
+    return sync_topk_out(root, nq, K, scores, idx);
+}
+
+int group_scores(Ctx *gc, int64_t k, int64_t query_row, double *u)
+{
+    Group *G = gc->group;
+    std::lock_guard<std::mutex> qlk(gc->query_mu);
+    int64_t n;
+    {
+        std::lock_guard<std::mutex> lk(gc->mu);
+        n = gc->rows_global;
+    }
+    const int ng = (int)G->subs.size();
+    return run_all(G, [&](int g) -> int {
+        Ctx *c = G->subs[(size_t)g];
+        std::lock_guard<std::mutex> lk(c->query_mu);
+        CHIP_HIP(c, hipSetDevice(c->device));
+        const void *q[1];
+        RingGuard rg(c);
+        const int rc = query_row_ptrs(c, &query_row, 1, n, q);
+        if (rc != CHIP_OK) return rc;
+        return ctx_scores_local(c, k, q[0], u, ng, ng == 1 ? 0 : g);   // disjoint entries of u per device
+    });
+}
+
+int group_synchronize(Ctx *gc)
+{
+    for (chip_ctx *s : gc->group->subs) {
+        const int rc = chip_synchronize(s);
+        if (rc != CHIP_OK) return rc;
+    }
+    return CHIP_OK;
+}
+
+int group_profile_enable(Ctx *gc, int on)
+{
+    for (chip_ctx *s : gc->group->subs) {
+        std::lock_guard<std::mutex> qlk(s->query_mu);
+        s->prof_on = on != 0;
+    }
+    return CHIP_OK;
+}
+
+}  // namespace chip
+
+using namespace chip;
+
+extern "C" {
+
+int chip_last_comm_error(const chip_ctx *ctx, const char **text)
+{
+    if (!ctx) return (int)ncclInvalidArgument;
+    int r = ctx->last_comm;
+    if (ctx->group)
+        for (const chip_ctx *s : ctx->group->subs)
+            if (s->last_comm) r = s->last_comm;
+    if (text) *text = ncclGetErrorString((ncclResult_t)r);
+    return r;
+}
+
+int chip_create_multi(chip_ctx **out, int32_t D, int64_t capacity_hint, const int32_t *devices, int32_t n_devices, uint32_t flags)
+{
+    if (!out) return CHIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!devices || n_devices < 1 || n_devices > 64 || capacity_hint < 0) return CHIP_ERR_INVALID_ARG;
+    if (flags & ~(kCreateStoreMask | CHIP_MULTI_EXCHANGE_COPY)) return CHIP_ERR_INVALID_ARG;
+    bool repeated = false;
+    for (int a = 0; a < n_devices; a++)
+        for (int b = a + 1; b < n_devices; b++) repeated = repeated || devices[a] == devices[b];
+    chip_ctx *gc = new (std::nothrow) chip_ctx();
+    if (!gc) return CHIP_ERR_OOM;
+    Group *G = new (std::nothrow) Group();
+    if (!G) { delete gc; return CHIP_ERR_OOM; }
+    gc->group = G;
+    gc->D = D;
+    gc->nranks = n_devices;
+    gc->device = devices[0];
+    G->transport = ((flags & CHIP_MULTI_EXCHANGE_COPY) || repeated) ? CHIP_EXCHANGE_COPY : CHIP_EXCHANGE_RCCL;
+    gc->group_transport = G->transport;
+    int rc = CHIP_OK;
+    for (int g = 0; g < n_devices && rc == CHIP_OK; g++) {
+        chip_ctx *s = nullptr;
+        rc = ctx_create(&s, D, capacity_hint, devices[g], g, n_devices, flags & kCreateStoreMask);
+        if (rc != CHIP_OK) break;
+        s->parent = gc;
+        G->subs.push_back(s);
+        G->same_dev.push_back(devices[g] == devices[0] ? 1 : 0);
+        // RCCL: every rank receives the gathered lists; copies: only the root's buffer is used
+        rc = exchange_create(s, n_devices, G->transport == CHIP_EXCHANGE_RCCL || g == 0);
+    }
+    if (rc == CHIP_OK && G->transport == CHIP_EXCHANGE_RCCL) {
+        std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
+        const ncclResult_t r = ncclCommInitAll(comms.data(), n_devices, devices);
+        if (r != ncclSuccess) { gc->last_comm = (int)r; rc = CHIP_ERR_COMM; }
+        else
+            for (int g = 0; g < n_devices; g++) G->subs[(size_t)g]->xchg->comm = comms[(size_t)g];
+    }
+    if (rc == CHIP_OK) {
+        G->workers.assign((size_t)n_devices, nullptr);
+        for (int g = 1; g < n_devices; g++) {
+            Worker *w = new (std::nothrow) Worker();
+            if (!w) { rc = CHIP_ERR_OOM; break; }
+            G->workers[(size_t)g] = w;
+            w->th = std::thread(worker_main, w, devices[g]);
+        }
+    }
+    if (rc != CHIP_OK) {
+        // keep the communicator error readable for the caller of a failed create: there is no ctx to ask, so it is lost --
+        // chip_strerror(CHIP_ERR_COMM) is all they get
+        ctx_destroy(gc);
+        return rc;
+    }
+    mirror_state(gc);
+    *out = gc;
+    return CHIP_OK;
+}
+
+int chip_comm_unique_id(void *id_out)
+{
+    if (!id_out) return CHIP_ERR_INVALID_ARG;
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return CHIP_ERR_COMM;
+    std::memcpy(id_out, &id, sizeof id);
+    return CHIP_OK;
+}
+
+int chip_comm_init_rank(chip_ctx *c, const void *id_in, int32_t n_ranks, int32_t rank)
+{
+    if (!c || !id_in) return CHIP_ERR_INVALID_ARG;
+    if (c->group || c->xchg) return CHIP_ERR_UNSUPPORTED;
+    if (n_ranks != c->nranks || rank != c->rank) return CHIP_ERR_INVALID_ARG;   // the communicator must match the shard layout of chip_create
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    if (!c->own_query_stream) return CHIP_ERR_UNSUPPORTED;   // chip_set_stream and an in-library exchange exclude each other
+    ncclUniqueId id;
+    std::memcpy(&id, id_in, sizeof id);
+    ncclComm_t comm = nullptr;
+    CHIP_NCCL(c, ncclCommInitRank(&comm, n_ranks, id, rank));
+    const int rc = exchange_create(c, n_ranks, true);
+    if (rc != CHIP_OK) { (void)ncclCommDestroy(comm); exchange_destroy(c); return rc; }
+    c->xchg->comm = comm;
+    // three small kernels per tick now go through the ctx stream underneath the scans: keep workgroup slots free for them
+    c->scan_reserve = env_int("CHIP_SCAN_RESERVE", 4);
+    return CHIP_OK;
+}
+
+}  // extern "C"

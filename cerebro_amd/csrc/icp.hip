@@ -327,6 +327,7 @@ static int icp_check_args(const double *A, const double *B, int32_t N, const chi
 extern "C" int chip_icp_ransac_enqueue(chip_ctx *c, const double *A, const double *B, int32_t N, const chip_ransac_params *p)
 {
     if (!c) return CHIP_ERR_INVALID_ARG;
+    if (c->group) c = static_cast<chip_ctx *>(chip::group_root(c));
     const int rc = icp_check_args(A, B, N, p);
     if (rc != CHIP_OK) return rc;
     std::lock_guard<std::mutex> lk(c->icp_mu);
@@ -336,6 +337,7 @@ extern "C" int chip_icp_ransac_enqueue(chip_ctx *c, const double *A, const doubl
 extern "C" int chip_icp_ransac_collect(chip_ctx *c, double T_colmajor[16], float *confidence, uint8_t *inlier_mask, chip_ransac_summary *summary)
 {
     if (!c || !T_colmajor || !confidence) return CHIP_ERR_INVALID_ARG;
+    if (c->group) c = static_cast<chip_ctx *>(chip::group_root(c));
     std::lock_guard<std::mutex> lk(c->icp_mu);
     return icp_collect_locked(c, T_colmajor, confidence, inlier_mask, summary);
 }
@@ -344,6 +346,7 @@ extern "C" int chip_icp_ransac(chip_ctx *c, const double *A, const double *B, in
                                double T_colmajor[16], float *confidence, uint8_t *inlier_mask, chip_ransac_summary *summary)
 {
     if (!c || !T_colmajor || !confidence) return CHIP_ERR_INVALID_ARG;
+    if (c->group) c = static_cast<chip_ctx *>(chip::group_root(c));
     int rc = icp_check_args(A, B, N, p);
     if (rc != CHIP_OK) return rc;
     std::lock_guard<std::mutex> lk(c->icp_mu);

@@ -8,7 +8,9 @@
 //   K3 narrow/copy    : M.col(_s) = desc (Cerebro.cpp:1005-1006): f64 -> f32 with a losslessness check.
 //   synth             : on-device synthetic DB (spec = oracle/dot_scan.c).
 //
-// CDNA4 notes: wave = 64; queries live in LDS (NQ*D*4 B) and are read with conflict-free ds_read_b128;
+// Storage type T is float (default: NetVLAD descriptors are float32 values on a float64 wire) or double (descriptors that
+// are genuinely float64, e.g. ReljaNetVLAD's numpy WPCA output, whole_image_desc_compute_server.py:148-149).
+// CDNA4 notes: wave = 64; queries live in LDS (NQ*D*sizeof(T) B) and are read with conflict-free ds_read_b128;
 // DB rows are streamed with 16-B-per-lane non-temporal global loads (1 KiB per wave-instruction, U in flight
 // per lane); the wave id is readfirstlane'd so row bases stay in SGPRs.  No MFMA: AI = NQ/2 flop/B.
 #include "chip_internal.h"
@@ -26,13 +28,17 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // NEXT tick's scan (a fused last-workgroup merge was measured to serialise ~28 us per tick).
 // One 16-byte streaming load of a DB row chunk.  POLICY 1 (production) = the non-temporal hint; 0 = plain; 2..5 = other
 // gfx950 cache-policy bit combinations, reachable only through CHIP_SCAN_VARIANT in tuning builds.
-template <int POLICY>
-__device__ __forceinline__ f32x4 stream_load(const f32x4 *p)
+template <typename T> struct Vec16;                       // 16 bytes of storage elements = one lane's share of a wave load
+template <> struct Vec16<float> { typedef f32x4 type; static constexpr int N = 4; };
+template <> struct Vec16<double> { typedef f64x2 type; static constexpr int N = 2; };
+
+template <int POLICY, typename V>
+__device__ __forceinline__ V stream_load(const V *p)
 {
     if constexpr (POLICY == 0) return *p;
     else if constexpr (POLICY == 1) return __builtin_nontemporal_load(p);
     else {
-        f32x4 v;
+        V v;
         if constexpr (POLICY == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
         else if constexpr (POLICY == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
         else if constexpr (POLICY == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 nt" : "=v"(v) : "v"(p) : "memory");
@@ -41,11 +47,86 @@ __device__ __forceinline__ f32x4 stream_load(const f32x4 *p)
     }
 }
 
-template <int NQ, int U, bool FULL, int NT, int R>
+// Dot products of one DB row with NQ staged queries in the fixed order of DESIGN.md 3: lane L accumulates elements
+// j*CH + N*L + c (j ascending, c = 0..N-1; N = 4 / CH = 256 for float storage, N = 2 / CH = 128 for double) into one fp64
+// accumulator per query by fma -- for float storage the product of two fp32 values is exact in fp64, so fma == mul-then-add;
+// for double storage the single rounding of the fma IS the definition (oracle: orc_dot_tree_f64) -- then the xor butterfly
+// acc[L] += acc[L ^ m], m = 32..1, after which every lane holds the same bits.
+template <typename T, int NQ, int U, bool FULL, int NT, int R>
+__device__ __forceinline__ void rows_dot(const T *const (&row)[R], const T *qs, int D, int lane, double (&acc)[R][NQ])
+{
+    typedef typename Vec16<T>::type V;
+    constexpr int N = Vec16<T>::N, CH = 64 * N;
+    const int e0 = lane * N;
+#pragma unroll
+    for (int rr = 0; rr < R; rr++)
+#pragma unroll
+        for (int q = 0; q < NQ; q++) acc[rr][q] = 0.0;
+    for (int base = 0; base < D; base += CH * U) {
+        V v[R][U];
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = base + u * CH + e0;
+                if (FULL || e < D) v[rr][u] = stream_load<NT>(reinterpret_cast<const V *>(row[rr] + e));
+            }
+        }
+        if constexpr (NT >= 2) {   // inline-asm loads: the compiler does not track them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int rr = 0; rr < R; rr++)
+#pragma unroll
+                for (int u = 0; u < U; u++) asm volatile("" : "+v"(v[rr][u]));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = base + u * CH + e0;
+            if (FULL || e < D) {
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const V w = *reinterpret_cast<const V *>(qs + q * D + e);
+#pragma unroll
+                    for (int rr = 0; rr < R; rr++)
+#pragma unroll
+                        for (int c = 0; c < N; c++) acc[rr][q] = __builtin_fma((double)w[c], (double)v[rr][u][c], acc[rr][q]);
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ double butterfly_sum(double a)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) a = a + __shfl_xor(a, m, 64);
+    return a;
+}
+
+template <typename T, int NQ>
+__device__ __forceinline__ void stage_queries(const ScanArgs &a, T *qs, int tid, int nthreads)
+{
+    typedef typename Vec16<T>::type V;
+    constexpr int N = Vec16<T>::N;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const T *src = static_cast<const T *>(a.q[q]);
+        for (int e = tid * N; e < a.D; e += nthreads * N)
+            *reinterpret_cast<V *>(qs + q * a.D + e) = *reinterpret_cast<const V *>(src + e);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ const T *row_base(const ScanArgs &a, int64_t r)
+{
+    return static_cast<const T *>(a.seg_table[r >> a.seg_shift]) + (r & a.seg_mask) * (int64_t)a.D;
+}
+
+template <typename T, int NQ, int U, bool FULL, int NT, int R>
 __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *qs = reinterpret_cast<float *>(smem);  // [NQ][D]
+    T *qs = reinterpret_cast<T *>(smem);  // [NQ][D]
     const int D = a.D;
     const int K = a.K;
     const int tid = threadIdx.x;
@@ -54,12 +135,7 @@ __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
     const int wpb = blockDim.x >> 6;
 
     // stage the query descriptors once per block (L2-resident after the first block)
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        const float *src = a.q[q];
-        for (int e = tid * 4; e < D; e += blockDim.x * 4)
-            *reinterpret_cast<f32x4 *>(qs + q * D + e) = *reinterpret_cast<const f32x4 *>(src + e);
-    }
+    stage_queries<T, NQ>(a, qs, tid, blockDim.x);
     __syncthreads();
 
     // per-wave running top-K: lane j < K holds the j-th best (score desc, index desc)
@@ -69,69 +145,22 @@ __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
     for (int q = 0; q < NQ; q++) { my_s[q] = -INFINITY; my_i[q] = -1; thr_s[q] = -INFINITY; thr_i[q] = -1; }
 
     const int64_t tw = (int64_t)gridDim.x * wpb;
-    const int e0 = lane * 4;
     // each wave owns rows w, w+tw, ... ; R of them are in flight together (R independent accumulator sets)
     for (int64_t r0 = (int64_t)blockIdx.x * wpb + wave; r0 < a.n_rows; r0 += tw * R) {
-        const float *row[R];
+        const T *row[R];
         double acc[R][NQ];
 #pragma unroll
         for (int rr = 0; rr < R; rr++) {
             const int64_t r = r0 + rr * tw;
-            const int64_t rc = r < a.n_rows ? r : r0;   // clamp (result of a clamped row is discarded)
-            row[rr] = a.seg_table[rc >> a.seg_shift] + (rc & a.seg_mask) * (int64_t)D;
-#pragma unroll
-            for (int q = 0; q < NQ; q++) acc[rr][q] = 0.0;
+            row[rr] = row_base<T>(a, r < a.n_rows ? r : r0);   // clamp (result of a clamped row is discarded)
         }
-        for (int base = 0; base < D; base += 256 * U) {
-            f32x4 v[R][U];
-#pragma unroll
-            for (int rr = 0; rr < R; rr++) {
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const int e = base + u * 256 + e0;
-                    if (FULL || e < D) {
-                        const f32x4 *p = reinterpret_cast<const f32x4 *>(row[rr] + e);
-                        v[rr][u] = stream_load<NT>(p);
-                    }
-                }
-            }
-            if constexpr (NT >= 2) {   // inline-asm loads: the compiler does not track them
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int rr = 0; rr < R; rr++)
-#pragma unroll
-                    for (int u = 0; u < U; u++) asm volatile("" : "+v"(v[rr][u]));
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int e = base + u * 256 + e0;
-                if (FULL || e < D) {
-#pragma unroll
-                    for (int q = 0; q < NQ; q++) {
-                        const f32x4 w = *reinterpret_cast<const f32x4 *>(qs + q * D + e);
-                        const double w0 = (double)w.x, w1 = (double)w.y, w2 = (double)w.z, w3 = (double)w.w;
-#pragma unroll
-                        for (int rr = 0; rr < R; rr++) {
-                            // exact products, one rounding per add: fma == mul-then-add here
-                            acc[rr][q] = __builtin_fma(w0, (double)v[rr][u].x, acc[rr][q]);
-                            acc[rr][q] = __builtin_fma(w1, (double)v[rr][u].y, acc[rr][q]);
-                            acc[rr][q] = __builtin_fma(w2, (double)v[rr][u].z, acc[rr][q]);
-                            acc[rr][q] = __builtin_fma(w3, (double)v[rr][u].w, acc[rr][q]);
-                        }
-                    }
-                }
-            }
-        }
+        rows_dot<T, NQ, U, FULL, NT, R>(row, qs, D, lane, acc);
 #pragma unroll
         for (int rr = 0; rr < R; rr++) {
             const int64_t r = r0 + rr * tw;
             if (r >= a.n_rows) break;   // wave-uniform
-            // fixed butterfly: acc[L] += acc[L ^ m], m = 32..1  (every lane ends with the same bits)
 #pragma unroll
-            for (int q = 0; q < NQ; q++) {
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) acc[rr][q] = acc[rr][q] + __shfl_xor(acc[rr][q], m, 64);
-            }
+            for (int q = 0; q < NQ; q++) acc[rr][q] = butterfly_sum(acc[rr][q]);
             const int64_t gi = r * a.idx_mul + a.idx_add;
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
@@ -200,52 +229,52 @@ __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
     }
 }
 
-template <int NQ, int U, bool FULL, int NT, int R>
+template <typename T, int NQ, int U, bool FULL, int NT, int R>
 static int launch_scan_k(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds, int block)
 {
-    if (lds > 65536) CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_scan_topk<NQ, U, FULL, NT, R>),
+    if (lds > 65536) CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_scan_topk<T, NQ, U, FULL, NT, R>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((db_scan_topk<NQ, U, FULL, NT, R>), dim3(grid), dim3(block), lds, s, a);
+    hipLaunchKernelGGL((db_scan_topk<T, NQ, U, FULL, NT, R>), dim3(grid), dim3(block), lds, s, a);
     CHIP_HIP(c, hipGetLastError());
     return CHIP_OK;
 }
 
-template <int NQ, int U, int NT, int R>
+template <typename T, int NQ, int U, int NT, int R>
 static int launch_scan_t(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds, int block)
 {
-    return a.D % (256 * U) == 0 ? launch_scan_k<NQ, U, true, NT, R>(c, s, a, grid, lds, block)
-                                : launch_scan_k<NQ, U, false, NT, R>(c, s, a, grid, lds, block);
+    return a.D % (64 * Vec16<T>::N * U) == 0 ? launch_scan_k<T, NQ, U, true, NT, R>(c, s, a, grid, lds, block)
+                                             : launch_scan_k<T, NQ, U, false, NT, R>(c, s, a, grid, lds, block);
 }
 
 // scan_variant (CHIP_SCAN_VARIANT, tuning/A-B only): 0 = production (U=8, non-temporal loads, 1 row in flight per wave)
-template <int NQ>
+template <typename T, int NQ>
 static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds, int block)
 {
 #ifdef CHIP_SCAN_TUNING_VARIANTS
     switch (c->scan_variant) {
-        case 1: return launch_scan_t<NQ, 4, 1, 1>(c, s, a, grid, lds, block);
-        case 2: return launch_scan_t<NQ, 16, 1, 1>(c, s, a, grid, lds, block);
-        case 3: return launch_scan_t<NQ, 8, 0, 1>(c, s, a, grid, lds, block);
-        case 4: return launch_scan_t<NQ, 4, 1, 2>(c, s, a, grid, lds, block);
-        case 5: return launch_scan_t<NQ, 8, 1, 2>(c, s, a, grid, lds, block);
-        case 6: return launch_scan_t<NQ, 4, 0, 2>(c, s, a, grid, lds, block);
-        case 7: return launch_scan_t<NQ, 8, 2, 1>(c, s, a, grid, lds, block);
-        case 8: return launch_scan_t<NQ, 8, 3, 1>(c, s, a, grid, lds, block);
-        case 9: return launch_scan_t<NQ, 8, 4, 1>(c, s, a, grid, lds, block);
-        case 10: return launch_scan_t<NQ, 8, 5, 1>(c, s, a, grid, lds, block);
+        case 1: return launch_scan_t<T, NQ, 4, 1, 1>(c, s, a, grid, lds, block);
+        case 2: return launch_scan_t<T, NQ, 16, 1, 1>(c, s, a, grid, lds, block);
+        case 3: return launch_scan_t<T, NQ, 8, 0, 1>(c, s, a, grid, lds, block);
+        case 4: return launch_scan_t<T, NQ, 4, 1, 2>(c, s, a, grid, lds, block);
+        case 5: return launch_scan_t<T, NQ, 8, 1, 2>(c, s, a, grid, lds, block);
+        case 6: return launch_scan_t<T, NQ, 4, 0, 2>(c, s, a, grid, lds, block);
+        case 7: return launch_scan_t<T, NQ, 8, 2, 1>(c, s, a, grid, lds, block);
+        case 8: return launch_scan_t<T, NQ, 8, 3, 1>(c, s, a, grid, lds, block);
+        case 9: return launch_scan_t<T, NQ, 8, 4, 1>(c, s, a, grid, lds, block);
+        case 10: return launch_scan_t<T, NQ, 8, 5, 1>(c, s, a, grid, lds, block);
         default: break;
     }
 #endif
-    return launch_scan_t<NQ, 8, 1, 1>(c, s, a, grid, lds, block);
+    return launch_scan_t<T, NQ, 8, 1, 1>(c, s, a, grid, lds, block);
 }
 
-// Workgroup shape of K1.  The nq query descriptors sit in LDS (nq*D*4 bytes per workgroup), so the shape follows D:
-// 2 workgroups x 512 threads per CU while two copies fit in the 160 KiB (D = 4096: 48 KiB each), else 1 x 1024 threads
-// (D = 8192, the reference's default model: 96 KiB) -- the same 16 waves per CU either way (measured: 6.7 TB/s vs 5.5
-// with 512 x 1).  CHIP_SCAN_BLOCK / CHIP_SCAN_BPC override (tuning only).
+// Workgroup shape of K1.  The nq query descriptors sit in LDS (nq*D*elem bytes per workgroup), so the shape follows D:
+// 2 workgroups x 512 threads per CU while two copies fit in the 160 KiB (D = 4096 fp32: 48 KiB each), else 1 x 1024 threads
+// (D = 8192 fp32, the reference's default model, or D = 4096 fp64: 96 KiB) -- the same 16 waves per CU either way
+// (measured: 6.7 TB/s vs 5.5 with 512 x 1).  CHIP_SCAN_BLOCK / CHIP_SCAN_BPC override (tuning only).
 static size_t scan_lds_bytes(const Ctx *c, int nq, int K, int block)
 {
-    const size_t lds_q = (size_t)nq * c->D * sizeof(float);
+    const size_t lds_q = (size_t)nq * c->D * c->elem;
     const size_t lds_m = (size_t)(block / 64) * nq * K * sizeof(chip_topk_entry);
     return lds_q > lds_m ? lds_q : lds_m;
 }
@@ -264,15 +293,29 @@ int scan_grid_for(const Ctx *c, int64_t n_rows, int nq)
     scan_shape(c, nq, &block, &bpc);
     const int wpb = block / 64;
     int64_t want = (n_rows + wpb - 1) / wpb;
-    // CHIP_SCAN_RESERVE (default 0) leaves workgroup slots free for the small kernels: a full grid holds every CU's registers
-    // (2 x 8 waves x 110 VGPRs), so a merge launched underneath a running scan waits for a scan workgroup to retire.  Reserving
-    // 4 slots cuts the merge's wait from ~1.7 ms to ~30 us at 1M rows for -0.15 % throughput; throughput is the headline, and a
-    // lone synchronous tick has nothing running underneath it, so the default keeps the full grid.
+    // scan_reserve leaves workgroup slots free for the small kernels: a full grid holds every CU's registers (2 x 8 waves x
+    // 110 VGPRs), so a merge (or the RCCL all-gather kernel) launched underneath a running scan waits for a scan workgroup to
+    // retire -- and grid-stride workgroups retire only at the END of the scan.  Reserving 4 slots cuts the merge's wait from
+    // ~1.7 ms to ~30 us at 1M rows for -0.15 % throughput.  Default: 0 on a plain ctx (throughput is the headline and a lone
+    // synchronous tick has nothing running underneath it), 4 on a sharded ctx, whose ctx stream must get local merge ->
+    // all-gather -> global merge through under every scan.  CHIP_SCAN_RESERVE overrides.
     int64_t cap = (int64_t)c->n_cus * bpc - c->scan_reserve;
     if (cap > c->max_grid) cap = c->max_grid;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
     return (int)want;
+}
+
+template <typename T>
+static int launch_scan_T(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid, size_t lds, int block)
+{
+    switch (nq) {
+        case 1: return launch_scan_q<T, 1>(c, s, a, grid, lds, block);
+        case 2: return launch_scan_q<T, 2>(c, s, a, grid, lds, block);
+        case 3: return launch_scan_q<T, 3>(c, s, a, grid, lds, block);
+        case 4: return launch_scan_q<T, 4>(c, s, a, grid, lds, block);
+    }
+    return CHIP_ERR_UNSUPPORTED;
 }
 
 int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid)
@@ -281,13 +324,53 @@ int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid)
     scan_shape(c, nq, &block, &bpc);
     const size_t lds = scan_lds_bytes(c, nq, a.K, block);
     if (lds > 160 * 1024 || grid > 512) return CHIP_ERR_UNSUPPORTED;  // K2 holds one partial list per thread
-    switch (nq) {
-        case 1: return launch_scan_q<1>(c, s, a, grid, lds, block);
-        case 2: return launch_scan_q<2>(c, s, a, grid, lds, block);
-        case 3: return launch_scan_q<3>(c, s, a, grid, lds, block);
-        case 4: return launch_scan_q<4>(c, s, a, grid, lds, block);
+    return c->elem == 8 ? launch_scan_T<double>(c, s, a, nq, grid, lds, block) : launch_scan_T<float>(c, s, a, nq, grid, lds, block);
+}
+
+// ------------------------------------------------------------------------------------------------ K1s
+// The whole score vector u = v^T * M.leftCols(k) of ONE query (src/Cerebro.cpp:1026; the reference's debug plot consumes all
+// of u, :1047-1052): same per-row arithmetic as K1 (rows_dot + butterfly => the same bits), one wave per row, out[local row].
+template <typename T, bool FULL>
+__global__ __launch_bounds__(512) void db_scan_scores(ScanArgs a, double *out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T *qs = reinterpret_cast<T *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wpb = blockDim.x >> 6;
+    stage_queries<T, 1>(a, qs, tid, blockDim.x);
+    __syncthreads();
+    const int64_t tw = (int64_t)gridDim.x * wpb;
+    for (int64_t r = (int64_t)blockIdx.x * wpb + wave; r < a.n_rows; r += tw) {
+        const T *row[1] = {row_base<T>(a, r)};
+        double acc[1][1];
+        rows_dot<T, 1, 4, FULL, 1, 1>(row, qs, a.D, lane, acc);
+        const double s = butterfly_sum(acc[0][0]);
+        if (lane == 0) out[r] = s;
     }
-    return CHIP_ERR_UNSUPPORTED;
+}
+
+int launch_scores(Ctx *c, hipStream_t s, const ScanArgs &a, double *out_dev)
+{
+    const size_t lds = (size_t)c->D * c->elem;
+    int64_t grid = (a.n_rows + 7) / 8;
+    if (grid > (int64_t)c->n_cus * 4) grid = (int64_t)c->n_cus * 4;
+    if (grid < 1) grid = 1;
+    const int chunk = 64 * (16 / c->elem) * 4;
+    const bool full = a.D % chunk == 0;
+    if (c->elem == 8) {
+        if (lds > 65536) {
+            CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_scan_scores<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_scan_scores<double, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (full) hipLaunchKernelGGL((db_scan_scores<double, true>), dim3((int)grid), dim3(512), lds, s, a, out_dev);
+        else hipLaunchKernelGGL((db_scan_scores<double, false>), dim3((int)grid), dim3(512), lds, s, a, out_dev);
+    } else {
+        if (full) hipLaunchKernelGGL((db_scan_scores<float, true>), dim3((int)grid), dim3(512), lds, s, a, out_dev);
+        else hipLaunchKernelGGL((db_scan_scores<float, false>), dim3((int)grid), dim3(512), lds, s, a, out_dev);
+    }
+    CHIP_HIP(c, hipGetLastError());
+    return CHIP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ K2
@@ -316,10 +399,10 @@ int launch_merge(Ctx *c, hipStream_t s, const MergeArgs &a, int nq)
 
 // ------------------------------------------------------------------------------------------------ K3
 struct StoreArgs {
-    float *const *seg_table;
+    void *const *seg_table;
     int32_t seg_shift;
     int64_t seg_mask;
-    float *ring;
+    void *ring;
     int32_t D;
     int32_t rank, nranks;
     int64_t first_global;
@@ -328,17 +411,33 @@ struct StoreArgs {
     uint32_t *flags;
 };
 
-__device__ __forceinline__ void store_row4(const StoreArgs &a, int64_t g, int e, f32x4 v)
+// four consecutive elements of global row g, starting at element e, into the DB (if this rank owns the row) and the ring
+template <typename T>
+__device__ __forceinline__ void store_row4(const StoreArgs &a, int64_t g, int e, const T (&v)[4])
 {
+    typedef typename Vec16<T>::type V;
+    constexpr int N = Vec16<T>::N;
+    V pk[4 / N];
+#pragma unroll
+    for (int c = 0; c < 4; c++) pk[c / N][c % N] = v[c];
     if (a.nranks == 1 || (g % a.nranks) == a.rank) {
         const int64_t loc = a.nranks == 1 ? g : g / a.nranks;
-        float *dst = a.seg_table[loc >> a.seg_shift] + (loc & a.seg_mask) * (int64_t)a.D + e;
-        *reinterpret_cast<f32x4 *>(dst) = v;
+        T *dst = static_cast<T *>(a.seg_table[loc >> a.seg_shift]) + (loc & a.seg_mask) * (int64_t)a.D + e;
+#pragma unroll
+        for (int h = 0; h < 4 / N; h++) reinterpret_cast<V *>(dst)[h] = pk[h];
     }
-    if (a.ring && g >= a.ring_from) *reinterpret_cast<f32x4 *>(a.ring + (g % CHIP_RING_ROWS) * (int64_t)a.D + e) = v;
+    if (a.ring && g >= a.ring_from) {
+        T *dst = static_cast<T *>(a.ring) + (g % CHIP_RING_ROWS) * (int64_t)a.D + e;
+#pragma unroll
+        for (int h = 0; h < 4 / N; h++) reinterpret_cast<V *>(dst)[h] = pk[h];
+    }
 }
 
-__global__ __launch_bounds__(256) void narrow_f64_rows(StoreArgs a, const double *__restrict__ src)
+// M.col(_s) = desc (Cerebro.cpp:1005-1006): wire type S (float64[] of the .srv, or float) -> storage type T.
+//   double -> float : round-to-nearest-even, flag bit0 unless (double)(float)x == x (lossless narrowing is the contract)
+//   float  -> double, same -> same : exact.        NaN / Inf in any combination: flag bit1.
+template <typename S, typename T>
+__global__ __launch_bounds__(256) void convert_rows(StoreArgs a, const S *__restrict__ src)
 {
     const int64_t per_row = a.D / 4;
     const int64_t total = a.n * per_row;
@@ -346,35 +445,23 @@ __global__ __launch_bounds__(256) void narrow_f64_rows(StoreArgs a, const double
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / per_row;
         const int e = (int)(i - r * per_row) * 4;
-        const f64x2 lo = *reinterpret_cast<const f64x2 *>(src + r * a.D + e);
-        const f64x2 hi = *reinterpret_cast<const f64x2 *>(src + r * a.D + e + 2);
-        const double x[4] = {lo.x, lo.y, hi.x, hi.y};
-        f32x4 v;
+        S x[4];
+        if constexpr (sizeof(S) == 8) {
+            const f64x2 lo = *reinterpret_cast<const f64x2 *>(src + r * a.D + e);
+            const f64x2 hi = *reinterpret_cast<const f64x2 *>(src + r * a.D + e + 2);
+            x[0] = lo.x; x[1] = lo.y; x[2] = hi.x; x[3] = hi.y;
+        } else {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(src + r * a.D + e);
+            x[0] = w.x; x[1] = w.y; x[2] = w.z; x[3] = w.w;
+        }
+        T v[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const float f = (float)x[c];  // round-to-nearest-even
-            if (!(fabs(x[c]) <= 1.79769313486231570e308)) bad |= 2u;         // NaN / Inf
-            else if ((double)f != x[c]) bad |= 1u;                             // not fp32-representable (incl. overflow)
-            v[c] = f;
+            v[c] = (T)x[c];
+            if (!(fabs((double)x[c]) <= 1.79769313486231570e308)) bad |= 2u;   // NaN / Inf
+            else if (sizeof(T) < sizeof(S) && (S)v[c] != x[c]) bad |= 1u;        // not fp32-representable (incl. overflow)
         }
-        store_row4(a, a.first_global + r, e, v);
-    }
-    if (bad) atomicOr(a.flags, bad);
-}
-
-__global__ __launch_bounds__(256) void copy_f32_rows(StoreArgs a, const float *__restrict__ src)
-{
-    const int64_t per_row = a.D / 4;
-    const int64_t total = a.n * per_row;
-    uint32_t bad = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / per_row;
-        const int e = (int)(i - r * per_row) * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + r * a.D + e);
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-            if (!(fabsf(v[c]) <= 3.402823466e38f)) bad |= 2u;
-        store_row4(a, a.first_global + r, e, v);
+        store_row4<T>(a, a.first_global + r, e, v);
     }
     if (bad) atomicOr(a.flags, bad);
 }
@@ -405,18 +492,15 @@ static int grid_for_elems(const Ctx *c, int64_t total_threads)
     return (int)g;
 }
 
-int launch_narrow_f64(Ctx *c, hipStream_t s, const double *src, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring)
+// src_elem: 8 = float64 rows (the wire type), 4 = float rows; the destination type is the ctx's storage type
+int launch_store_rows(Ctx *c, hipStream_t s, const void *src, int src_elem, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring)
 {
     StoreArgs a = make_store_args(c, first_global, n, flags_dev, write_ring);
-    hipLaunchKernelGGL(narrow_f64_rows, dim3(grid_for_elems(c, n * (c->D / 4))), dim3(256), 0, s, a, src);
-    CHIP_HIP(c, hipGetLastError());
-    return CHIP_OK;
-}
-
-int launch_copy_f32(Ctx *c, hipStream_t s, const float *src, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring)
-{
-    StoreArgs a = make_store_args(c, first_global, n, flags_dev, write_ring);
-    hipLaunchKernelGGL(copy_f32_rows, dim3(grid_for_elems(c, n * (c->D / 4))), dim3(256), 0, s, a, src);
+    const dim3 grid(grid_for_elems(c, n * (c->D / 4))), block(256);
+    if (src_elem == 8 && c->elem == 4) hipLaunchKernelGGL((convert_rows<double, float>), grid, block, 0, s, a, static_cast<const double *>(src));
+    else if (src_elem == 8) hipLaunchKernelGGL((convert_rows<double, double>), grid, block, 0, s, a, static_cast<const double *>(src));
+    else if (c->elem == 4) hipLaunchKernelGGL((convert_rows<float, float>), grid, block, 0, s, a, static_cast<const float *>(src));
+    else hipLaunchKernelGGL((convert_rows<float, double>), grid, block, 0, s, a, static_cast<const float *>(src));
     CHIP_HIP(c, hipGetLastError());
     return CHIP_OK;
 }
@@ -452,6 +536,7 @@ struct SynthArgs {
     int64_t n_plant;
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void synth_rows(SynthArgs a)
 {
     const int64_t per_row = a.st.D / 4;
@@ -471,14 +556,14 @@ __global__ __launch_bounds__(256) void synth_rows(SynthArgs a)
         if (lo < a.n_plant && a.plant_dst[lo] == g) { kind = a.plant_kind[lo]; src = a.plant_src[lo]; }
         const uint64_t key = synth_rowkey(a.seed, g);
         const uint64_t skey = kind ? synth_rowkey(a.seed, src) : 0;
-        f32x4 v;
+        T v[4];   // the generator is defined in float; a double-storage DB holds the same values widened
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            if (kind == 0) v[c] = (float)synth_from_key(key, e + c) * a.scale;
-            else if (kind == 2) v[c] = (float)synth_from_key(skey, e + c) * a.scale;
-            else v[c] = (float)(5 * synth_from_key(skey, e + c) + synth_from_key(key, e + c)) * a.scale_planted;
+            if (kind == 0) v[c] = (T)((float)synth_from_key(key, e + c) * a.scale);
+            else if (kind == 2) v[c] = (T)((float)synth_from_key(skey, e + c) * a.scale);
+            else v[c] = (T)((float)(5 * synth_from_key(skey, e + c) + synth_from_key(key, e + c)) * a.scale_planted);
         }
-        store_row4(a.st, g, e, v);
+        store_row4<T>(a.st, g, e, v);
     }
 }
 
@@ -495,7 +580,8 @@ int launch_synth(Ctx *c, hipStream_t s, int64_t first_global, int64_t n, uint64_
     a.plant_src = plant_src_dev;
     a.plant_kind = plant_kind_dev;
     a.n_plant = n_plant;
-    hipLaunchKernelGGL(synth_rows, dim3(grid_for_elems(c, n * (c->D / 4))), dim3(256), 0, s, a);
+    if (c->elem == 8) hipLaunchKernelGGL(synth_rows<double>, dim3(grid_for_elems(c, n * (c->D / 4))), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(synth_rows<float>, dim3(grid_for_elems(c, n * (c->D / 4))), dim3(256), 0, s, a);
     CHIP_HIP(c, hipGetLastError());
     return CHIP_OK;
 }

@@ -1247,6 +1247,7 @@ extern "C" int chip_pnp_ransac_batch(chip_ctx *c, int32_t P, const double *const
                                      uint8_t *const *inlier_mask, chip_ransac_summary *summary)
 {
     if (!c || P < 0 || (P > 0 && (!X || !uv || !N)) || !p || !T_colmajor || !confidence) return CHIP_ERR_INVALID_ARG;
+    if (c->group) c = static_cast<chip_ctx *>(chip::group_root(c));   // 1k x 512 is far too small to shard: devices[0] (SURVEY 8e "replicas only")
     const int32_t S = p->sample_size;
     for (int i = 0; i < P; i++) {
         if (!X[i] || !uv[i]) return CHIP_ERR_INVALID_ARG;

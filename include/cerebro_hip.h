@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CHIP_ABI_VERSION 1
+#define CHIP_ABI_VERSION 2
 
 /* ------------------------------------------------------------------------------------------ status codes */
 enum {
@@ -41,7 +41,8 @@ enum {
     CHIP_ERR_RANGE = -7,            /* l / k / row index outside the appended range                       */
     CHIP_ERR_UNSUPPORTED = -8,      /* e.g. D not a multiple of 4, topk > CHIP_MAX_TOPK, nq > CHIP_MAX_NQ  */
     CHIP_ERR_TOO_FEW_POINTS = -9,   /* PnP with < 20 correspondences (DlsPnpWithRansac.cpp:136-139 returns -1) */
-    CHIP_ERR_BUSY = -10             /* async slot still in flight / not enqueued                          */
+    CHIP_ERR_BUSY = -10,            /* async slot still in flight / not enqueued                          */
+    CHIP_ERR_COMM = -11             /* an RCCL call failed; chip_last_comm_error() has the ncclResult_t    */
 };
 
 #define CHIP_MAX_TOPK 16
@@ -54,6 +55,8 @@ const char *chip_strerror(int status);
 int chip_abi_version(void);
 /* last hipError_t seen by this ctx (0 = hipSuccess) and its hipGetErrorString text */
 int chip_last_hip_error(const chip_ctx *ctx, const char **text);
+/* last ncclResult_t seen by this ctx (0 = ncclSuccess) and its ncclGetErrorString text */
+int chip_last_comm_error(const chip_ctx *ctx, const char **text);
 
 /* ------------------------------------------------------------------------------------------ lifecycle
  * Replaces  MatrixXd M = MatrixXd::Zero(descriptor_size, 29000)  (src/Cerebro.cpp:946): device-resident,
@@ -71,6 +74,44 @@ int chip_last_hip_error(const chip_ctx *ctx, const char **text);
 #define CHIP_RING_ROWS 4096
 int  chip_create(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device, int32_t shard_rank, int32_t shard_count);
 void chip_destroy(chip_ctx *ctx);
+
+/* Storage type of the DB rows.  The reference's M is MatrixXd (src/Cerebro.cpp:946); the default NetVLAD server emits
+ * float32 VALUES on the float64 wire (whole_image_desc_compute_server.py:631,648), for which float rows are lossless and
+ * half the HBM traffic; the ReljaNetVLAD model (:148-149, numpy matmul with the WPCA matrix, the only 4096-D model) emits
+ * genuine float64, for which the rows must be double to keep the candidate selection bit-exact.
+ *   chip_create / flags 0 : decided by the data -- float rows, unless the FIRST append (into the still empty DB) carries a
+ *                           value that is not float32-representable: then the DB becomes a double-row DB and that append
+ *                           succeeds unrounded.  Later non-representable values in a float DB fail (CHIP_ERR_NOT_F32).
+ *   CHIP_CREATE_STORE_F32 : float rows, never switches.        CHIP_CREATE_STORE_F64 : double rows from the start.
+ * Double rows: scores are fp64 FMA chains (one rounding per term) in the fixed order of DESIGN.md 3 with 2 elements per lane
+ * per 128-element chunk; needs 3*D*8 B <= 160 KiB (D <= 6824); the MFMA many-query mode is float-only.                  */
+#define CHIP_CREATE_STORE_F32 1u
+#define CHIP_CREATE_STORE_F64 2u
+int  chip_create_ex(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device, int32_t shard_rank, int32_t shard_count,
+                    uint32_t flags);
+
+/* ------------------------------------------------------------------------------------------ multi-GPU inside the library
+ * (a) ONE process, G GPUs -- the shape of the reference: the loop-candidate producer is one thread of one process
+ *     (src/cerebro_node.cpp:499, src/Cerebro.cpp:903).  chip_create_multi returns ONE ctx backed by G per-device
+ *     sub-contexts (rows round-robin, row i on devices[i % G]); every entry point of this header that takes a ctx works on
+ *     it unchanged: appends feed all devices, chip_loop_tick* = G local scans -> per-device local top-k -> exchange ->
+ *     merge + decision on devices[0], PnP / ICP run on devices[0].  One host worker thread per device enqueues that
+ *     device's work, so the host cost of a tick does not grow with G.
+ *     Exchange: an RCCL communicator over the G devices (ncclCommInitAll; ncclAllGather of 3 x topk (score,index) entries per
+ *     rank per tick, enqueued in-stream between the local and the global merge) when the devices are distinct; device
+ *     copies (lists written / copied straight into the root's gather buffer behind events) when CHIP_MULTI_EXCHANGE_COPY is
+ *     passed or the list names a device twice (RCCL refuses two ranks on one device) -- the latter lets a 1-GPU box run the
+ *     G = 2..8 code path.
+ * (b) one process PER GPU (torchrun-style launch): create each rank's ctx with chip_create(.., shard_rank, shard_count),
+ *     then attach an RCCL communicator: rank 0 calls chip_comm_unique_id, distributes the 128 bytes by any means, every
+ *     rank calls chip_comm_init_rank.  From then on chip_loop_tick / _enqueue / _collect and chip_query_* work on the
+ *     sharded ctx (collectively: every rank must make the same calls in the same order) and return the same result on
+ *     every rank.  chip_scan_local / chip_merge_decide remain for callers that bring their own transport.          */
+#define CHIP_MULTI_EXCHANGE_COPY 4u
+int  chip_create_multi(chip_ctx **out, int32_t D, int64_t capacity_hint, const int32_t *devices, int32_t n_devices, uint32_t flags);
+#define CHIP_COMM_ID_BYTES 128
+int  chip_comm_unique_id(void *id_out /* CHIP_COMM_ID_BYTES */);
+int  chip_comm_init_rank(chip_ctx *ctx, const void *id /* CHIP_COMM_ID_BYTES */, int32_t n_ranks, int32_t rank);
 /* Make an externally owned hipStream_t (e.g. the stream torch.distributed synchronises its collectives with) the
  * ctx stream: synchronous queries, merges and the stream-ordering promises of chip_scan_local refer to it.  The value
  * is taken literally: NULL is HIP's null stream.  chip_reset_stream returns to the ctx's private stream. */
@@ -89,7 +130,8 @@ int chip_db_append_f64(chip_ctx *ctx, const double *desc, int64_t n, uint32_t fl
 int chip_db_append_f32(chip_ctx *ctx, const float *desc, int64_t n, int64_t *first_index);
 int64_t chip_db_size(const chip_ctx *ctx);           /* global number of appended rows (== l)             */
 /* Read back rows (global indices; in sharded mode only rows owned by this rank or still in the ring). */
-int chip_db_read_rows_f32(chip_ctx *ctx, const int64_t *rows, int64_t n, float *out);
+int chip_db_read_rows_f32(chip_ctx *ctx, const int64_t *rows, int64_t n, float *out);   /* CHIP_ERR_NOT_F32 on a double-row DB */
+int chip_db_read_rows_f64(chip_ctx *ctx, const int64_t *rows, int64_t n, double *out);
 
 /* Bench/test helper: append n rows of the integer-domain synthetic generator generated ON DEVICE
  * (spec: oracle/dot_scan.c orc_synth_row_f32; SURVEY.md 8d allows on-device generation for the 1M DB).
@@ -108,6 +150,14 @@ int chip_query_rows(chip_ctx *ctx, int64_t k, const int64_t *query_rows, int32_t
                     double *scores, int64_t *idx);
 int chip_query_vectors_f32(chip_ctx *ctx, int64_t k, const float *queries, int32_t nq, int32_t topk,
                            double *scores, int64_t *idx);
+/* double query vectors: as they are on a double-row DB; on a float-row DB they must be float32-representable (else
+ * CHIP_ERR_NOT_F32 -- a rounded query would silently change scores). */
+int chip_query_vectors_f64(chip_ctx *ctx, int64_t k, const double *queries, int32_t nq, int32_t topk,
+                           double *scores, int64_t *idx);
+/* The whole score vector  u = v^T * M.leftCols(k)  of ONE query row (src/Cerebro.cpp:1026; the reference's debug plot consumes
+ * all of u, :1047-1052) -- same arithmetic, same bits as the scores chip_query_rows selects from.  u: k doubles (host).
+ * A sharded ctx without an exchange fills only the entries of the rows it owns. */
+int chip_query_scores(chip_ctx *ctx, int64_t k, int64_t query_row, double *u);
 
 /* Many-query batched mode: Q query descriptors (host, Q x D fp32) against rows [0,k) in ONE pass of
  * the DB as an fp32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32) with a fused exact top-k.  Semantics are those of
@@ -255,7 +305,12 @@ typedef struct {
     int64_t capacity_local;     /* rows reserved on this rank                                      */
     int64_t lossy_rows;         /* rows appended with CHIP_APPEND_ALLOW_ROUNDING that actually rounded */
     char    arch[32];           /* gcnArchName, e.g. "gfx950:sramecc+:xnack-"                      */
+    int32_t storage_bytes;      /* 4 = float rows, 8 = double rows                                 */
+    int32_t n_devices;          /* 1, or G of chip_create_multi (then the other fields describe devices[0]) */
+    int32_t exchange;           /* CHIP_EXCHANGE_*                                                 */
+    int32_t reserved;
 } chip_info;
+enum { CHIP_EXCHANGE_NONE = 0, CHIP_EXCHANGE_RCCL = 1, CHIP_EXCHANGE_COPY = 2 };
 int chip_get_info(const chip_ctx *ctx, chip_info *info);
 
 /* Per-kernel timing on the ctx stream (hipEvents bracketing every scan launch). */

@@ -39,6 +39,12 @@ void     orc_synth_row_f32(uint64_t seed, int64_t row, int32_t D, int32_t kind, 
  * lane L (0..63) accumulates elements j*256+4L+c, j ascending, c=0..3; then
  * acc[L] += acc[L^m] for m=32,16,8,4,2,1.  Products of fp32 values are exact in fp64.   */
 double   orc_dot_tree_f32(const float *q, const float *row, int32_t D);
+/* Double rows: lane L sums elements j*128 + 2L + c by fused multiply-add (one rounding per term), then the same butterfly. */
+double   orc_dot_tree_f64(const double *q, const double *row, int32_t D);
+void     orc_scan_topk_f64(const double *db, int64_t k, int32_t D, const double *queries, int32_t nq, int32_t K,
+                           double *out_scores, int64_t *out_idx, int32_t nthreads);
+/* all scores of one query over rows [0,k); elem = 4 (float rows / float query) or 8 */
+void     orc_scores(const void *db, int32_t elem, int64_t k, int32_t D, const void *query, double *u, int32_t nthreads);
 /* Plain left-to-right fp64 dot (the most literal reading of v^T * M.col(i), Cerebro.cpp:1026). */
 double   orc_dot_seq_f64(const double *q, const double *col, int32_t D);
 
@@ -84,6 +90,8 @@ typedef struct { int64_t last_l; } orc_loop_state;
 
 /* One pass of the while-loop body on a row-major fp32 DB holding >= l rows. */
 void orc_loop_tick_f32(orc_loop_state *st, const orc_dot_params *p, const float *db, int32_t D,
+                       int64_t l, orc_tick_result *out);
+void orc_loop_tick_f64(orc_loop_state *st, const orc_dot_params *p, const double *db, int32_t D,
                        int64_t l, orc_tick_result *out);
 
 /* Reference-faithful CPU path used as bench.py's cpu_baseline (kind "port"):

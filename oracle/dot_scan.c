@@ -75,6 +75,29 @@ double orc_dot_tree_f32(const float *q, const float *row, int32_t D)
     return acc[0];
 }
 
+/* Double-row DBs (genuinely float64 descriptors, e.g. ReljaNetVLAD's numpy WPCA output,
+ * scripts/whole_image_desc_compute_server.py:148-149; the reference's M is MatrixXd, src/Cerebro.cpp:946).  Products of two
+ * doubles are NOT exact, so the definition fixes BOTH the rounding of every term and the order: lane L accumulates elements
+ * j*128 + 2L + c (j ascending, c = 0,1) by FUSED multiply-add -- acc = fma(q[e], row[e], acc), one rounding per term -- then
+ * the same xor butterfly as the float path.  (The device reads 16 bytes per lane per wave load: 2 doubles.) */
+double orc_dot_tree_f64(const double *q, const double *row, int32_t D)
+{
+    double acc[64];
+    for (int L = 0; L < 64; L++) acc[L] = 0.0;
+    for (int32_t base = 0; base < D; base += 128)
+        for (int L = 0; L < 64; L++)
+            for (int c = 0; c < 2; c++) {
+                int32_t e = base + 2 * L + c;
+                if (e < D) acc[L] = fma(q[e], row[e], acc[L]);
+            }
+    for (int m = 32; m >= 1; m >>= 1) {
+        double nxt[64];
+        for (int L = 0; L < 64; L++) nxt[L] = acc[L] + acc[L ^ m];
+        memcpy(acc, nxt, sizeof acc);
+    }
+    return acc[0];
+}
+
 double orc_dot_seq_f64(const double *q, const double *col, int32_t D)
 {
     double s = 0.0;
@@ -175,6 +198,49 @@ void orc_scan_topk_synth(uint64_t seed, int64_t k, int32_t D,
     free(tsc); free(tix);
 }
 
+/* top-K over double rows, threads over disjoint row ranges + exact merge (partition independent under the total order) */
+void orc_scan_topk_f64(const double *db, int64_t k, int32_t D, const double *queries, int32_t nq, int32_t K,
+                       double *out_scores, int64_t *out_idx, int32_t nthreads)
+{
+    if (nthreads <= 0) nthreads = 1;
+    double *tsc = (double *)malloc(sizeof(double) * (size_t)nthreads * nq * K);
+    int64_t *tix = (int64_t *)malloc(sizeof(int64_t) * (size_t)nthreads * nq * K);
+    for (int32_t t = 0; t < nthreads * nq; t++) topk_init(tsc + (size_t)t * K, tix + (size_t)t * K, K);
+#pragma omp parallel num_threads(nthreads)
+    {
+#ifdef _OPENMP
+        int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        int t = 0, nt = 1;
+#endif
+        int64_t lo = k * t / nt, hi = k * (t + 1) / nt;
+        for (int64_t i = lo; i < hi; i++)
+            for (int32_t q = 0; q < nq; q++)
+                topk_push(tsc + ((size_t)t * nq + q) * K, tix + ((size_t)t * nq + q) * K, K,
+                          orc_dot_tree_f64(queries + (size_t)q * D, db + (size_t)i * D, D), i);
+    }
+    for (int32_t q = 0; q < nq; q++) {
+        double *sc = out_scores + (size_t)q * K; int64_t *ix = out_idx + (size_t)q * K;
+        topk_init(sc, ix, K);
+        for (int t = 0; t < nthreads; t++)
+            for (int32_t j = 0; j < K; j++) {
+                int64_t id = tix[((size_t)t * nq + q) * K + j];
+                if (id >= 0) topk_push(sc, ix, K, tsc[((size_t)t * nq + q) * K + j], id);
+            }
+    }
+    free(tsc); free(tix);
+}
+
+/* the whole score vector u = v^T M[:, :k] (Cerebro.cpp:1026) in the device's summation order; elem = 4 (float rows) or 8 */
+void orc_scores(const void *db, int32_t elem, int64_t k, int32_t D, const void *query, double *u, int32_t nthreads)
+{
+    if (nthreads <= 0) nthreads = 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t i = 0; i < k; i++)
+        u[i] = elem == 8 ? orc_dot_tree_f64((const double *)query, (const double *)db + (size_t)i * D, D)
+                         : orc_dot_tree_f32((const float *)query, (const float *)db + (size_t)i * D, D);
+}
+
 /* ---------------------------------------------------------------- the tick */
 void orc_dot_params_default(orc_dot_params *p)
 {
@@ -215,6 +281,37 @@ void orc_loop_tick_f32(orc_loop_state *st, const orc_dot_params *p, const float 
         if (i64abs(out->argmax[0] - out->argmax[1]) < p->locality &&
             i64abs(out->argmax[0] - out->argmax[2]) < p->locality && out->maxv[0] > p->thresh) {
             out->found = 1;                /* :1078-1081 foundLoops.push_back( t[l-1], t[u_argmax], u_max ) */
+            out->idx_curr = l - 1;
+            out->idx_prev = out->argmax[0];
+            out->score = out->maxv[0];
+        }
+    }
+    st->last_l = l; /* :1098 */
+}
+
+/* The same tick over a double-row DB: identical control flow, scores by orc_dot_tree_f64. */
+void orc_loop_tick_f64(orc_loop_state *st, const orc_dot_params *p, const double *db, int32_t D, int64_t l, orc_tick_result *out)
+{
+    memset(out, 0, sizeof *out);
+    out->idx_curr = out->idx_prev = -1;
+    for (int q = 0; q < 3; q++) { out->argmax[q] = -1; out->maxv[q] = -INFINITY; }
+    if (l - st->last_l < p->min_new) { out->status = 0; return; } /* :962-966 */
+    const double *qv[3] = { db + (size_t)(l - 1) * D, db + (size_t)(l - 2) * D, db + (size_t)(l - 3) * D }; /* :987-989 */
+    int64_t k = l - p->lag; /* :1019 */
+    out->status = 1;
+    if (k > p->min_k) {     /* :1022 */
+        out->status = 2;
+        for (int q = 0; q < 3; q++) {
+            double best = -INFINITY; int64_t arg = -1;
+            for (int64_t i = 0; i < k; i++) {
+                double s = orc_dot_tree_f64(qv[q], db + (size_t)i * D, D);
+                if (s >= best) { best = s; arg = i; } /* :1035-1043, later index wins ties */
+            }
+            out->maxv[q] = best; out->argmax[q] = arg;
+        }
+        if (i64abs(out->argmax[0] - out->argmax[1]) < p->locality &&
+            i64abs(out->argmax[0] - out->argmax[2]) < p->locality && out->maxv[0] > p->thresh) { /* :1056 */
+            out->found = 1;
             out->idx_curr = l - 1;
             out->idx_prev = out->argmax[0];
             out->score = out->maxv[0];

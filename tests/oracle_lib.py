@@ -58,6 +58,15 @@ def load():
     lib.orc_synth_row_f32.argtypes = [C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, V]
     lib.orc_dot_tree_f32.restype = C.c_double
     lib.orc_dot_tree_f32.argtypes = [V, V, C.c_int32]
+    lib.orc_dot_tree_f64.restype = C.c_double
+    lib.orc_dot_tree_f64.argtypes = [V, V, C.c_int32]
+    lib.orc_scan_topk_f64.restype = None
+    lib.orc_scan_topk_f64.argtypes = [V, C.c_int64, C.c_int32, V, C.c_int32, C.c_int32, V, V, C.c_int32]
+    lib.orc_scores.restype = None
+    lib.orc_scores.argtypes = [V, C.c_int32, C.c_int64, C.c_int32, V, V, C.c_int32]
+    lib.orc_loop_tick_f64.restype = None
+    lib.orc_loop_tick_f64.argtypes = [C.POINTER(OrcLoopState), C.POINTER(OrcDotParams), V, C.c_int32, C.c_int64,
+                                      C.POINTER(OrcTickResult)]
     lib.orc_dot_seq_f64.restype = C.c_double
     lib.orc_dot_seq_f64.argtypes = [V, V, C.c_int32]
     lib.orc_scan_topk_f32.restype = None
@@ -152,6 +161,46 @@ class LoopOracle:
         r = OrcTickResult()
         load().orc_loop_tick_f32(C.byref(self.state), C.byref(self.params), _p(self.db), self.db.shape[1], l, C.byref(r))
         return r.as_dict()
+
+
+class LoopOracle64:
+    """The same ticks on a host fp64 DB (double-row storage mode): scores by orc_dot_tree_f64 (fma chains)."""
+
+    def __init__(self, db: np.ndarray, params: OrcDotParams | None = None):
+        self.db = np.ascontiguousarray(db, dtype=np.float64)
+        self.state = OrcLoopState(0)
+        self.params = params or default_params()
+
+    def tick(self, l: int) -> dict:
+        r = OrcTickResult()
+        load().orc_loop_tick_f64(C.byref(self.state), C.byref(self.params), _p(self.db), self.db.shape[1], l, C.byref(r))
+        return r.as_dict()
+
+
+def dot_tree_f64(q: np.ndarray, row: np.ndarray) -> float:
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    row = np.ascontiguousarray(row, dtype=np.float64)
+    return float(load().orc_dot_tree_f64(_p(q), _p(row), q.size))
+
+
+def scan_topk_f64(db: np.ndarray, k: int, queries: np.ndarray, K: int, nthreads: int = 1):
+    db = np.ascontiguousarray(db, dtype=np.float64)
+    queries = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, db.shape[1])
+    nq = queries.shape[0]
+    sc = np.empty((nq, K), dtype=np.float64)
+    ix = np.empty((nq, K), dtype=np.int64)
+    load().orc_scan_topk_f64(_p(db), k, db.shape[1], _p(queries), nq, K, _p(sc), _p(ix), nthreads)
+    return sc, ix
+
+
+def scores(db: np.ndarray, k: int, query: np.ndarray, nthreads: int = 1) -> np.ndarray:
+    """u = v^T M[:, :k] in the device's summation order; db dtype float32 or float64 selects the path"""
+    assert db.dtype in (np.float32, np.float64)
+    db = np.ascontiguousarray(db)
+    query = np.ascontiguousarray(query, dtype=db.dtype)
+    u = np.empty(k, dtype=np.float64)
+    load().orc_scores(_p(db), db.dtype.itemsize, k, db.shape[1], _p(query), _p(u), nthreads)
+    return u
 
 
 def ref_scan_f64_colmajor(M: np.ndarray, k: int, v, vm, vmm):

@@ -1,0 +1,163 @@
+"""Double-row storage mode (SURVEY App. B "store that DB as fp64"): the reference's M is MatrixXd (src/Cerebro.cpp:946) and
+the only 4096-D model, ReljaNetVLAD, emits genuine float64 (numpy matmul with the WPCA matrix,
+scripts/whole_image_desc_compute_server.py:148-149).  Bar: indices and scores bit-exact vs the f64 oracle
+(orc_dot_tree_f64: fma chains in the fixed lane order + butterfly)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import scenarios
+from cerebro_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def same_tick(g, o):
+    g = g.as_dict() if hasattr(g, "as_dict") else g
+    for key in ("status", "found", "idx_curr", "idx_prev", "argmax"):
+        assert g[key] == o[key], (key, g, o)
+    assert float(g["score"]).hex() == float(o["score"]).hex()
+    assert [float(x).hex() for x in g["maxv"]] == [float(x).hex() for x in o["maxv"]]
+
+
+def relja_like(seed, N, D, plants=()):
+    """float64 descriptors that are NOT float32-representable: unit-norm rows of a float64 matmul, like
+    np.matmul(u, WPCA_M) + WPCA_b followed by /= norm (server.py:148-149).  Planted rows are noisy copies / duplicates."""
+    rng = np.random.default_rng(seed)
+    W = rng.standard_normal((64, D))
+    db = rng.standard_normal((N, 64)) @ W + 0.01 * rng.standard_normal(D)
+    for dst, src, kind in sorted(plants):
+        db[dst] = db[src] if kind == 2 else db[src] + 0.2 * np.linalg.norm(db[src]) / np.sqrt(D) * rng.standard_normal(D)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    assert not np.array_equal(db.astype(np.float32).astype(np.float64), db)
+    return db
+
+
+@pytest.mark.parametrize("D,N", [(4, 300), (250 * 4, 700), (1024, 900), (4096, 1200), (6824, 400)])
+def test_f64_topk_parity_shapes(D, N):
+    plants, loops, ties = scenarios.loop_plants(N, 3, seed=D)
+    db = relja_like(D, N, D, plants)
+    with capi.Chip(D, storage="f64") as chip:
+        assert chip.info()["storage_bytes"] == 8
+        chip.append_f64(db)
+        rows = [N - 1, N - 2, N - 3, loops[0][1]]
+        for nq in ((1, 2, 3, 4) if D * 8 * 4 <= 160 * 1024 else (1, 2, 3)):
+            for K in (1, 8, 16):
+                for k in (0, 1, 7, N - 50, N):
+                    want = oracle_lib.scan_topk_f64(db, k, db[rows[:nq]], K)
+                    got = chip.query_rows(k, rows[:nq], K)
+                    assert np.array_equal(got[1], want[1]), (nq, K, k)
+                    assert np.array_equal(bits(got[0]), bits(want[0])), (nq, K, k)
+        q = relja_like(5, 3, D)
+        got, want = chip.query_vectors_f64(N, q, 8), oracle_lib.scan_topk_f64(db, N, q, 8)
+        assert np.array_equal(got[1], want[1]) and np.array_equal(bits(got[0]), bits(want[0]))
+        assert chip.read_rows_f64([0, N // 2, N - 1]).tobytes() == db[[0, N // 2, N - 1]].tobytes()
+        u = chip.query_scores(N - 50, N - 1)
+        assert np.array_equal(bits(u), bits(oracle_lib.scores(db, N - 50, db[N - 1])))
+        with pytest.raises(capi.ChipError) as e:
+            chip.read_rows([0])                      # double rows do not fit a float buffer
+        assert e.value.status == capi.CHIP_ERR_NOT_F32
+        with pytest.raises(capi.ChipError) as e:
+            chip.query_batch(N, np.zeros((4, D), np.float32), 4)    # the MFMA many-query mode is float-only
+        assert e.value.status == capi.CHIP_ERR_UNSUPPORTED
+
+
+def test_f64_tick_sequence_and_auto_switch():
+    """chip_create (no flag): the first append of a non-float32 descriptor into the EMPTY DB turns it into a double-row DB
+    -- no rounding, no error; INTEGRATION.md 2 no longer needs CHIP_APPEND_ALLOW_ROUNDING for ReljaNetVLAD."""
+    D, N = 1024, 1500
+    plants, loops, ties = scenarios.loop_plants(N, 6, seed=42)
+    db = relja_like(7, N, D, plants)
+    assert ties
+    orc = oracle_lib.LoopOracle64(db)
+    with capi.Chip(D) as chip:
+        assert chip.info()["storage_bytes"] == 4
+        assert chip.append_f64(db[:1]) == 0
+        assert chip.info()["storage_bytes"] == 8 and chip.info()["lossy_rows"] == 0
+        chip.append_f64(db[1:700])
+        chip.append_f32(db[700:701].astype(np.float32))           # float rows widen exactly into a double DB
+        dbm = db.copy()
+        dbm[700] = db[700].astype(np.float32)
+        chip.append_f64(db[701:])
+        orc = oracle_lib.LoopOracle64(dbm)
+        n_found = 0
+        sched = [1, 3, 5, 30, 55, 57, 58, 61] + list(range(64, N + 1, 3))
+        ls = set(sched)
+        for l, _, _ in loops:
+            ls -= {l - 1, l - 2}
+            ls.add(l)
+        for l in sorted(ls):
+            o = orc.tick(l)
+            same_tick(chip.loop_tick(l), o)
+            n_found += o["found"]
+        assert n_found >= len(loops)
+        s, t1, t2 = ties[0]
+        l, q, p = loops[0]
+        sc, ix = chip.query_rows(l - 50, [q], 3)
+        assert list(ix[0]) == [t2, t1, s] and sc[0][0] == sc[0][1] == sc[0][2]
+    # a float32-valued stream stays a float DB; a later genuinely-double row is then an error (not silently rounded)
+    f32db = scenarios.build_db(3, 64, D, [])
+    with capi.Chip(D) as chip:
+        chip.append_f64(f32db.astype(np.float64))
+        assert chip.info()["storage_bytes"] == 4
+        with pytest.raises(capi.ChipError) as e:
+            chip.append_f64(db[:1])
+        assert e.value.status == capi.CHIP_ERR_NOT_F32 and chip.size() == 64
+    # CHIP_CREATE_STORE_F32 never switches
+    with capi.Chip(D, storage="f32") as chip:
+        with pytest.raises(capi.ChipError) as e:
+            chip.append_f64(db[:1])
+        assert e.value.status == capi.CHIP_ERR_NOT_F32 and chip.size() == 0 and chip.info()["storage_bytes"] == 4
+    # D too large for three double queries in LDS: explicit request refused, automatic switch keeps the float contract
+    with pytest.raises(capi.ChipError) as e:
+        capi.Chip(8192, storage="f64")
+    assert e.value.status == capi.CHIP_ERR_UNSUPPORTED
+
+
+def test_f64_4096d_100k_full_oracle_parity():
+    """BASELINE config 3's DB size with ReljaNetVLAD-like float64 descriptors: append_f64 succeeds unrounded and the tick is
+    bit-exact vs the f64 oracle over the whole prefix."""
+    D, N = 4096, 100_053
+    l = N
+    q, p = l - 1, 41_234
+    plants = [(q - j, p - j, 1) for j in range(3)] + [(p + 5, p, 2)]
+    rng = np.random.default_rng(20190412)
+    W = rng.standard_normal((64, D))
+    db = np.empty((N, D), dtype=np.float64)
+    for a in range(0, N, 8192):
+        b = min(N, a + 8192)
+        db[a:b] = rng.standard_normal((b - a, 64)) @ W
+    for dst, src, kind in sorted(plants):
+        db[dst] = db[src] if kind == 2 else db[src] + 0.2 * np.linalg.norm(db[src]) / np.sqrt(D) * rng.standard_normal(D)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    with capi.Chip(D, capacity_hint=N) as chip:
+        for a in range(0, N, 20_000):
+            chip.append_f64(db[a:a + 20_000])
+        assert chip.info()["storage_bytes"] == 8 and chip.info()["lossy_rows"] == 0 and chip.size() == N
+        r = chip.loop_tick(l)
+        wsc, wix = oracle_lib.scan_topk_f64(db, l - 50, db[[l - 1, l - 2, l - 3]], 8, nthreads=min(os.cpu_count() or 1, 64))
+        assert r.status == capi.CHIP_TICK_SCANNED and r.found == 1 and r.idx_prev == p + 5 and r.idx_curr == q
+        assert list(r.argmax) == list(wix[:, 0]) and [float(x).hex() for x in r.maxv] == [float(x).hex() for x in wsc[:, 0]]
+        got = chip.query_rows(l - 50, [l - 1, l - 2, l - 3], 8)
+        assert np.array_equal(got[1], wix) and np.array_equal(bits(got[0]), bits(wsc))
+
+
+@pytest.mark.parametrize("G", [2, 8])
+def test_f64_group(G):
+    D, N = 1024, 1300
+    plants, loops, _ = scenarios.loop_plants(N, 4, seed=77)
+    db = relja_like(9, N, D, plants)
+    orc = oracle_lib.LoopOracle64(db)
+    with capi.Chip(D, devices=[0] * G) as chip:
+        chip.append_f64(db[:500])              # every device takes the same storage decision
+        chip.append_f64(db[500:])
+        assert chip.info()["storage_bytes"] == 8
+        for l in scenarios.default_schedule(N):
+            same_tick(chip.loop_tick(l), orc.tick(l))
+        assert chip.read_rows_f64([3, 500, N - 1]).tobytes() == db[[3, 500, N - 1]].tobytes()

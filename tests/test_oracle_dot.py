@@ -199,3 +199,91 @@ def test_all_cores_baseline_equals_single_thread_reference_path():
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
     assert list(a[1]) == [965, 966, 967]                             # last tiled copies of rows 5, 6, 7
+
+
+# ------------------------------------------------------------------ double-row mode (orc_dot_tree_f64 / orc_loop_tick_f64)
+def _fma_exact(a: float, b: float, c: float) -> float:
+    """fma by exact rational arithmetic: ONE rounding of a*b + c (Fraction -> float is correctly rounded)"""
+    return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+
+def _dot_tree_f64_py(q, row):
+    D = len(q)
+    acc = [0.0] * 64
+    for base in range(0, D, 128):
+        for L in range(64):
+            for c in range(2):
+                e = base + 2 * L + c
+                if e < D:
+                    acc[L] = _fma_exact(float(q[e]), float(row[e]), acc[L])
+    m = 32
+    while m >= 1:
+        acc = [acc[L] + acc[L ^ m] for L in range(64)]
+        m >>= 1
+    return acc[0]
+
+
+@pytest.mark.parametrize("D", [4, 126, 128, 130, 300, 1024])
+def test_dot_tree_f64_is_the_stated_fma_chain(D):
+    """The f64 definition fixes the rounding of every term (fused multiply-add) AND the order (lane L takes elements
+    j*128 + 2L + c; butterfly 32..1): pinned against exact rational arithmetic, so a libm / compiler fma that double-rounds
+    would be caught."""
+    rng = np.random.default_rng(D)
+    q = rng.standard_normal(D) / 8
+    for i in range(3):
+        row = rng.standard_normal(D) / 8
+        got = oracle_lib.dot_tree_f64(q, row)
+        assert got == _dot_tree_f64_py(q, row)
+        exact = float(sum(Fraction(float(a)) * Fraction(float(b)) for a, b in zip(q, row)))
+        assert abs(got - exact) <= 64 * np.finfo(np.float64).eps * float(np.abs(q * row).sum())
+    # the mul-then-add reading differs in the last bits for genuine doubles -- the reason the definition says fma
+    diff = 0
+    for i in range(20):
+        row = rng.standard_normal(D) / 8
+        a = oracle_lib.dot_tree_f64(q, row)
+        acc = np.zeros(64)
+        for base in range(0, D, 128):
+            for L in range(64):
+                for c in range(2):
+                    e = base + 2 * L + c
+                    if e < D:
+                        acc[L] = acc[L] + q[e] * row[e]
+        m = 32
+        while m >= 1:
+            acc = acc + acc[np.arange(64) ^ m]
+            m >>= 1
+        diff += a != acc[0]
+    assert D < 100 or diff > 0
+
+
+def test_f64_tick_and_topk_oracle_consistency():
+    """orc_loop_tick_f64 / orc_scan_topk_f64 / orc_scores agree with each other, are thread-count independent, and on
+    float32-valued data the f64 path selects what the f32 path selects (products are exact there, only the lane grouping
+    differs, so scores agree to a few ulp)."""
+    D, N = 1024, 600
+    plants, loops, ties = scenarios.loop_plants(N, 4, seed=21)
+    db32 = scenarios.build_db(22, N, D, plants)
+    rng = np.random.default_rng(1)
+    db = db32.astype(np.float64) * (1.0 + 2.0 ** -40 * rng.standard_normal((N, D)))      # genuine doubles
+    db[[d for d, s, k in plants if k == 2]] = db[[s for d, s, k in plants if k == 2]]     # keep exact duplicates exact
+    o64 = oracle_lib.LoopOracle64(db)
+    found = 0
+    for l in scenarios.default_schedule(N):
+        r = o64.tick(l)
+        if r["status"] == 2:
+            k = l - 50
+            sc1, ix1 = oracle_lib.scan_topk_f64(db, k, db[[l - 1, l - 2, l - 3]], 4, nthreads=1)
+            sc3, ix3 = oracle_lib.scan_topk_f64(db, k, db[[l - 1, l - 2, l - 3]], 4, nthreads=3)
+            assert np.array_equal(ix1, ix3) and sc1.tobytes() == sc3.tobytes()
+            assert list(ix1[:, 0]) == r["argmax"] and list(sc1[:, 0]) == r["maxv"]
+            u = oracle_lib.scores(db, k, db[l - 1], nthreads=2)
+            assert u.max() == r["maxv"][0] and int(np.flatnonzero(u == u.max())[-1]) == r["argmax"][0]
+        found += r["found"]
+    assert found >= len(loops)
+    a = oracle_lib.LoopOracle(db32)
+    b = oracle_lib.LoopOracle64(db32.astype(np.float64))
+    for l in scenarios.default_schedule(N):
+        ra, rb = a.tick(l), b.tick(l)
+        assert (ra["status"], ra["found"], ra["argmax"]) == (rb["status"], rb["found"], rb["argmax"])
+        if ra["status"] == 2:
+            assert np.allclose(ra["maxv"], rb["maxv"], rtol=1e-14, atol=1e-16)

@@ -213,6 +213,47 @@ def test_sharded_scan_matches_single():
                 c.close()
 
 
+def test_10k_full_oracle_parity():
+    """BASELINE config 2 at its own size (4096-D x 10k, "dot-product + top-k only"): full CPU oracle scan vs one GPU tick and
+    the top-8 lists, bit-exact.  164 MB: the DB is Infinity-Cache resident at this size."""
+    D, N, seed = 4096, 10_053, 20190412
+    l = N
+    q, p = l - 1, 4_321
+    plants = [(q - j, p - j, 1) for j in range(3)] + [(p + 5, p, 2), (77, p - 1, 2)]   # a later and an earlier exact duplicate
+    with capi.Chip(D, capacity_hint=N) as chip:
+        chip.append_synthetic(N, seed, plants)
+        r = chip.loop_tick(l)
+        qrows = oracle_lib.synth_rows(seed, [l - 1, l - 2, l - 3], D, plants)
+        wsc, wix = oracle_lib.scan_topk_synth(seed, l - 50, D, qrows, 8, plants, nthreads=os.cpu_count() or 1)
+        assert r.status == capi.CHIP_TICK_SCANNED and r.found == 1 and r.idx_curr == q
+        assert list(r.argmax) == list(wix[:, 0]) == [p + 5, p - 1, p - 2] and r.idx_prev == p + 5
+        assert [float(x).hex() for x in r.maxv] == [float(x).hex() for x in wsc[:, 0]]
+        for K in (1, 5, 8, 16):
+            w = oracle_lib.scan_topk_synth(seed, l - 50, D, qrows, K, plants, nthreads=os.cpu_count() or 1)
+            assert_topk_equal(chip.query_rows(l - 50, [l - 1, l - 2, l - 3], K), w)
+        # the three score vectors u, um, umm in full (src/Cerebro.cpp:1026-1028): every column, bit for bit
+        db = oracle_lib.synth_rows(seed, range(l - 50), D, plants)
+        for j in range(3):
+            u = chip.query_scores(l - 50, l - 1 - j)
+            assert np.array_equal(bits(u), bits(oracle_lib.scores(db, l - 50, qrows[j], nthreads=os.cpu_count() or 1)))
+            assert int(np.flatnonzero(u == u.max())[-1]) == r.argmax[j]      # maxCoeff + LAST index attaining it (:1035-1043)
+
+
+def test_score_vector_export_2500():
+    """chip_query_scores: u = v^T M[:, :k] for one query row, checked against orc_dot_tree_f32 for EVERY column at
+    4096-D x 2500 and at a ragged D."""
+    for D, N in ((4096, 2500), (252, 700)):
+        db = scenarios.build_db(77 + D, N, D, [])
+        with capi.Chip(D) as chip:
+            chip.append_f32(db)
+            for k, row in ((N - 50, N - 1), (N, 0), (1, 5), (0, 5)):
+                u = chip.query_scores(k, row)
+                assert u.shape == (k,) and np.array_equal(bits(u), bits(oracle_lib.scores(db, k, db[row])))
+            with pytest.raises(capi.ChipError) as e:
+                chip.query_scores(N + 1, 0)
+            assert e.value.status == capi.CHIP_ERR_RANGE
+
+
 def test_100k_full_oracle_parity():
     """BASELINE config 2/3 scale (4096-D x 100k): full CPU oracle scan (threads) vs one GPU tick, bit-exact."""
     D, N, seed = 4096, 100_053, 20190412
