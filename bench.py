@@ -8,7 +8,11 @@ BASELINE.json's metric is quoted on: synthetic 4096-D fp32 descriptors x 1M keyf
   python bench.py --gpus N --steps K --warmup W
   N > 1 (torchrun, one rank per GPU): the 1M-row DB is row-sharded round-robin over the N GPUs (BASELINE
   config 4, strong scaling); each tick = local scan -> RCCL all-gather of 3 x top-k (score,index) per rank
-  -> merge + decision on every rank.
+  -> merge + decision on every rank.  The collective lives INSIDE libcerebro_hip.so (chip_comm_init_rank +
+  ncclAllGather enqueued in-stream); torch.distributed is only the control plane (unique-id broadcast, barriers,
+  max-over-ranks of the elapsed time).
+  N > 1 WITHOUT torchrun (--gpus N, WORLD_SIZE unset): ONE process drives the N GPUs through chip_create_multi
+  (the reference's process shape: one thread of one process, cerebro_node.cpp:499).
 
 Prints ONE JSON line (rank 0).  `value` = ticks/s with the DB resident in HBM.  `roofline` prices the
 dominant kernel (db_scan_topk) by its ALGORITHMIC bytes (4*D*rows scanned per launch) over its
@@ -40,8 +44,9 @@ SEED = 20190412
 TICK_WINDOW = 1000   # distinct tick positions; longer runs cycle through them (keeps sharded ticks inside the replicated ring)
 
 
-def plan_ticks(rows_scanned: int, n_ticks: int):
-    """l_i = rows_scanned + LAG + 3*i ; every 4th tick is a planted revisit (fires the :1056 rule)."""
+def plan_ticks(rows_scanned: int, n_ticks: int, avoid=()):
+    """l_i = rows_scanned + LAG + 3*i ; every 4th tick is a planted revisit (fires the :1056 rule).
+    avoid: (lo, hi) row windows the revisited rows p, p-1, p-2 must stay out of (rows planted by another plan)."""
     n_ticks = min(n_ticks, TICK_WINDOW)
     ls = [rows_scanned + LAG + 3 * i for i in range(n_ticks)]
     rng = np.random.default_rng(1)
@@ -50,6 +55,8 @@ def plan_ticks(rows_scanned: int, n_ticks: int):
     for i, l in enumerate(ls):
         if i % 4 == 0:
             p = int(rng.integers(1000, rows_scanned - 1000))
+            while any(lo - 3 <= p < hi + 3 for lo, hi in avoid):
+                p = int(rng.integers(1000, rows_scanned - 1000))
             for j in range(3):
                 plants.append((l - 1 - j, p - j, 1))
             expect.append((l - 1, p))
@@ -208,6 +215,74 @@ def batch_leg(chip, rows: int, Q: int = 256):
                          "algorithmic_flops_per_launch": flops, "traffic": None}}
 
 
+def run_ticks(chip, tick_ls, params, inflight, stamps=None):
+    """Pipelined tick loop: up to `inflight` ticks enqueued ahead, results collected in order.  stamps (optional list) gets
+    the host time of every collect -- the per-step cadence of the steady state."""
+    from cerebro_amd import capi
+    out = []
+    W = max(1, min(inflight, capi.CHIP_MAX_INFLIGHT - 1))
+    pending = []
+    prev = -1
+    for i, l in enumerate(tick_ls):
+        if len(pending) == W:
+            out.append(chip.loop_tick_collect(pending.pop(0)))
+            if stamps is not None:
+                stamps.append(time.perf_counter())
+        s = i % W
+        if l <= prev:
+            chip.loop_reset()   # tick positions wrapped
+        prev = l
+        chip.loop_tick_enqueue(l, s, params)
+        pending.append(s)
+    while pending:
+        out.append(chip.loop_tick_collect(pending.pop(0)))
+        if stamps is not None:
+            stamps.append(time.perf_counter())
+    return out
+
+
+def check_results(results, exp):
+    """sanity (not the parity check -- that is tests/ -m gpu): planted revisits must fire with the planted index"""
+    for r, e in zip(results, exp):
+        if e is not None:
+            assert r.found == 1 and r.idx_curr == e[0] and r.idx_prev == e[1], (r.as_dict(), e)
+        else:
+            assert r.found == 0, r.as_dict()
+
+
+def size_leg(chip, rows, plan, params, inflight, n_ticks=240, warm=20):
+    """The same tick loop over a SHORTER prefix of the resident DB (BASELINE configs 2 and 3: 10k and 100k keyframes).
+    `plan` = (ls, expect) of plan_ticks(rows, ...)."""
+    ls, expect = plan
+    ls, expect = ls[:warm + n_ticks], expect[:warm + n_ticks]
+    chip.loop_reset()
+    run_ticks(chip, ls[:warm], params, inflight)
+    chip.synchronize()
+    stamps = []
+    t0 = time.perf_counter()
+    res = run_ticks(chip, ls[warm:], params, inflight, stamps)
+    chip.synchronize()
+    dt = time.perf_counter() - t0
+    check_results(res, expect[warm:])
+    n = len(ls) - warm
+    chip.loop_reset()
+    chip.profile_enable(True)
+    chip.profile_reset()
+    run_ticks(chip, ls[warm:warm + 30], params, inflight)
+    ms, cnt, _, _ = chip.profile_scan()
+    chip.profile_enable(False)
+    avg_s = ms / 1e3 / max(1, cnt)
+    alg = 4.0 * D * rows
+    cache_resident = alg <= 256 * 2**20
+    gaps = np.diff(np.array(stamps))
+    return {"db_rows": rows, "value": n / dt, "unit": "loop-queries/s", "ms_per_step": 1e3 * dt / n,
+            "ms_per_step_median": 1e3 * float(np.median(gaps)) if gaps.size else None, "steps": n,
+            "roofline": {"bound": "hbm" if not cache_resident else "hbm (NOT an HBM figure: the 164 MB prefix is Infinity-Cache resident, 256 MiB)",
+                         "achieved": alg / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "db_scan_topk", "avg_kernel_ms": avg_s * 1e3, "launches": cnt,
+                         "algorithmic_bytes_per_launch": alg, "cache_resident": cache_resident}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,13 +293,20 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20000, help="columns in the CPU baseline sample")
     ap.add_argument("--dim", type=int, default=4096, help="descriptor size (BASELINE: 4096; the reference's default model emits 8192)")
     ap.add_argument("--inflight", type=int, default=16)
+    ap.add_argument("--storage", choices=["f32", "f64"], default="f32",
+                    help="row type of the DB: f32 (BASELINE: synthetic fp32 descriptors) or f64 (double rows, e.g. ReljaNetVLAD)")
     ap.add_argument("--no-pnp", action="store_true", help="skip the auxiliary PnP-RANSAC leg (config 3)")
     ap.add_argument("--no-batch", action="store_true", help="skip the auxiliary many-query MFMA leg (row N4)")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the 10k / 100k legs (BASELINE configs 2, 3)")
     ap.add_argument("--replicated", action="store_true",
                     help="N > 1 only: every GPU holds the whole DB and serves its own stream of ticks (no collective; weak "
-                         "scaling) instead of the default 8-way row shard of BASELINE config 4")
+                         "scaling) instead of the default N-way row shard of BASELINE config 4")
     ap.add_argument("--force-sharded", action="store_true",
-                    help="testing aid: run the sharded code path (scan_local -> RCCL all-gather -> merge) even with 1 rank")
+                    help="testing aid: run the sharded code path (scan -> local merge -> RCCL all-gather -> merge) even with 1 rank")
+    ap.add_argument("--same-device", action="store_true",
+                    help="testing aid for a 1-GPU box: one process, --gpus N sub-contexts all on device 0 (device-copy exchange)")
+    ap.add_argument("--host-exchange", action="store_true",
+                    help="N > 1 under torchrun: exchange through torch.distributed (cerebro_amd/sharded.py) instead of the in-library RCCL")
     args = ap.parse_args()
 
     import torch
@@ -233,22 +315,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    group_mode = world == 1 and args.gpus > 1           # one process drives all GPUs (chip_create_multi)
+    if world > 1 and world != args.gpus:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     dist = None
     replicated = args.replicated and world > 1
-    if world > 1 or args.force_sharded:
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        # BENCH_DIST_BACKEND=gloo is a functional-test aid for a 1-GPU box: the ranks then share device 0 (RCCL refuses two
-        # ranks on one device) and exchange through gloo; the measured figure is then not an N-GPU number.
-        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-        if backend != "nccl":
-            local_rank = local_rank % torch.cuda.device_count()
+        # Control plane only (unique id, barriers, max of the elapsed time).  "gloo" keeps torch from building a second
+        # RCCL communicator next to the library's; BENCH_DIST_BACKEND=nccl selects torch's RCCL backend instead.
+        # With --host-exchange the data path goes through this backend too (then nccl is the default).
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl" if args.host_exchange else "gloo")
+        ndev = torch.cuda.device_count()
+        if ndev < world:
+            local_rank = local_rank % ndev   # functional-test aid: ranks share devices (only valid with the host exchange over gloo)
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -259,16 +341,57 @@ def main():
         local_rank = 0
 
     n_ticks = args.warmup + args.steps
-    ls, plants, expect = plan_ticks(args.rows, n_ticks)
+    # the 10k / 100k legs (N = 1) tick over shorter prefixes of the same DB: their planted query rows are DB rows of the
+    # longer scans, so the longer plans keep their revisited rows out of those windows
+    leg_rows = [r for r in (10_000, 100_000) if r + 4000 < args.rows] if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 \
+        and not args.no_sizes and not args.force_sharded else []
+    windows = [(r, r + LAG + 3 * 260 + 3) for r in leg_rows]
+    ls, plants, expect = plan_ticks(args.rows, n_ticks, avoid=windows)
     total_rows = ls[-1]
     if n_ticks > len(ls):   # cycle: tick i uses position i % TICK_WINDOW (the host-side last_l is reset at every wrap)
         ls = [ls[i % TICK_WINDOW] for i in range(n_ticks)]
         expect = [expect[i % TICK_WINDOW] for i in range(n_ticks)]
+    size_plans = {}
+    for r in leg_rows:
+        l2, p2, e2 = plan_ticks(r, 260, avoid=[w for w in windows if w[0] < r])
+        plants = sorted(plants + p2)
+        size_plans[r] = (l2, e2)
+    assert len({p[0] for p in plants}) == len(plants)
 
     global D
     D = args.dim
-    chip = capi.Chip(D, capacity_hint=total_rows, device=local_rank, shard_rank=0 if replicated else rank,
-                     shard_count=1 if replicated else world)
+    storage = None if args.storage == "f32" else "f64"
+    if group_mode:
+        ndev = torch.cuda.device_count()
+        devices = [0] * args.gpus if args.same_device else list(range(args.gpus))
+        if not args.same_device and ndev < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {ndev} device(s) visible (use --same-device for a functional run)")
+        chip = capi.Chip(D, capacity_hint=total_rows, devices=devices, storage=storage)
+    else:
+        chip = capi.Chip(D, capacity_hint=total_rows, device=local_rank, shard_rank=0 if replicated else rank,
+                         shard_count=1 if replicated else world, storage=storage)
+    det = None
+    exchange = "none"
+    if (world > 1 and not replicated) or args.force_sharded:
+        if args.host_exchange:
+            if dist is None:
+                import torch.distributed as dist
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+                os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            from cerebro_amd.sharded import ShardedLoopDetector
+            det = ShardedLoopDetector(chip, topk=TOPK, device=torch.device("cuda", local_rank))
+            exchange = f"host-driven: torch.distributed all_gather_into_tensor ({dist.get_backend()})"
+        else:
+            # in-library RCCL: rank 0 makes the unique id, the control plane hands it round, every rank attaches
+            uid = [capi.comm_unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(uid, src=0)
+            chip.comm_init_rank(uid[0], world, rank)
+            exchange = "in-library RCCL: ncclAllGather of 3 x top-k (score, index) per rank per tick, enqueued in-stream"
+    elif group_mode:
+        exchange = {capi.CHIP_EXCHANGE_RCCL: "in-library RCCL (ncclCommInitAll, one worker thread per device)",
+                    capi.CHIP_EXCHANGE_COPY: "in-library device copies (devices repeat: RCCL refuses two ranks on one device)"}[chip.info()["exchange"]]
     info = chip.info()
     t_fill = time.perf_counter()
     chip.append_synthetic(total_rows, SEED, plants)
@@ -281,31 +404,12 @@ def main():
             dist.barrier()
         chip.synchronize()
 
-    results = []
-    if (world == 1 and not args.force_sharded) or replicated:
-        def run(tick_ls):
-            out = []
-            W = max(1, min(args.inflight, capi.CHIP_MAX_INFLIGHT - 1))
-            pending = []
-            prev = -1
-            for i, l in enumerate(tick_ls):
-                if len(pending) == W:
-                    out.append(chip.loop_tick_collect(pending.pop(0)))
-                s = i % W
-                if l <= prev:
-                    chip.loop_reset()   # tick positions wrapped
-                prev = l
-                chip.loop_tick_enqueue(l, s, params)
-                pending.append(s)
-            while pending:
-                out.append(chip.loop_tick_collect(pending.pop(0)))
-            return out
+    if det is None:
+        def run(tick_ls, stamps=None):
+            return run_ticks(chip, tick_ls, params, args.inflight, stamps)
     else:
-        from cerebro_amd.sharded import ShardedLoopDetector
-        det = ShardedLoopDetector(chip, topk=TOPK, device=torch.device("cuda", local_rank))
-
-        def run(tick_ls):
-            # pipelined: scan(i+1) on the ctx's other internal stream overlaps all-gather(i) + merge(i) on torch's stream
+        def run(tick_ls, stamps=None):
+            # host-driven exchange: scan(i+1) on the ctx's scan streams overlaps all-gather(i) + merge(i) on torch's stream
             out = []
             W = max(1, min(args.inflight, capi.CHIP_MAX_INFLIGHT - 1))
             pending = []
@@ -313,23 +417,28 @@ def main():
             for i, l in enumerate(tick_ls):
                 if len(pending) == W:
                     out.append(det.collect(pending.pop(0)))
+                    if stamps is not None:
+                        stamps.append(time.perf_counter())
                 s = i % W
                 if l <= prev:
                     chip.loop_reset()   # tick positions wrapped
                 prev = l
-                st = det.tick_enqueue(l, s, params)   # scan_local -> RCCL all-gather (384 B/rank over xGMI) -> merge
+                st = det.tick_enqueue(l, s, params)
                 assert st == capi.CHIP_TICK_SCANNED
                 pending.append(s)
             while pending:
                 out.append(det.collect(pending.pop(0)))
+                if stamps is not None:
+                    stamps.append(time.perf_counter())
             return out
 
     chip.loop_reset()
     barrier()
     run(ls[:args.warmup])
     barrier()
+    stamps = []
     t0 = time.perf_counter()
-    results = run(ls[args.warmup:])
+    results = run(ls[args.warmup:], stamps)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -345,78 +454,91 @@ def main():
     scan_ms, n_launch, bytes_last, span_ms = chip.profile_scan()
     chip.profile_enable(False)
 
-    # sanity (not the parity check -- that is tests/ -m gpu): planted revisits must fire with the planted index
-    exp = expect[args.warmup:]
-    for r, e in zip(results, exp):
-        if e is not None:
-            assert r.found == 1 and r.idx_curr == e[0] and r.idx_prev == e[1], (r.as_dict(), e)
-        else:
-            assert r.found == 0, r.as_dict()
+    check_results(results, expect[args.warmup:])
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
-        local_rows = args.rows if replicated else (args.rows + world - 1) // world
-        alg_bytes = 4.0 * D * local_rows                       # one pass of the fp32 DB prefix (this rank's share)
+        n_gpus = args.gpus if group_mode else world
+        shards = 1 if replicated else n_gpus
+        local_rows = (args.rows + shards - 1) // shards
+        alg_bytes = 4.0 * D * local_rows                       # one pass of the prefix as fp32 (this GPU's share), whatever the storage type
         avg_s = scan_ms / 1e3 / max(1, n_launch)              # per-launch duration (what rocprofv3 --stats reports)
         achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-        traffic = None
+        traffic = traffic_source = None
         pj = ROOT / "profiles" / "scan_traffic.json"
-        # the committed PMC measurement is of the headline launch (4096-D x 1M rows on one GPU); other shapes report null
-        if pj.exists() and D == 4096 and args.rows == 1_000_000 and world == 1:
+        # the committed PMC measurement is of the headline launch (4096-D x 1M fp32 rows on one GPU); other shapes report null
+        if pj.exists() and D == 4096 and args.rows == 1_000_000 and n_gpus == 1 and args.storage == "f32":
             try:
                 traffic = json.loads(pj.read_text()).get("hbm_bytes_per_launch")
+                traffic_source = "profiles/scan_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this launch shape, separate run; not re-measured in this run)"
             except Exception:
                 traffic = None
+        gaps = np.diff(np.array(stamps))
         out = {
             "metric": f"loop-queries/sec (ticks of 3 descriptors vs {D}-D x {fmt_rows(args.rows)} DB)",   # same string at every N; PnP-RANSAC hypotheses/sec: see "pnp" (N = 1)
             "value": (world if replicated else 1) * args.steps / elapsed,   # replicas each run `steps` ticks of their own
             "unit": "loop-queries/s",
-            "n_gpus": world,
+            "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_median": 1e3 * float(np.median(gaps)) if gaps.size else None,   # cadence of result collection in steady state (rank 0)
             "higher_is_better": True,
             "scaling": "weak" if replicated else "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (on-device integer-domain generator, seed 20190412, planted revisits)",
+            "data": "synthetic (on-device integer-domain generator, seed 20190412, planted revisits; rows are unit-norm in expectation, "
+                    "norm spread ~1.1 % rms at D=4096: Irwin-Hall integers x one constant, so that CPU and GPU generate identical bits)",
             "config": {"workload": f"{D}-D fp32 descriptors x {args.rows} keyframe DB, 3 queries/tick, top-{TOPK} + accept rule",
-                       "db_rows": args.rows, "D": D, "queries_per_tick": 3, "topk": TOPK, "storage": "fp32 rows (verified-lossless narrowing of the f64 wire type), fp64 accumulate",
+                       "db_rows": args.rows, "D": D, "queries_per_tick": 3, "topk": TOPK,
+                       "storage": "fp32 rows (verified-lossless narrowing of the f64 wire type), fp64 accumulate" if args.storage == "f32"
+                                  else "fp64 rows (double-row mode: 2x the HBM bytes of the fp32 layout; roofline still priced on 4*D*k algorithmic bytes)",
                        "loop_query": "one tick of Cerebro::descrip_N__dot__descrip_0_N = 3 descriptor queries + top-k + accept rule",
-                       "dist_backend": os.environ.get("BENCH_DIST_BACKEND", "nccl") if world > 1 else None,
-                       "sharding": "single GPU" if world == 1 else (f"{world} replicas of the whole DB, independent tick streams, no collective" if replicated
-                                                                   else f"row round-robin over {world} GPUs + RCCL all-gather of top-k"),
+                       "process_layout": "one process" if world == 1 else f"{world} processes (one per GPU)",
+                       "exchange": exchange,
+                       "control_plane": (dist.get_backend() if dist is not None else None),
+                       "sharding": "single GPU" if n_gpus == 1 else (f"{world} replicas of the whole DB, independent tick streams, no collective" if replicated
+                                                                     else f"row round-robin over {n_gpus} GPUs + all-gather of top-k"),
                        "descriptor_queries_per_s": 3 * args.steps / elapsed,
                        "db_fill_s": t_fill, "arch": info["arch"], "n_cus": info["n_cus"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "db_scan_topk", "avg_kernel_ms": avg_s * 1e3, "launches": n_launch,
                          "measured": "hipEvents around each launch on the kernel's stream, separate pass of the same ticks",
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if world == 1 and not args.no_pnp:
+        if size_plans:
+            out["sizes"] = {fmt_rows(r): size_leg(chip, r, plan, params, args.inflight) for r, plan in sorted(size_plans.items())}
+            out["sizes"][fmt_rows(args.rows)] = {"db_rows": args.rows, "value": out["value"], "unit": "loop-queries/s", "ms_per_step": out["ms_per_step"],
+                                                 "ms_per_step_median": out["ms_per_step_median"], "steps": args.steps,
+                                                 "roofline": out["roofline"]}
+        if n_gpus == 1 and world == 1 and not args.no_pnp:
             out["pnp"] = pnp_leg(chip, min(args.cpu_budget, 5.0))
-        if world == 1 and not args.no_batch:
+        if n_gpus == 1 and world == 1 and not args.no_batch and args.storage == "f32":
             out["batch"] = batch_leg(chip, args.rows)
-        if world == 1 and args.cpu_budget > 0:
+        if n_gpus == 1 and world == 1 and args.cpu_budget > 0:
             cols_per_s, n, dt = cpu_baseline(args.cpu_sample, args.cpu_budget)
             out["cpu_baseline"] = {"value": cols_per_s / args.rows, "unit": "loop-queries/s", "cores": 1, "kind": "port",
                                    "sample": f"{n} ticks of 3 fp64 GEMVs over a {args.cpu_sample}-column x 4096 column-major M "
-                                             f"({dt:.1f} s), scaled to {args.rows} columns; host has {os.cpu_count()} cores, "
+                                             f"({dt:.1f} s), scaled to {args.rows} columns; sequential-order port (one s += q[e]*col[e] "
+                                             "chain per column, -O2 -ffp-contract=off: does not vectorise) -- Eigen is absent from this image, "
+                                             f"its GEMV would use packet accumulators; host has {os.cpu_count()} cores, "
                                              "reference path is single-threaded (Eigen without OpenMP)"}
             ac_cols = max(args.cpu_sample, 200_000)      # 6.5 GB of fp64: large enough to defeat the host caches
             cols_per_s, n, dt, nt = cpu_baseline_all_cores(ac_cols, min(args.cpu_budget, 6.0))
             out["cpu_baseline_all_cores"] = {"value": cols_per_s / args.rows, "unit": "loop-queries/s", "cores": nt, "kind": "port",
                                              "sample": f"{n} ticks over a {ac_cols}-column x 4096 fp64 M ({dt:.1f} s), OpenMP static "
-                                                       f"over columns, scaled to {args.rows} columns; {os.cpu_count()} logical CPUs visible, "
+                                                       f"over columns, same sequential-order port, scaled to {args.rows} columns; {os.cpu_count()} logical CPUs visible, "
                                                        f"{nt} usable under the affinity mask / cgroup quota"}
         print(json.dumps(out), flush=True)
 
-    if 'det' in locals():
+    if det is not None:
         det.close()
     chip.close()
     if dist is not None:

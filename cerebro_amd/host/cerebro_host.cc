@@ -19,6 +19,14 @@ Cerebro::Cerebro(int descriptor_size, int device, int64_t capacity_hint) : D_(de
     if (status_ != CHIP_OK) ctx_ = nullptr;
 }
 
+Cerebro::Cerebro(int descriptor_size, const std::vector<int> &devices, int64_t capacity_hint, uint32_t create_flags) : D_(descriptor_size)
+{
+    chip_dot_params_default(&params);
+    std::vector<int32_t> dev(devices.begin(), devices.end());
+    status_ = chip_create_multi(&ctx_, descriptor_size, capacity_hint, dev.data(), (int32_t)dev.size(), create_flags);
+    if (status_ != CHIP_OK) ctx_ = nullptr;
+}
+
 Cerebro::~Cerebro()
 {
     run_thread_disable();

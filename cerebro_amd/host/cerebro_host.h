@@ -42,6 +42,11 @@ class Cerebro {
 public:
     // descriptor_size: learnt by the reference from a zero-image service call (Cerebro.cpp:75-120)
     explicit Cerebro(int descriptor_size, int device = 0, int64_t capacity_hint = 29000 /* Cerebro.cpp:946 */);
+    // The same object over several GPUs of this node (chip_create_multi): the DB is row-sharded over `devices`, every method
+    // below is unchanged for the caller -- the dot-product thread stays ONE thread of ONE process as in the reference
+    // (src/cerebro_node.cpp:499); the per-shard top-k lists are exchanged inside the library (RCCL all-gather).  A device
+    // named twice selects the device-copy exchange (lets a 1-GPU machine run the sharded code path).
+    Cerebro(int descriptor_size, const std::vector<int> &devices, int64_t capacity_hint = 29000, uint32_t create_flags = 0);
     ~Cerebro();
     Cerebro(const Cerebro &) = delete;
     Cerebro &operator=(const Cerebro &) = delete;

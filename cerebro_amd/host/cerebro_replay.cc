@@ -1,13 +1,14 @@
 // cerebro_replay -- offline replay harness of the loop-candidate producer (BASELINE configs 1 and 5: "harness ready,
 // data absent": feed it the descriptors of an EuRoC run and a tick schedule and it reproduces foundLoops).
 //
-//   cerebro_replay <stream.bin> <out.json> [device]
+//   cerebro_replay [--devices a,b,..] <stream.bin> <out.json> [device]
 // stream.bin (little endian): "CRBR" u32 version=1, u32 D, u64 N, u64 n_ticks, then N x {u32 sec, u32 nsec},
 // N x D float64 descriptors (the .srv wire type), n_ticks x i64 l (value of wholeImageComputedList_size() at each
 // iteration of the dot-product thread; rows < l are appended before the tick).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "cerebro_host.h"
@@ -32,11 +33,21 @@ static int parse_only(const char *in, const char *outp)
     return 0;
 }
 
+// --devices a,b,c (first option): run the loop detector over several GPUs of this node from this one process
+// (chip_create_multi; a device named twice = the device-copy exchange, e.g. --devices 0,0,0,0 on a 1-GPU machine).
+static std::vector<int> g_devices;
+
+static cerebro_hip::Cerebro *make_cerebro(int D, int device, int64_t hint)
+{
+    return g_devices.empty() ? new cerebro_hip::Cerebro(D, device, hint) : new cerebro_hip::Cerebro(D, g_devices, hint);
+}
+
 static int from_state(const char *in, const char *outp, int device)
 {
     cerebro_hip::StateDescriptors sd;
     if (!cerebro_hip::load_state_json(in, sd)) { std::fprintf(stderr, "parse error: %s\n", sd.error.c_str()); return 6; }
-    cerebro_hip::Cerebro cer(sd.D, device, (int64_t)sd.stampNSec.size());
+    std::unique_ptr<cerebro_hip::Cerebro> cer_p(make_cerebro(sd.D, device, (int64_t)sd.stampNSec.size()));
+    cerebro_hip::Cerebro &cer = *cer_p;
     if (!cer.ok()) { std::fprintf(stderr, "chip_create failed: %s\n", chip_strerror(cer.last_status())); return 3; }
     const int64_t n = cer.loadStateFromDisk(in);
     if (n < 0) { std::fprintf(stderr, "loadStateFromDisk: %s\n", cer.last_error().c_str()); return 4; }
@@ -140,6 +151,15 @@ static int replay_rand() { g_rand_next = g_rand_next * 1103515245ul + 12345ul; r
 
 int main(int argc, char **argv)
 {
+    if (argc >= 3 && std::strcmp(argv[1], "--devices") == 0) {
+        for (const char *p = argv[2]; *p;) {
+            g_devices.push_back(std::atoi(p));
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+        argv += 2;
+        argc -= 2;
+    }
     int policy = 0;
     if (argc >= 5 && std::strcmp(argv[1], "--policy") == 0) {
         policy = std::strcmp(argv[2], "naive") == 0 ? 1 : std::strcmp(argv[2], "clique") == 0 ? 2 : -1;
@@ -171,7 +191,8 @@ int main(int argc, char **argv)
         return 2;
     }
     std::fclose(f);
-    cerebro_hip::Cerebro cer((int)D, argc > 3 ? std::atoi(argv[3]) : 0, (int64_t)N);
+    std::unique_ptr<cerebro_hip::Cerebro> cer_p(make_cerebro((int)D, argc > 3 ? std::atoi(argv[3]) : 0, (int64_t)N));
+    cerebro_hip::Cerebro &cer = *cer_p;
     if (!cer.ok()) { std::fprintf(stderr, "chip_create failed: %s\n", chip_strerror(cer.last_status())); return 3; }
     cer.rand_source = replay_rand;
     int64_t appended = 0;

@@ -50,14 +50,18 @@ def test_replay_without_gpu_fails_loudly(tmp_path):
 
 
 @pytest.mark.gpu
-def test_replay_matches_oracle(tmp_path):
+@pytest.mark.parametrize("devices", [None, "0", "0,0,0"])
+def test_replay_matches_oracle(tmp_path, devices):
+    """devices: the C++ host class over chip_create_multi -- "0" = a one-device group over an RCCL communicator, "0,0,0" = the
+    three-way sharded code path on one device (device-copy exchange); the reference's call sites read the same either way."""
     D, N = 512, 1300
     plants, loops, ties = scenarios.loop_plants(N, 6, seed=21)
     db = scenarios.build_db(77, N, D, plants)
     stamps = [(1403636579 + i // 20, (i % 20) * 50_000_000) for i in range(N)]     # 20 Hz keyframes
     ticks = scenarios.default_schedule(N)
     write_stream(tmp_path / "s.bin", db, stamps, ticks)
-    r = subprocess.run([str(LIB / "cerebro_replay"), str(tmp_path / "s.bin"), str(tmp_path / "o.json")], capture_output=True, text=True)
+    r = subprocess.run([str(LIB / "cerebro_replay")] + (["--devices", devices] if devices else []) + [str(tmp_path / "s.bin"), str(tmp_path / "o.json")],
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     got = json.loads((tmp_path / "o.json").read_text())
     orc = oracle_lib.LoopOracle(db)
@@ -210,16 +214,17 @@ def test_cold_start_from_state_json_matches_oracle(tmp_path):
 
 # ------------------------------------------------------------------ N4: top-k candidate policies over the C ABI
 @pytest.mark.gpu
-@pytest.mark.parametrize("policy,step", [("naive", 3), ("clique", 1), ("clique", 3), ("clique", 5)])
-def test_policy_replay_matches_oracle(tmp_path, policy, step):
+@pytest.mark.parametrize("policy,step,devices", [("naive", 3, None), ("clique", 1, None), ("clique", 3, None), ("clique", 5, None),
+                                                 ("naive", 3, "0,0"), ("clique", 3, "0,0,0,0")])
+def test_policy_replay_matches_oracle(tmp_path, policy, step, devices):
     import test_oracle_policies as pol
     db, plants = pol.policy_db(seed=9)
     N = db.shape[0]
     stamps = [(1403636579 + i // 20, (i % 20) * 50_000_000) for i in range(N)]
     ticks = list(range(step, N + 1, step))
     write_stream(tmp_path / "s.bin", db, stamps, ticks)
-    r = subprocess.run([str(LIB / "cerebro_replay"), "--policy", policy, str(tmp_path / "s.bin"), str(tmp_path / "o.json")],
-                       capture_output=True, text=True)
+    r = subprocess.run([str(LIB / "cerebro_replay")] + (["--devices", devices] if devices else []) +
+                       ["--policy", policy, str(tmp_path / "s.bin"), str(tmp_path / "o.json")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     got = json.loads((tmp_path / "o.json").read_text())
     orc = oracle_lib.NaivePolicyOracle(db) if policy == "naive" else oracle_lib.CliquePolicyOracle(db, oracle_lib.AnsiRand())
