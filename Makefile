@@ -19,7 +19,7 @@ ORC_SRCS   := $(wildcard oracle/*.c)
 
 all: lib oracle host
 lib: $(LIBDIR)/libcerebro_hip.so
-oracle: oracle/_build/liboracle.so
+oracle: oracle/_build/liboracle.so oracle/_build/liboracle_eispack.so
 host: $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay $(LIBDIR)/minimal_loop_detector
 
 $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/chip_internal.h $(CSRC)/ransac_common.h $(CSRC)/topk_merge.h include/cerebro_hip.h
@@ -41,6 +41,12 @@ $(LIBDIR)/cerebro_replay: $(HOSTDIR)/cerebro_replay.cc $(LIBDIR)/libcerebro_host
 oracle/_build/liboracle.so: $(ORC_SRCS) oracle/cerebro_oracle.h
 	@mkdir -p oracle/_build
 	$(CC) $(ORCFLAGS) -shared $(ORC_SRCS) -o $@ -lm
+
+# The same oracle with EISPACK's original overflow-guard DIVISION in the Francis QR step (what Eigen::EigenSolver runs) instead
+# of the exact power-of-two scaling: test infrastructure for tests/test_oracle_pnp_departures.py only.
+oracle/_build/liboracle_eispack.so: $(ORC_SRCS) oracle/cerebro_oracle.h
+	@mkdir -p oracle/_build
+	$(CC) $(ORCFLAGS) -DORC_EISPACK_DIVIDE -shared $(ORC_SRCS) -o $@ -lm
 
 # ---- plain-C-ABI example (the INTEGRATION.md call sequence without ROS / Eigen) ----
 $(LIBDIR)/minimal_loop_detector: examples/minimal_loop_detector.cc include/cerebro_hip.h $(LIBDIR)/libcerebro_hip.so

@@ -472,7 +472,11 @@ static int francis_qr(double H[EN][EN], double V[EN][EN], double wr[EN], double 
                  * 2^e with |p|+|q|+|r| = f * 2^e, f in [0.5,1): the scaling is then exact (no rounding) and costs three
                  * exponent adjustments instead of three divisions on the critical path of every step. */
                 s = fabs(p) + fabs(q) + fabs(r);
+#ifdef ORC_EISPACK_DIVIDE   /* EISPACK hqr2 / Eigen::EigenSolver as written: kept buildable to show the two select alike */
+                p = p / s; q = q / s; r = r / s;
+#else
                 { int e2; (void)frexp(s, &e2); p = ldexp(p, -e2); q = ldexp(q, -e2); r = ldexp(r, -e2); }
+#endif
                 if (m == l) break;
                 if (fabs(H[m][m - 1]) * (fabs(q) + fabs(r)) <
                     eps * (fabs(p) * (fabs(H[m - 1][m - 1]) + fabs(z) + fabs(H[m + 1][m + 1])))) break;
@@ -482,18 +486,27 @@ static int francis_qr(double H[EN][EN], double V[EN][EN], double wr[EN], double 
             for (int k = m; k <= n - 1; k++) { /* double QR step on rows l..n, columns m..n */
                 int notlast = (k != n - 1);
                 int ex = 0;
+                (void)ex;
                 dbg_ksteps++;
                 if (k != m) {
                     p = H[k][k - 1]; q = H[k + 1][k - 1]; r = notlast ? H[k + 2][k - 1] : 0.0;
                     x = fabs(p) + fabs(q) + fabs(r);
                     if (x == 0.0) continue;
+#ifdef ORC_EISPACK_DIVIDE
+                    p = p / x; q = q / x; r = r / x;
+#else
                     (void)frexp(x, &ex);                 /* exact power-of-two scaling, see above */
                     p = ldexp(p, -ex); q = ldexp(q, -ex); r = ldexp(r, -ex);
+#endif
                 }
                 s = sqrt(p * p + q * q + r * r);
                 if (p < 0) s = -s;
                 if (s != 0.0) {
+#ifdef ORC_EISPACK_DIVIDE
+                    if (k != m) H[k][k - 1] = -s * x;
+#else
                     if (k != m) H[k][k - 1] = ldexp(-s, ex);
+#endif
                     else if (l != m) H[k][k - 1] = -H[k][k - 1];
                     p = p + s;
                     x = p / s; y = q / s; z = r / s;

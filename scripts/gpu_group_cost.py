@@ -40,11 +40,11 @@ out = {"host_cost_short_prefix": {}, "rows_125k": {}}
 for G in (1, 2, 4, 8):
     with capi.Chip(D, capacity_hint=8000, devices=[0] * G, copy_exchange=True) as chip:
         chip.append_synthetic(8000, 1)
-        ls = [2000 + 3 * i for i in range(1500)]
+        ls = [4000 + 3 * i for i in range(1300)]   # query rows stay inside the replicated ring (newest 4096 rows)
         loop(chip, ls[:200])
         chip.loop_reset()
         tps, enq_us = loop(chip, ls)
-        out["host_cost_short_prefix"][f"G={G}"] = {"ticks_per_s": tps, "enqueue_us_per_tick": enq_us, "prefix_rows": 1950}
+        out["host_cost_short_prefix"][f"G={G}"] = {"ticks_per_s": tps, "enqueue_us_per_tick": enq_us, "prefix_rows": 3950}
 
 rows = 125_000
 ls = [rows + 50 + 3 * i for i in range(600)]

@@ -19,7 +19,19 @@ CASES = [dict(seed=20190412, N=500, D=256, n_loops=4, plant_seed=1),
          dict(seed=77, N=900, D=1000, n_loops=5, plant_seed=3)]   # D not a multiple of 256
 
 
+OUT = HERE / (sys.argv[1] if len(sys.argv) > 1 else "dot_scan_golden.json")
+
+
+def refuse_to_overwrite(path):
+    """tests/golden/FROZEN.json pins the v1 fixtures by checksum: they are golden vectors, not regression snapshots.  A kernel /
+    oracle change that alters bits is judged AGAINST the frozen file (north-star tolerance); it never regenerates it."""
+    if path.exists():
+        raise SystemExit(f"{path.name} is frozen (tests/golden/FROZEN.json, tests/test_golden_frozen.py): refusing to overwrite. "
+                         "Write additional cases to a NEW file (pass its name as argv[1]).")
+
+
 def main():
+    refuse_to_overwrite(OUT)
     out = {"generator": "oracle/dot_scan.c orc_synth_row_f32", "cases": []}
     for c in CASES:
         plants, loops, ties = scenarios.loop_plants(c["N"], c["n_loops"], c["plant_seed"])
@@ -40,7 +52,7 @@ def main():
                                  loops=[list(x) for x in loops], ties=[list(t) for t in ties], found_loops=found,
                                  topk_rows=rows, topk_k=k, K=K, topk_idx=ix.tolist(),
                                  topk_scores_hex=[[float(x).hex() for x in row] for row in sc]))
-    (HERE / "dot_scan_golden.json").write_text(json.dumps(out, indent=1))
+    OUT.write_text(json.dumps(out, indent=1))
     print("wrote", HERE / "dot_scan_golden.json", [len(c["found_loops"]) for c in out["cases"]])
 
 

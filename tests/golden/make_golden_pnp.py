@@ -9,11 +9,24 @@ import numpy as np
 
 HERE = Path(__file__).resolve().parent
 sys.path.insert(0, str(HERE.parent))
+sys.path.insert(0, str(HERE.parent.parent))
 import np_mirror_pnp as M  # noqa: E402
 import oracle_lib as O  # noqa: E402
 
 
+OUT = HERE / (sys.argv[1] if len(sys.argv) > 1 else "pnp_golden.json")
+
+
+def refuse_to_overwrite(path):
+    """tests/golden/FROZEN.json pins the v1 fixtures by checksum: they are golden vectors, not regression snapshots.  A kernel /
+    oracle change that alters bits is judged AGAINST the frozen file (north-star tolerance); it never regenerates it."""
+    if path.exists():
+        raise SystemExit(f"{path.name} is frozen (tests/golden/FROZEN.json, tests/test_golden_frozen.py): refusing to overwrite. "
+                         "Write additional cases to a NEW file (pass its name as argv[1]).")
+
+
 def main():
+    refuse_to_overwrite(OUT)
     X, uv, T, inl = M.make_scene(N=512, outlier_frac=0.3, noise_px=0.5, seed=4242)
     out = dict(scene="np_mirror_pnp.make_scene(N=512, outlier_frac=0.3, noise_px=0.5, seed=4242)",
                X=X.tolist(), uv=uv.tolist(), T_true=T.tolist(), cases=[])
@@ -26,8 +39,8 @@ def main():
                                  mask_hex=np.packbits(r["mask"]).tobytes().hex(),
                                  T_colmajor_hex=[float(x).hex() for x in r["T"].T.reshape(16)]))
         print(nh, seed, s)
-    (HERE / "pnp_golden.json").write_text(json.dumps(out))
-    print("wrote pnp_golden.json", (HERE / "pnp_golden.json").stat().st_size, "bytes")
+    OUT.write_text(json.dumps(out))
+    print("wrote pnp_golden.json", OUT.stat().st_size, "bytes")
 
 
 if __name__ == "__main__":
