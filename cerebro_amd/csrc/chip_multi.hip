@@ -463,6 +463,7 @@ int chip_create_multi(chip_ctx **out, int32_t D, int64_t capacity_hint, const in
         rc = ctx_create(&s, D, capacity_hint, devices[g], g, n_devices, flags & kCreateStoreMask);
         if (rc != CHIP_OK) break;
         s->parent = gc;
+        s->scan_reserve = env_int("CHIP_SCAN_RESERVE", 4);   // the exchange + merges run underneath the scans on every device, also at G = 1
         G->subs.push_back(s);
         G->same_dev.push_back(devices[g] == devices[0] ? 1 : 0);
         // RCCL: every rank receives the gathered lists; copies: only the root's buffer is used

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "cerebro_host.h"
@@ -62,6 +63,101 @@ static int from_state(const char *in, const char *outp, int device)
     std::fclose(o);
     std::fprintf(stderr, "cerebro_replay: %lld descriptors from state.json, %d loop candidates\n", (long long)n, cer.foundLoops_count());
     return 0;
+}
+
+// --compare <reference.json> <candidate.json> : no GPU.  Diffs two loop-candidate dumps in the format the reference's node
+// writes at shutdown (loopcandidates_liverun.json = Cerebro::foundLoops_as_JSON().dump(4), src/cerebro_node.cpp:769-770, keys
+// of src/Cerebro.cpp:1149-1159) -- e.g. a recorded EuRoC run of the reference against `cerebro_replay <stream> <out.json>` fed
+// the same descriptors and tick schedule (BASELINE configs 1 and 5).  Candidates are matched IN ORDER on the four time stamps
+// (sec/nsec of t_curr and t_prev): that is the selection.  global_a / global_b are not compared (the reference reports the
+// index into DataManager's data_map, this harness the DB row); scores are compared numerically and the largest difference is
+// reported (Eigen's summation order differs from the fixed tree in the last bits).  Prints one JSON object; exit status 0 iff
+// the two selections are identical.
+struct LoopRec { uint64_t sa = 0, na = 0, sb = 0, nb = 0; double score = 0.0; int have = 0; };
+
+static bool parse_loop_dump(const char *path, std::vector<LoopRec> &out, std::string &err)
+{
+    FILE *f = std::fopen(path, "rb");
+    if (!f) { err = std::string("cannot open ") + path; return false; }
+    std::string t;
+    char buf[1 << 16];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) t.append(buf, n);
+    std::fclose(f);
+    const char *p = t.c_str(), *e = p + t.size();
+    auto ws = [&] { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; };
+    ws();
+    if (p < e && std::strncmp(p, "null", 4) == 0) return true;   // nlohmann dumps an empty (never pushed-to) json as null
+    if (p >= e || *p != '[') { err = "expected a JSON array"; return false; }
+    p++;
+    for (;;) {
+        ws();
+        if (p < e && *p == ']') return true;
+        if (p >= e || *p != '{') { err = "expected an object"; return false; }
+        p++;
+        LoopRec r;
+        for (;;) {
+            ws();
+            if (p < e && *p == '}') { p++; break; }
+            if (p >= e || *p != '"') { err = "expected a key"; return false; }
+            const char *k = ++p;
+            while (p < e && *p != '"') p++;
+            if (p >= e) { err = "unterminated key"; return false; }
+            const std::string key(k, p);
+            p++;
+            ws();
+            if (p >= e || *p != ':') { err = "expected ':'"; return false; }
+            p++;
+            ws();
+            char *q = nullptr;
+            if (key == "score") { r.score = std::strtod(p, &q); r.have |= 16; }
+            else if (key == "time_sec_a") { r.sa = std::strtoull(p, &q, 10); r.have |= 1; }
+            else if (key == "time_nsec_a") { r.na = std::strtoull(p, &q, 10); r.have |= 2; }
+            else if (key == "time_sec_b") { r.sb = std::strtoull(p, &q, 10); r.have |= 4; }
+            else if (key == "time_nsec_b") { r.nb = std::strtoull(p, &q, 10); r.have |= 8; }
+            else (void)std::strtod(p, &q);   // time_double_*, global_*: numbers, not part of the comparison
+            if (!q || q == p) { err = "expected a number for key " + key; return false; }
+            p = q;
+            ws();
+            if (p < e && *p == ',') p++;
+        }
+        if (r.have != 31) { err = "candidate without time_sec/nsec_a/b + score"; return false; }
+        out.push_back(r);
+        ws();
+        if (p < e && *p == ',') p++;
+    }
+}
+
+static int compare_dumps(const char *ref_path, const char *cand_path)
+{
+    std::vector<LoopRec> a, b;
+    std::string err;
+    if (!parse_loop_dump(ref_path, a, err)) { std::fprintf(stderr, "%s: %s\n", ref_path, err.c_str()); return 6; }
+    if (!parse_loop_dump(cand_path, b, err)) { std::fprintf(stderr, "%s: %s\n", cand_path, err.c_str()); return 6; }
+    size_t n = a.size() < b.size() ? a.size() : b.size(), first = n;
+    double max_d = 0.0;
+    for (size_t i = 0; i < n; i++) {
+        if (a[i].sa != b[i].sa || a[i].na != b[i].na || a[i].sb != b[i].sb || a[i].nb != b[i].nb) { first = i; break; }
+        const double d = a[i].score > b[i].score ? a[i].score - b[i].score : b[i].score - a[i].score;
+        if (d > max_d) max_d = d;
+    }
+    const bool same = first == n && a.size() == b.size();
+    std::printf("{\"identical_selection\": %s, \"n_reference\": %zu, \"n_candidate\": %zu, \"matched_prefix\": %zu, \"max_abs_score_diff\": %.17g",
+                same ? "true" : "false", a.size(), b.size(), first, max_d);
+    if (!same) {
+        std::printf(", \"first_divergence\": {\"index\": %zu", first);
+        auto one = [](const char *name, const std::vector<LoopRec> &v, size_t i) {
+            if (i < v.size())
+                std::printf(", \"%s\": {\"time_sec_a\": %llu, \"time_nsec_a\": %llu, \"time_sec_b\": %llu, \"time_nsec_b\": %llu, \"score\": %.17g}", name,
+                            (unsigned long long)v[i].sa, (unsigned long long)v[i].na, (unsigned long long)v[i].sb, (unsigned long long)v[i].nb, v[i].score);
+            else std::printf(", \"%s\": null", name);
+        };
+        one("reference", a, first);
+        one("candidate", b, first);
+        std::printf("}");
+    }
+    std::printf("}\n");
+    return same ? 0 : 1;
 }
 
 // --gate <in.txt> : no GPU.  One candidate per line: sec1 nsec1 sec2 nsec2 idx1 idx2 pf_matches g1 g2 g3 then 3 x 16 doubles
@@ -167,6 +263,7 @@ int main(int argc, char **argv)
         argv += 2;
         argc -= 2;
     }
+    if (argc >= 4 && std::strcmp(argv[1], "--compare") == 0) return compare_dumps(argv[2], argv[3]);
     if (argc >= 3 && std::strcmp(argv[1], "--gate") == 0) return gate(argv[2]);
     if (argc >= 3 && std::strcmp(argv[1], "--threeway") == 0) return threeway(argv[2], argc > 3 ? std::atoi(argv[3]) : 0);
     if (argc >= 4 && std::strcmp(argv[1], "--parse-only") == 0) return parse_only(argv[2], argv[3]);

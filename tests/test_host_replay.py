@@ -77,6 +77,46 @@ def test_replay_matches_oracle(tmp_path, devices):
         for k, v in w.items():
             assert g[k] == v, (k, g, w)            # score round-trips exactly through %.17g
         assert g["time_double_a"] == pytest.approx(w["time_sec_a"] + 1e-9 * w["time_nsec_a"])
+    # the one-command check for whoever holds a recorded run of the reference: its dump vs ours
+    (tmp_path / "liverun.json").write_text(json.dumps([dict(w, time_double_a=0.0, time_double_b=0.0, global_a=0, global_b=0) for w in want], indent=4))
+    r = subprocess.run([str(LIB / "cerebro_replay"), "--compare", str(tmp_path / "liverun.json"), str(tmp_path / "o.json")], capture_output=True, text=True)
+    assert r.returncode == 0 and json.loads(r.stdout)["identical_selection"], r.stdout + r.stderr
+
+
+def test_compare_recorded_reference_run(tmp_path):
+    """cerebro_replay --compare: diff of a recorded loopcandidates_liverun.json (the reference's own dump, nlohmann dump(4),
+    src/cerebro_node.cpp:769-770) against this harness's output.  No GPU: pure host logic."""
+    rng = np.random.default_rng(5)
+    ref = []
+    for i in range(40):
+        sa, na = 1403636579 + 3 * i, int(rng.integers(0, 10**9))
+        sb, nb = 1403636000 + i, int(rng.integers(0, 10**9))
+        ref.append({"time_sec_a": sa, "time_nsec_a": na, "time_sec_b": sb, "time_nsec_b": nb, "time_double_a": sa + 1e-9 * na,
+                    "time_double_b": sb + 1e-9 * nb, "global_a": 4000 + 7 * i, "global_b": 100 + i, "score": float(rng.uniform(0.86, 0.99))})
+
+    def run(a, b):
+        (tmp_path / "ref.json").write_text(a if isinstance(a, str) else json.dumps(a, indent=4))
+        (tmp_path / "ours.json").write_text(b if isinstance(b, str) else json.dumps(b, separators=(",", ":")))
+        r = subprocess.run([str(LIB / "cerebro_replay"), "--compare", str(tmp_path / "ref.json"), str(tmp_path / "ours.json")], capture_output=True, text=True)
+        return r.returncode, (json.loads(r.stdout) if r.stdout.strip() else r.stderr)
+
+    ours = [dict(c, global_a=c["global_a"] // 7, global_b=c["global_b"] - 100, score=c["score"] * (1 + 2e-16)) for c in ref]   # other index space, last-bit scores
+    rc, j = run(ref, ours)
+    assert rc == 0 and j["identical_selection"] and j["n_reference"] == j["n_candidate"] == j["matched_prefix"] == 40
+    assert 0 < j["max_abs_score_diff"] < 1e-15
+    bad = [dict(c) for c in ours]
+    bad[17]["time_nsec_b"] += 50_000_000                       # a neighbouring keyframe was selected
+    rc, j = run(ref, bad)
+    assert rc == 1 and not j["identical_selection"] and j["matched_prefix"] == 17 and j["first_divergence"]["index"] == 17
+    assert j["first_divergence"]["reference"]["time_nsec_b"] + 50_000_000 == j["first_divergence"]["candidate"]["time_nsec_b"]
+    rc, j = run(ref, ours[:30])                                 # candidates missing at the end
+    assert rc == 1 and j["matched_prefix"] == 30 and j["first_divergence"]["candidate"] is None
+    rc, j = run(ref, ours[:5] + ours[6:])                       # one candidate missing in the middle
+    assert rc == 1 and j["first_divergence"]["index"] == 5
+    rc, j = run("null", "[]")                                   # nlohmann dumps a never-pushed-to json as null
+    assert rc == 0 and j["n_reference"] == 0
+    rc, j = run(ref, '[{"time_sec_a": 1}]')
+    assert rc == 6 and "score" in j
 
 
 # ------------------------------------------------------------------ N1: state.json cold start
