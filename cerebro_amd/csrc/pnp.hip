@@ -630,6 +630,19 @@ struct EigArgs {
 #define VV(i, j) Vs[(i) * EN + (j)]
 #define XX(i, j) Xs[(i) * EN + (j)]
 
+// pnp_eig_score is ONE wave per workgroup: the LDS unit executes a wave's DS instructions in issue order, so a write by any lane
+// is visible to a later read by any lane of the same wave without waiting for the write to complete.  What the code needs
+// between its phases is therefore only that the COMPILER keeps the program order of the LDS accesses -- a wavefront-scope
+// fence + scheduling barrier -- not __syncthreads(), whose workgroup-scope fence drains the LDS queue (s_waitcnt lgkmcnt(0)).
+// Measured: 20 fewer full LDS drains in the kernel, no change in the call time (1.17 ms) -- the double-shift step is bound by
+// its dependent fp64 chain (exact sqrt + IEEE division of the reflector, ~45 dependent operations), not by the LDS queue.
+#define WAVE_SYNC()                                                   \
+    do {                                                              \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        \
+        __builtin_amdgcn_wave_barrier();                              \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        \
+    } while (0)
+
 __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
 {
     __shared__ double Hs[EN * EN], Vs[EN * EN], Xs[EN * EN];
@@ -650,7 +663,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
         const int s = a.sample[hyp * kSampleMax + lane];
         sxs[3 * lane] = pr.X[3 * s]; sxs[3 * lane + 1] = pr.X[3 * s + 1]; sxs[3 * lane + 2] = pr.X[3 * s + 2];
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     if (a.debug_stop == 1) return;
     // ================= Householder reduction to Hessenberg form (orthes) =================
@@ -693,7 +706,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                 }
                 for (; i <= high; i++) HH(i, j) = HH(i, j) - f * lane_value_f64(ov, i);
             }
-            __syncthreads();
+            WAVE_SYNC();
             if (lane <= high) {  // H = H (I - u u^T/h), row i = lane
                 const int i = lane;
                 double f = 0.0;
@@ -717,15 +730,15 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                 }
                 for (; j <= high; j++) HH(i, j) = HH(i, j) - f * lane_value_f64(ov, j);
             }
-            __syncthreads();
+            WAVE_SYNC();
             if (lane == 0) {
                 ortm[m] = scale * (om - g);
                 HH(m, m - 1) = scale * g;
             }
-            __syncthreads();
+            WAVE_SYNC();
         } else {
             if (lane == 0) ortm[m] = 0.0;
-            __syncthreads();
+            WAVE_SYNC();
         }
     }
     // accumulate the reflectors into V (ortran)
@@ -740,14 +753,14 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                 g = (g / om) / hmm;
                 for (int i = m; i <= high; i++) VV(i, j) = VV(i, j) + g * (i == m ? om : HH(i, m - 1));
             }
-            __syncthreads();
+            WAVE_SYNC();
         }
     }
     for (int e = lane; e < EN * EN; e += 64) {
         const int i = e / EN, j = e % EN;
         if (j < i - 1) Hs[e] = 0.0;
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     if (a.debug_stop == 2) return;
     // ================= Francis double-shift QR with accumulation (hqr2) =================
@@ -775,9 +788,9 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
         }
         if (l == n) {  // one root
             const double v = HH(n, n) + exshift;
-            __syncthreads();
+            WAVE_SYNC();
             if (lane == 0) { HH(n, n) = v; wr[n] = v; wi[n] = 0.0; }
-            __syncthreads();
+            WAVE_SYNC();
             n--; iter = 0;
         } else if (l == n - 1) {  // two roots
             w = HH(n, n - 1) * HH(n - 1, n);
@@ -786,9 +799,9 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             z = sqrt(fabs(q));
             const double hnn = HH(n, n) + exshift, hn1 = HH(n - 1, n - 1) + exshift;
             x = hnn;
-            __syncthreads();
+            WAVE_SYNC();
             if (lane == 0) { HH(n, n) = hnn; HH(n - 1, n - 1) = hn1; }
-            __syncthreads();
+            WAVE_SYNC();
             if (q >= 0) {  // real pair
                 z = (p >= 0) ? p + z : p - z;
                 const double w0 = x + z;
@@ -800,7 +813,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                 p = x / s; q = z / s;
                 r = sqrt(p * p + q * q);
                 p = p / r; q = q / r;
-                __syncthreads();
+                WAVE_SYNC();
                 if (lane >= n - 1 && lane < nn) {  // rows n-1, n
                     const int j = lane;
                     const double zz = HH(n - 1, j);
@@ -813,17 +826,17 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                     VV(i, n - 1) = q * zz + p * VV(i, n);
                     VV(i, n) = q * VV(i, n) - p * zz;
                 }
-                __syncthreads();
+                WAVE_SYNC();
                 if (lane <= n) {  // columns n-1, n
                     const int i = lane;
                     const double zz = HH(i, n - 1);
                     HH(i, n - 1) = q * zz + p * HH(i, n);
                     HH(i, n) = q * HH(i, n) - p * zz;
                 }
-                __syncthreads();
+                WAVE_SYNC();
             } else {  // complex pair
                 if (lane == 0) { wr[n - 1] = x + p; wr[n] = x + p; wi[n - 1] = z; wi[n] = -z; }
-                __syncthreads();
+                WAVE_SYNC();
             }
             n -= 2; iter = 0;
         } else {
@@ -831,9 +844,9 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             if (l < n) { y = HH(n - 1, n - 1); w = HH(n, n - 1) * HH(n - 1, n); }
             if (iter == 10) {  // Wilkinson's exceptional shift
                 exshift = exshift + x;
-                __syncthreads();
+                WAVE_SYNC();
                 if (lane >= low && lane <= n) HH(lane, lane) = HH(lane, lane) - x;
-                __syncthreads();
+                WAVE_SYNC();
                 s = fabs(HH(n, n - 1)) + fabs(HH(n - 1, n - 2));
                 x = y = 0.75 * s;
                 w = -0.4375 * s * s;
@@ -845,9 +858,9 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                     s = sqrt(s);
                     if (y < x) s = -s;
                     s = x - w / ((y - x) / 2.0 + s);
-                    __syncthreads();
+                    WAVE_SYNC();
                     if (lane >= low && lane <= n) HH(lane, lane) = HH(lane, lane) - s;
-                    __syncthreads();
+                    WAVE_SYNC();
                     exshift = exshift + s;
                     x = y = w = 0.964;
                 }
@@ -882,9 +895,9 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                 m = 63 - __builtin_clzll(bm);   // lane l always passes and l <= n-2 in this branch
                 p = __shfl(pm, m, 64); q = __shfl(qm, m, 64); r = __shfl(rm, m, 64);
             }
-            __syncthreads();
+            WAVE_SYNC();
             if (lane >= m + 2 && lane <= n) { HH(lane, lane - 2) = 0.0; if (lane > m + 2) HH(lane, lane - 3) = 0.0; }
-            __syncthreads();
+            WAVE_SYNC();
             // Double QR step on rows l..n, columns m..n.  Per step: (1) the reflector from column k-1, (2) row modification
             // (lane = column j of H), (3) column modification (lane = row i of H) together with the accumulation into V
             // (lanes 32..58 = row i of V): both have the form  pp = x*A(i,k) + y*A(i,k+1) [+ z*A(i,k+2)], so one
@@ -923,7 +936,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                         x = lane_value_f64(quo, 0); y = lane_value_f64(quo, 1); z = lane_value_f64(quo, 2);
                         q = lane_value_f64(quo, 3); r = lane_value_f64(quo, 4);
                     }
-                    __syncthreads();
+                    WAVE_SYNC();
                     if (wr_sub && lane == 63) HH(k, k - 1) = hkk1;
                     if (lane >= k && lane < nn) {  // row modification, column j = lane
                         const int j = lane;
@@ -932,7 +945,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                         HH(k, j) = HH(k, j) - pp * x;
                         HH(k + 1, j) = HH(k + 1, j) - pp * y;
                     }
-                    __syncthreads();
+                    WAVE_SYNC();
                     const int imax = (n < k + 3) ? n : k + 3;
                     double c0 = 0.0;
                     if ((lane < 32) ? (lane <= imax) : (lane - 32 <= high)) {  // H rows 0..imax | V rows 0..26
@@ -950,12 +963,12 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                         fr = (k + 1 != n - 1) ? lane_value_f64(c0, k + 3) : 0.0;
                         fwd = true;
                     }
-                    __syncthreads();
+                    WAVE_SYNC();
                 }
             }
         }
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     if (a.debug_stop == 3) return;
     // ================= back-substitution (real eigenvalues only), one lane per eigenvector =================
@@ -1029,7 +1042,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
         model[8] = R[2]; model[9] = R[5]; model[10] = R[8]; model[11] = 0.0;
         model[12] = t3[0]; model[13] = t3[1]; model[14] = t3[2]; model[15] = 1.0;
     }
-    __syncthreads();
+    WAVE_SYNC();
     if (nsol != 1) {
         if (lane == 0) { a.valid[hyp] = 0; a.nin[hyp] = 0; a.cost[hyp] = INFINITY; }
         return;
