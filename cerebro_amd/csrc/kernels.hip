@@ -32,11 +32,20 @@ template <typename T> struct Vec16;                       // 16 bytes of storage
 template <> struct Vec16<float> { typedef f32x4 type; static constexpr int N = 4; };
 template <> struct Vec16<double> { typedef f64x2 type; static constexpr int N = 2; };
 
+// DB rows are reached through a pointer loaded from the segment table, which the compiler can only treat as a GENERIC pointer:
+// it would emit flat_load, which is tracked by BOTH vmcnt and lgkmcnt -- every wait for an LDS read (the staged queries) then
+// also waits for the row loads in flight.  The explicit address-space cast makes them global_load (vmcnt only).
+template <typename V>
+__device__ __forceinline__ const __attribute__((address_space(1))) V *as_global(const V *p)
+{
+    return (const __attribute__((address_space(1))) V *)p;
+}
+
 template <int POLICY, typename V>
 __device__ __forceinline__ V stream_load(const V *p)
 {
-    if constexpr (POLICY == 0) return *p;
-    else if constexpr (POLICY == 1) return __builtin_nontemporal_load(p);
+    if constexpr (POLICY == 0) return *as_global(p);
+    else if constexpr (POLICY == 1) return __builtin_nontemporal_load(as_global(p));
     else {
         V v;
         if constexpr (POLICY == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
