@@ -208,11 +208,19 @@ def batch_leg(chip, rows: int, Q: int = 256):
     assert (ix[:, 0] == (np.arange(Q) * 7919) % rows).all()      # every query finds itself
     k_s = ms / 1e3 / cnt
     flops = 2.0 * Q * rows * D
+    traffic = traffic_source = None
+    pj = ROOT / "profiles" / "batch_traffic.json"
+    if pj.exists() and D == 4096 and rows == 1_000_000 and Q == 256:
+        try:
+            traffic = json.loads(pj.read_text()).get("hbm_bytes_per_launch")
+            traffic_source = "profiles/batch_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 of this launch shape, separate run)"
+        except Exception:
+            traffic = None
     return {"metric": "batched queries/sec (Q x DB fp32 GEMM on MFMA + fused top-k)", "value": Q / dt, "unit": "queries/s",
             "Q": Q, "db_rows": rows, "ms_per_call": dt * 1e3, "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact k-ordered fmaf chain)",
             "roofline": {"bound": "mfma", "achieved": flops / k_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                          "frac": flops / k_s / 1e12 / 157.3, "kernel": "db_gemm_topk", "avg_kernel_ms": k_s * 1e3,
-                         "algorithmic_flops_per_launch": flops, "traffic": None}}
+                         "algorithmic_flops_per_launch": flops, "traffic": traffic, "traffic_source": traffic_source}}
 
 
 def run_ticks(chip, tick_ls, params, inflight, stamps=None):

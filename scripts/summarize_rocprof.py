@@ -48,6 +48,8 @@ def main(tag: str, src: str = "gpurun_out/prof"):
             lines += ["", "`db_scan_topk` launches by prefix length (duration clusters; the headline 1M-row launch is the last row):", "",
                       "| launches | avg (us) | min (us) | max (us) |", "|---|---|---|---|"]
             lines += [f"| {c} | {a:.2f} | {mn:.2f} | {mx:.2f} |" for c, a, mn, mx in scan_clusters]
+            lines += ["", "(The 10k / 100k legs alternate their launches between two scan streams, so consecutive launches overlap and their",
+                      "rocprofv3 durations are inflated; the `min` column and bench.py's hipEvent pass -- one stream -- are the kernel itself.)"]
         lines += ["", "Note on `topk_merge`: its rocprofv3 duration includes the time its dispatch packet spends blocked on the scan-finished",
                   "event (the host enqueues tick i's merge while scan i is still running; the packet is picked up at once and waits), so",
                   "avg/max are about one scan long while min is the kernel itself. It runs on the ctx stream, overlapped with the next scan.", ""]
