@@ -223,6 +223,28 @@ def batch_leg(chip, rows: int, Q: int = 256):
                          "algorithmic_flops_per_launch": flops, "traffic": traffic, "traffic_source": traffic_source}}
 
 
+class c_stdout_to_stderr:
+    """RCCL prints a version banner through C stdio when a communicator is created; with stdout on a pipe it would come out at
+    process exit, AFTER the JSON line.  Creating communicators inside this context sends it to stderr instead (fd 1 is pointed at
+    fd 2 and the C buffers are flushed before it is restored), so stdout carries the one JSON line and nothing else."""
+
+    def __enter__(self):
+        import ctypes
+        self.libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self.libc.fflush(None)
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        self.libc.fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def run_ticks(chip, tick_ls, params, inflight, stamps=None):
     """Pipelined tick loop: up to `inflight` ticks enqueued ahead, results collected in order.  stamps (optional list) gets
     the host time of every collect -- the per-step cadence of the steady state."""
@@ -374,7 +396,8 @@ def main():
         devices = [0] * args.gpus if args.same_device else list(range(args.gpus))
         if not args.same_device and ndev < args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but only {ndev} device(s) visible (use --same-device for a functional run)")
-        chip = capi.Chip(D, capacity_hint=total_rows, devices=devices, storage=storage)
+        with c_stdout_to_stderr():
+            chip = capi.Chip(D, capacity_hint=total_rows, devices=devices, storage=storage)
     else:
         chip = capi.Chip(D, capacity_hint=total_rows, device=local_rank, shard_rank=0 if replicated else rank,
                          shard_count=1 if replicated else world, storage=storage)
@@ -395,7 +418,8 @@ def main():
             uid = [capi.comm_unique_id() if rank == 0 else None]
             if dist is not None:
                 dist.broadcast_object_list(uid, src=0)
-            chip.comm_init_rank(uid[0], world, rank)
+            with c_stdout_to_stderr():
+                chip.comm_init_rank(uid[0], world, rank)
             exchange = "in-library RCCL: ncclAllGather of 3 x top-k (score, index) per rank per tick, enqueued in-stream"
     elif group_mode:
         exchange = {capi.CHIP_EXCHANGE_RCCL: "in-library RCCL (ncclCommInitAll, one worker thread per device)",
