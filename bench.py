@@ -570,11 +570,14 @@ def main():
                                                        f"{nt} usable under the affinity mask / cgroup quota"}
         print(json.dumps(out), flush=True)
 
-    if det is not None:
-        det.close()
-    chip.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    # whatever C stdio output is still buffered in this process (RCCL banners of torch's own communicator, ...) leaves through
+    # stderr: stdout has carried the JSON line and must carry nothing after it
+    with c_stdout_to_stderr():
+        if det is not None:
+            det.close()
+        chip.close()
+        if dist is not None:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
