@@ -472,8 +472,14 @@ int chip_create_multi(chip_ctx **out, int32_t D, int64_t capacity_hint, const in
     if (rc == CHIP_OK && G->transport == CHIP_EXCHANGE_RCCL) {
         std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
         const ncclResult_t r = ncclCommInitAll(comms.data(), n_devices, devices);
-        if (r != ncclSuccess) { gc->last_comm = (int)r; rc = CHIP_ERR_COMM; }
-        else
+        if (r != ncclSuccess) {
+            // No communicator (RCCL absent / misconfigured, peer access refused ...): the lists are 384 B per device and tick, so
+            // the device-copy exchange is a full substitute -- fall back to it instead of failing the create; the ncclResult_t
+            // stays readable through chip_last_comm_error and chip_get_info reports CHIP_EXCHANGE_COPY.
+            gc->last_comm = (int)r;
+            G->transport = CHIP_EXCHANGE_COPY;
+            gc->group_transport = CHIP_EXCHANGE_COPY;
+        } else
             for (int g = 0; g < n_devices; g++) G->subs[(size_t)g]->xchg->comm = comms[(size_t)g];
     }
     if (rc == CHIP_OK) {

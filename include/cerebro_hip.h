@@ -101,7 +101,8 @@ int  chip_create_ex(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t de
  *     rank per tick, enqueued in-stream between the local and the global merge) when the devices are distinct; device
  *     copies (lists written / copied straight into the root's gather buffer behind events) when CHIP_MULTI_EXCHANGE_COPY is
  *     passed or the list names a device twice (RCCL refuses two ranks on one device) -- the latter lets a 1-GPU box run the
- *     G = 2..8 code path.
+ *     G = 2..8 code path.  If RCCL cannot build the communicator the create does not fail: it falls back to the copy exchange
+ *     (chip_get_info().exchange tells which one is in use, chip_last_comm_error() why).
  * (b) one process PER GPU (torchrun-style launch): create each rank's ctx with chip_create(.., shard_rank, shard_count),
  *     then attach an RCCL communicator: rank 0 calls chip_comm_unique_id, distributes the 128 bytes by any means, every
  *     rank calls chip_comm_init_rank.  From then on chip_loop_tick / _enqueue / _collect and chip_query_* work on the
