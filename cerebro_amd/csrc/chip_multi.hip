@@ -13,6 +13,7 @@
 #include <rccl/rccl.h>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <new>
 #include <thread>
@@ -103,13 +104,26 @@ int xchg_query(Ctx *c, int64_t k, const void *const *q, int nq, int K, double *s
 // ------------------------------------------------------------------------------------------------ group: workers
 // One host thread per sub-context: it makes that device current once and enqueues the device's share of every group call,
 // so the host cost of a tick (two launches, a few events, the collective) is paid G-wide in parallel instead of serially.
+// Several host threads may be inside group calls at once (the reference's appender, querier and PnP threads share the ctx), so a
+// worker has a FIFO of jobs, each pointing at the completion record of the call it belongs to.  A worker runs its jobs in the
+// order they were posted; calls that must stay ordered across devices (ticks / queries: they carry collectives) are posted
+// under the group's query lock, hence in the same order on every worker.
+struct JobGroup {
+    std::mutex m;
+    std::condition_variable cv;
+    int remaining = 0;
+    int rc = CHIP_OK;
+};
+struct Job {
+    std::function<int()> fn;
+    JobGroup *grp = nullptr;
+};
 struct Worker {
     std::thread th;
     std::mutex m;
     std::condition_variable cv;
-    std::function<int()> job;
-    bool has = false, done = false, quit = false;
-    int rc = 0;
+    std::deque<Job> q;
+    bool quit = false;
 };
 
 struct Group {
@@ -125,16 +139,18 @@ static void worker_main(Worker *w, int device)
     (void)hipSetDevice(device);
     std::unique_lock<std::mutex> lk(w->m);
     for (;;) {
-        w->cv.wait(lk, [&] { return w->has || w->quit; });
-        if (w->quit) return;
-        std::function<int()> job = std::move(w->job);
-        w->has = false;
+        w->cv.wait(lk, [&] { return !w->q.empty() || w->quit; });
+        if (w->q.empty()) return;   // quit, nothing pending
+        Job job = std::move(w->q.front());
+        w->q.pop_front();
         lk.unlock();
-        const int rc = job();
+        const int rc = job.fn();
+        {
+            std::lock_guard<std::mutex> g(job.grp->m);
+            if (rc != CHIP_OK && job.grp->rc == CHIP_OK) job.grp->rc = rc;
+            if (--job.grp->remaining == 0) job.grp->cv.notify_all();
+        }
         lk.lock();
-        w->rc = rc;
-        w->done = true;
-        w->cv.notify_all();
     }
 }
 
@@ -142,21 +158,21 @@ static void worker_main(Worker *w, int device)
 static int run_all(Group *G, const std::function<int(int)> &fn)
 {
     const int n = (int)G->subs.size();
+    JobGroup jg;
+    jg.remaining = n - 1;
     for (int g = 1; g < n; g++) {
         Worker *w = G->workers[g];
         std::lock_guard<std::mutex> lk(w->m);
-        w->job = [&fn, g] { return fn(g); };
-        w->has = true;
-        w->done = false;
-        w->cv.notify_all();
+        Job j;
+        j.fn = [&fn, g] { return fn(g); };
+        j.grp = &jg;
+        w->q.push_back(std::move(j));
+        w->cv.notify_one();
     }
     int rc = fn(0);
-    for (int g = 1; g < n; g++) {
-        Worker *w = G->workers[g];
-        std::unique_lock<std::mutex> lk(w->m);
-        w->cv.wait(lk, [&] { return w->done; });
-        if (rc == CHIP_OK) rc = w->rc;
-    }
+    std::unique_lock<std::mutex> lk(jg.m);
+    jg.cv.wait(lk, [&] { return jg.remaining == 0; });
+    if (rc == CHIP_OK) rc = jg.rc;
     return rc;
 }
 
