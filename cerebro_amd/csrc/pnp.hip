@@ -628,7 +628,6 @@ struct EigArgs {
 
 #define HH(i, j) Hs[(i) * EN + (j)]
 #define VV(i, j) Vs[(i) * EN + (j)]
-#define XX(i, j) Xs[(i) * EN + (j)]
 
 // pnp_eig_score is ONE wave per workgroup: the LDS unit executes a wave's DS instructions in issue order, so a write by any lane
 // is visible to a later read by any lane of the same wave without waiting for the write to complete.  What the code needs
@@ -645,7 +644,7 @@ struct EigArgs {
 
 __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
 {
-    __shared__ double Hs[EN * EN], Vs[EN * EN], Xs[EN * EN];
+    __shared__ double Hs[EN * EN], Vs[EN * EN];
     __shared__ double ortm[EN], wr[EN], wi[EN], Tf[27], sxs[kSampleMax * 3], model[16];
     const int lane = threadIdx.x;
     const int hyp = blockIdx.x;                                    // slot: hypothesis (hyp % H) of problem (hyp / H)
@@ -979,6 +978,17 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
         const double pe = wr[nn_];
         int l = nn_;
         double zz = 0.0, ss = 0.0;
+        // The eigenvector x of the quasi-triangular form (entries 0..nn_) needs no matrix of its own: after the QR iteration only rows
+        // {0, 1, 3, 9} of V are still read (the back-transform of the monomials 1, s3, s2, s1 below), so x lives in the other 23
+        // rows -- column c <= 12 at the start of free row F[c], column 25 - c behind it (c + 1 + 26 - c = 27 entries fill the row),
+        // column 26 in a row of its own.  6 KiB less LDS per wave: 11 instead of 8 waves per CU when many problems are batched.
+        double *xcol;
+        {
+            const int c = nn_ <= 12 ? nn_ : (nn_ <= 25 ? 25 - nn_ : 13);   // index into the free rows
+            const int row = c < 1 ? 2 : (c < 6 ? c + 3 : c + 4);            // F = {2, 4..8, 10..26}
+            xcol = Vs + row * EN + ((nn_ > 12 && nn_ <= 25) ? 26 - nn_ : 0);
+        }
+#define XX(i, j) xcol[(i)]
         XX(nn_, nn_) = 1.0;
         for (int i = nn_ - 1; i >= 0; i--) {
             const double ww = HH(i, i) - pe;
@@ -1009,6 +1019,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             for (int k = 0; k <= nn_; k++) acc = acc + VV(i, k) * XX(k, nn_);
             v4[rrw] = acc;
         }
+#undef XX
         const double s1 = v4[3] / v4[0], s2 = v4[2] / v4[0], s3 = v4[1] / v4[0];
         if (fabs(s1) <= DBL_MAX && fabs(s2) <= DBL_MAX && fabs(s3) <= DBL_MAX) {
             const double nq = sqrt(((1.0 + s1 * s1) + s2 * s2) + s3 * s3);
