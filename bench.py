@@ -418,9 +418,29 @@ def main():
             uid = [capi.comm_unique_id() if rank == 0 else None]
             if dist is not None:
                 dist.broadcast_object_list(uid, src=0)
-            with c_stdout_to_stderr():
-                chip.comm_init_rank(uid[0], world, rank)
-            exchange = "in-library RCCL: ncclAllGather of 3 x top-k (score, index) per rank per tick, enqueued in-stream"
+            ok = 1
+            try:
+                with c_stdout_to_stderr():
+                    chip.comm_init_rank(uid[0], world, rank)
+            except capi.ChipError as e:   # e.g. RCCL refusing the topology: every rank must learn of it and take the same path
+                sys.stderr.write(f"[bench rank {rank}] chip_comm_init_rank failed: {e}\n")
+                ok = 0
+            if dist is not None:
+                flag = torch.tensor([ok], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if ok:
+                exchange = "in-library RCCL: ncclAllGather of 3 x top-k (score, index) per rank per tick, enqueued in-stream"
+            else:
+                # agreed fallback: the host-driven exchange over a torch.distributed RCCL group (the ctx of a rank whose attach
+                # did succeed is rebuilt, so that every rank runs the same code path)
+                sys.stderr.write(f"[bench rank {rank}] falling back to the host-driven exchange (torch.distributed nccl)\n")
+                chip.close()
+                chip = capi.Chip(D, capacity_hint=total_rows, device=local_rank, shard_rank=rank, shard_count=world, storage=storage)
+                from cerebro_amd.sharded import ShardedLoopDetector
+                grp = dist.new_group(backend="nccl") if dist is not None and dist.get_backend() != "nccl" else None
+                det = ShardedLoopDetector(chip, topk=TOPK, group=grp, device=torch.device("cuda", local_rank))
+                exchange = "host-driven fallback: torch.distributed all_gather_into_tensor (nccl) after chip_comm_init_rank failed"
     elif group_mode:
         exchange = {capi.CHIP_EXCHANGE_RCCL: "in-library RCCL (ncclCommInitAll, one worker thread per device)",
                     capi.CHIP_EXCHANGE_COPY: "in-library device copies (devices repeat: RCCL refuses two ranks on one device)"}[chip.info()["exchange"]]
