@@ -420,6 +420,8 @@ def main():
                 dist.broadcast_object_list(uid, src=0)
             ok = 1
             try:
+                if os.environ.get("BENCH_FAIL_COMM_INIT"):   # test hook: exercise the agreed fallback below
+                    raise capi.ChipError(capi.CHIP_ERR_COMM, "chip_comm_init_rank", "BENCH_FAIL_COMM_INIT")
                 with c_stdout_to_stderr():
                     chip.comm_init_rank(uid[0], world, rank)
             except capi.ChipError as e:   # e.g. RCCL refusing the topology: every rank must learn of it and take the same path
@@ -438,7 +440,12 @@ def main():
                 chip.close()
                 chip = capi.Chip(D, capacity_hint=total_rows, device=local_rank, shard_rank=rank, shard_count=world, storage=storage)
                 from cerebro_amd.sharded import ShardedLoopDetector
-                grp = dist.new_group(backend="nccl") if dist is not None and dist.get_backend() != "nccl" else None
+                if dist is None:
+                    import torch.distributed as dist
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+                    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                grp = dist.new_group(backend="nccl") if dist.get_backend() != "nccl" else None
                 det = ShardedLoopDetector(chip, topk=TOPK, group=grp, device=torch.device("cuda", local_rank))
                 exchange = "host-driven fallback: torch.distributed all_gather_into_tensor (nccl) after chip_comm_init_rank failed"
     elif group_mode:

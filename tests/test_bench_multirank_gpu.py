@@ -56,6 +56,13 @@ def test_bench_one_process_group_same_device():
 def test_bench_force_sharded_uses_in_library_rccl():
     j = _run_single(["--force-sharded", "--rows", "60000"])
     assert j["n_gpus"] == 1 and "in-library RCCL" in j["config"]["exchange"] and j["value"] > 0
+    # the agreed fallback when attaching the communicator fails on some rank: host-driven exchange, same answers
+    os.environ["BENCH_FAIL_COMM_INIT"] = "1"
+    try:
+        j = _run_single(["--force-sharded", "--rows", "60000"])
+    finally:
+        del os.environ["BENCH_FAIL_COMM_INIT"]
+    assert "host-driven fallback" in j["config"]["exchange"] and j["value"] > 0
 
 
 def test_bench_sizes_key_and_f64_storage():
