@@ -45,7 +45,10 @@ md += ["", f"Derived: `GRBM_GUI_ACTIVE` / 8 XCDs = {gui:.3e} cycles per launch; 
        "| ... + barrier per 64 MFMAs | 122.9 | 0.781 |",
        "| ... + 8 LDS-DMA per wave per 64 MFMAs, `vmcnt(16)` | 116.4 | 0.740 |",
        "| A from a `[k][row]` image (`ds_read_b32`), B swizzled rows read as `ds_read2_b32` (4-way conflict), no VALU | 142.2 | 0.904 |",
-       "| ... + LDS-DMA + counted barrier per 64 MFMAs | 128.6 | 0.818 |", "",
+       "| ... + LDS-DMA + counted barrier per 64 MFMAs | 128.6 | 0.818 |",
+       "| 128 x 64 per wave (4 x 2 MFMA tiles, workgroup tile 256 x 128): 16 MFMAs per 4 A + 2 B reads, no DMA | 146.0 | 0.928 |",
+       "| ... + 12 LDS-DMA + barrier per 128 MFMAs (two 48-KiB stages) | 133.3 | 0.847 |", "",
+       "(The last two rows are the next step that was NOT taken: +3 points in the probe for a rewrite of the tile mapping and the epilogue.)", "",
        "Ablation of the shipped kernel with the accumulators kept alive: without the top-k epilogue 117.9 (two stages) / 120.3 (four stages)",
        "against 114.6 / 113.6 with it on that box: the epilogue is 3-6 % of the kernel (round 1: 17 %).", ""]
 (ROOT / "profiles/r02_batch_pmc.md").write_text("\n".join(md))
