@@ -20,9 +20,19 @@
         if (st_ != CHIP_OK) { std::fprintf(stderr, "%s -> %s\n", #call, chip_strerror(st_)); return 2; }   \
     } while (0)
 
-int main()
+// Usage: minimal_loop_detector [device list]   e.g. "0,1,2,3" = one handle over four GPUs (chip_create_multi; row i of the DB on
+// device i % 4, the per-device top-k lists exchanged by RCCL inside the library); a repeated device ("0,0") runs the sharded code
+// path on one GPU.  Without an argument: chip_create on device 0.  Everything after the create line is the same either way.
+int main(int argc, char **argv)
 {
     const int D = 4096, N = 600;
+    std::vector<int32_t> devices;
+    if (argc > 1)
+        for (const char *p = argv[1]; *p;) {
+            devices.push_back(std::atoi(p));
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
     std::mt19937 rng(7);
     std::normal_distribution<float> gauss(0.f, 1.f);
     std::vector<std::vector<double>> desc(N, std::vector<double>(D));   // the .srv wire type is float64[] holding float32 values
@@ -38,7 +48,8 @@ int main()
     }
 
     chip_ctx *chip = nullptr;
-    CHECK(chip_create(&chip, D, /*capacity_hint*/ 29000, /*device*/ 0, /*shard_rank*/ 0, /*shard_count*/ 1));   // Cerebro.cpp:946
+    if (devices.empty()) CHECK(chip_create(&chip, D, /*capacity_hint*/ 29000, /*device*/ 0, /*shard_rank*/ 0, /*shard_count*/ 1));   // Cerebro.cpp:946
+    else CHECK(chip_create_multi(&chip, D, 29000, devices.data(), (int32_t)devices.size(), 0));
     chip_dot_params prm;
     chip_dot_params_default(&prm);                                                                               // :912-914
 

@@ -285,4 +285,11 @@ def test_example_program_is_built_against_the_c_abi_only():
 def test_example_program_detects_the_revisit_and_recovers_the_pose():
     r = subprocess.run([str(LIB / "minimal_loop_detector")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    single = [l for l in r.stdout.splitlines() if l.startswith("loop candidate")]
+    # the same program over chip_create_multi: a one-device group (RCCL communicator) and four shards on one device
+    for devs in ("0", "0,0,0,0"):
+        rm = subprocess.run([str(LIB / "minimal_loop_detector"), devs], capture_output=True, text=True, timeout=300)
+        assert rm.returncode == 0, rm.stdout + rm.stderr
+        assert [l for l in rm.stdout.splitlines() if l.startswith("loop candidate")] == single
+    assert r.returncode == 0, r.stdout + r.stderr
     assert "loop candidate" in r.stdout and "PnP:" in r.stdout
