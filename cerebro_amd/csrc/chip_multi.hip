@@ -238,13 +238,15 @@ int group_read_rows(Ctx *gc, const int64_t *rows, int64_t n, void *out, int out_
 {
     Group *G = gc->group;
     std::lock_guard<std::mutex> qlk(gc->query_mu);
-    const int elem = gc->elem, D = gc->D;
-    if (out_elem < elem) return CHIP_ERR_NOT_F32;
+    const int D = gc->D;
+    int elem;
     int64_t total;
     {
-        std::lock_guard<std::mutex> lk(gc->mu);
+        std::lock_guard<std::mutex> lk(gc->mu);   // mirror_state writes both under this lock
         total = gc->rows_global;
+        elem = gc->elem;
     }
+    if (out_elem < elem) return CHIP_ERR_NOT_F32;
     const bool conv = out_elem != elem;
     std::vector<float> tmp;
     if (conv) tmp.resize((size_t)n * D);
