@@ -98,6 +98,85 @@ def run_ticks(n=12, seed=5):
     return bad
 
 
+def run_f64_and_groups(n=40, seed=23):
+    """Round-2 surface under the same randomised treatment: double-row DBs (genuinely float64 values, ties, duplicated rows,
+    extreme magnitudes; chosen explicitly or by the automatic switch), groups of 1..8 sub-contexts on one device (float and
+    double rows), score-vector export, tick schedules through the group entry points -- all bit for bit vs the oracle."""
+    import scenarios
+    rng = np.random.default_rng(seed)
+    bad = []
+    for it in range(n):
+        f64 = it % 2 == 0
+        G = int(rng.choice([0, 0, 1, 2, 3, 5, 8]))                     # 0 = plain ctx
+        D = int(rng.choice([4, 60, 252, 256, 1000, 1024, 4096] + ([6824] if f64 else [8192])))
+        N = int(rng.integers(60, 1500)) if D <= 4096 else int(rng.integers(60, 300))
+        kind = it % 4
+        if kind == 0: db = rng.standard_normal((N, D))
+        elif kind == 1: db = rng.integers(-2, 3, (N, D)).astype(np.float64) * (1.0 + 2.0 ** -40 if f64 else 1.0)   # exact ties
+        elif kind == 2:
+            db = rng.standard_normal((N, D)); db[rng.integers(0, N, N // 2)] = db[rng.integers(0, N)]
+        else: db = rng.standard_normal((N, D)) * 10.0 ** rng.integers(-20, 15)
+        if not f64: db = db.astype(np.float32).astype(np.float64)
+        elif kind != 1: db[0, 0] = 0.1                                   # make sure the first append is not float32-representable
+        scan = (lambda k, q, K: O.scan_topk_f64(db, k, q, K)) if f64 else (lambda k, q, K: O.scan_topk(db.astype(np.float32), k, q, K))
+        kw = dict(devices=[0] * G) if G else {}
+        storage = None if (it % 3 == 0 and (not f64 or kind != 1)) else ("f64" if f64 else "f32")    # None: decided by the data
+        k = int(rng.integers(0, N + 1)); nq = int(rng.integers(1, 4 if f64 and D * 8 * 4 > 160 * 1024 else 5)); topk = int(rng.integers(1, 17))
+        with capi.Chip(D, storage=storage, **kw) as chip:
+            cut = int(rng.integers(1, N + 1))
+            chip.append_f64(db[:cut])
+            if cut < N: chip.append_f64(db[cut:])
+            ok = chip.info()["storage_bytes"] == (8 if f64 else 4) and chip.size() == N
+            q = db[rng.integers(0, N, nq)]
+            gs, gi = chip.query_vectors_f64(k, q, topk)
+            os_, oi = scan(k, q if f64 else q.astype(np.float32), topk)
+            ok = ok and np.array_equal(gi, oi) and np.array_equal(gs.view(np.uint64), os_.view(np.uint64))
+            lo = max(0, N - 4000) if G > 1 else 0                        # sharded layouts: query rows come from the replicated ring
+            rows = rng.integers(lo, N, nq)
+            gs2, gi2 = chip.query_rows(k, rows, topk)
+            os2, oi2 = scan(k, db[rows] if f64 else db[rows].astype(np.float32), topk)
+            ok = ok and np.array_equal(gi2, oi2) and np.array_equal(gs2.view(np.uint64), os2.view(np.uint64))
+            u = chip.query_scores(k, int(rows[0]))
+            want_u = O.scores(db if f64 else db.astype(np.float32), k, db[rows[0]] if f64 else db[rows[0]].astype(np.float32))
+            ok = ok and np.array_equal(u.view(np.uint64), want_u.view(np.uint64))
+            back = chip.read_rows_f64([0, N - 1])
+            ok = ok and back.tobytes() == db[[0, N - 1]].tobytes()
+        if not ok:
+            bad.append(("scan", it, D, N, k, nq, topk, kind, f64, G, storage))
+    for it in range(max(2, n // 8)):                                    # tick schedules through groups, float and double rows
+        D = int(rng.choice([64, 256, 512])); N = int(rng.integers(300, 1000)); G = int(rng.choice([1, 2, 3, 8])); f64 = it % 2 == 1
+        plants, loops, ties = scenarios.loop_plants(N, 4, seed=300 + it)
+        db32 = scenarios.build_db(400 + it, N, D, plants)
+        db = db32.astype(np.float64)
+        if f64:
+            db = db * (1.0 + 2.0 ** -40 * rng.standard_normal((N, D)))
+            for d_, s_, k_ in plants:
+                if k_ == 2: db[d_] = db[s_]
+        orc = O.LoopOracle64(db) if f64 else O.LoopOracle(db32)
+        ls, l = [], 0
+        while True:
+            l += int(rng.choice([1, 2, 3, 3, 3, 4, 7, 20]))
+            if l > N: break
+            ls.append(l)
+        want = [orc.tick(l) for l in ls]
+        def same(g, o):
+            g = g.as_dict()
+            return all(g[k] == o[k] for k in ("status", "found", "idx_curr", "idx_prev", "argmax")) and \
+                float(g["score"]).hex() == float(o["score"]).hex() and [float(x).hex() for x in g["maxv"]] == [float(x).hex() for x in o["maxv"]]
+        with capi.Chip(D, devices=[0] * G) as chip:
+            chip.append_f64(db)
+            got = [chip.loop_tick(l) for l in ls]
+            if not all(same(g, o) for g, o in zip(got, want)): bad.append(("group-sync", it, G, f64))
+            chip.loop_reset()
+            W = int(rng.integers(1, 20)); pend = []; got = []
+            for i, l in enumerate(ls):
+                if len(pend) == W: got.append(chip.loop_tick_collect(pend.pop(0)))
+                chip.loop_tick_enqueue(l, i % W); pend.append(i % W)
+            while pend: got.append(chip.loop_tick_collect(pend.pop(0)))
+            if not all(same(g, o) for g, o in zip(got, want)): bad.append(("group-pipelined", it, G, W, f64))
+    return bad
+
+
 if __name__ == "__main__":
     t0 = time.time()
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 120
@@ -108,4 +187,7 @@ if __name__ == "__main__":
     bt = run_ticks(12)
     print(f"tick fuzz: {len(bt)} mismatches in 12 schedules")
     for b in bt[:10]: print(b)
+    bf = run_f64_and_groups(80)
+    print(f"f64 / group fuzz: {len(bf)} mismatches in 80 + 10 cases")
+    for b in bf[:10]: print(b)
 

@@ -28,3 +28,9 @@ def test_tick_schedule_fuzz():
     import gpu_scan_fuzz
     bad = gpu_scan_fuzz.run_ticks(6)
     assert not bad, bad[:3]
+
+
+def test_f64_and_group_fuzz():
+    import gpu_scan_fuzz
+    bad = gpu_scan_fuzz.run_f64_and_groups(40)
+    assert not bad, bad[:3]
