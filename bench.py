@@ -26,6 +26,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -403,6 +404,7 @@ def main():
                          shard_count=1 if replicated else world, storage=storage)
     det = None
     exchange = "none"
+    abandon_process = False
     if (world > 1 and not replicated) or args.force_sharded:
         if args.host_exchange:
             if dist is None:
@@ -418,21 +420,52 @@ def main():
             uid = [capi.comm_unique_id() if rank == 0 else None]
             if dist is not None:
                 dist.broadcast_object_list(uid, src=0)
-            ok = 1
-            try:
-                if os.environ.get("BENCH_FAIL_COMM_INIT"):   # test hook: exercise the agreed fallback below
-                    raise capi.ChipError(capi.CHIP_ERR_COMM, "chip_comm_init_rank", "BENCH_FAIL_COMM_INIT")
-                with c_stdout_to_stderr():
+            # The attach is a blocking RCCL bootstrap: it runs on a helper thread with a deadline, so that a rank stuck in it
+            # (a node whose RCCL bootstrap network is unusable) costs the benchmark its exchange, not the whole run.
+            attach = {}
+
+            def attach_comm():
+                try:
+                    if os.environ.get("BENCH_FAIL_COMM_INIT"):   # test hooks: exercise the agreed fallbacks below
+                        raise capi.ChipError(capi.CHIP_ERR_COMM, "chip_comm_init_rank", "BENCH_FAIL_COMM_INIT")
+                    if os.environ.get("BENCH_HANG_COMM_INIT"):
+                        time.sleep(1e6)
                     chip.comm_init_rank(uid[0], world, rank)
-            except capi.ChipError as e:   # e.g. RCCL refusing the topology: every rank must learn of it and take the same path
-                sys.stderr.write(f"[bench rank {rank}] chip_comm_init_rank failed: {e}\n")
-                ok = 0
-            if dist is not None:
-                flag = torch.tensor([ok], dtype=torch.int32)
+                    attach["ok"] = True
+                except capi.ChipError as e:   # e.g. RCCL refusing the topology
+                    attach["err"] = e
+
+            with c_stdout_to_stderr():
+                th = threading.Thread(target=attach_comm, daemon=True)
+                th.start()
+                th.join(float(os.environ.get("BENCH_COMM_INIT_TIMEOUT", "180")))
+            comm_hung = th.is_alive()
+            ok = 1 if attach.get("ok") else 0
+            if comm_hung:
+                sys.stderr.write(f"[bench rank {rank}] chip_comm_init_rank did not return within its deadline\n")
+            elif not ok:
+                sys.stderr.write(f"[bench rank {rank}] chip_comm_init_rank failed: {attach.get('err')}\n")
+            if dist is not None:   # every rank must learn of it and take the same path
+                flag = torch.tensor([ok, 0 if comm_hung else 1], dtype=torch.int32)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = int(flag.item())
+                ok, comm_hung = int(flag[0].item()), int(flag[1].item()) == 0
             if ok:
                 exchange = "in-library RCCL: ncclAllGather of 3 x top-k (score, index) per rank per tick, enqueued in-stream"
+            elif comm_hung:
+                # an RCCL bootstrap that hangs would hang torch.distributed's nccl group as well: exchange over the control
+                # plane that demonstrably works.  The stuck ctx is abandoned (its attach is still running), the process leaves
+                # through os._exit after the JSON line.
+                sys.stderr.write(f"[bench rank {rank}] falling back to the host-driven exchange over {dist.get_backend() if dist else 'nccl'}\n")
+                abandon_process = True
+                chip = capi.Chip(D, capacity_hint=total_rows, device=local_rank, shard_rank=rank, shard_count=world, storage=storage)
+                from cerebro_amd.sharded import ShardedLoopDetector
+                if dist is None:
+                    import torch.distributed as dist
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+                    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+                    dist.init_process_group("gloo")
+                det = ShardedLoopDetector(chip, topk=TOPK, device=torch.device("cuda", local_rank))
+                exchange = f"host-driven fallback: torch.distributed all_gather_into_tensor ({dist.get_backend()}) after chip_comm_init_rank hung"
             else:
                 # agreed fallback: the host-driven exchange over a torch.distributed RCCL group (the ctx of a rank whose attach
                 # did succeed is rebuilt, so that every rank runs the same code path)
@@ -599,6 +632,11 @@ def main():
 
     # whatever C stdio output is still buffered in this process (RCCL banners of torch's own communicator, ...) leaves through
     # stderr: stdout has carried the JSON line and must carry nothing after it
+    if abandon_process:   # a helper thread is still inside RCCL's bootstrap: no orderly teardown is possible
+        if dist is not None:
+            dist.barrier()
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
     with c_stdout_to_stderr():
         if det is not None:
             det.close()

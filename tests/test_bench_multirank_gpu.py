@@ -63,6 +63,14 @@ def test_bench_force_sharded_uses_in_library_rccl():
     finally:
         del os.environ["BENCH_FAIL_COMM_INIT"]
     assert "host-driven fallback" in j["config"]["exchange"] and j["value"] > 0
+    # ... and when the attach never returns (an RCCL bootstrap that hangs): deadline, exchange over the control plane, clean exit
+    os.environ["BENCH_HANG_COMM_INIT"] = "1"
+    os.environ["BENCH_COMM_INIT_TIMEOUT"] = "2"
+    try:
+        j = _run_single(["--force-sharded", "--rows", "60000"])
+    finally:
+        del os.environ["BENCH_HANG_COMM_INIT"], os.environ["BENCH_COMM_INIT_TIMEOUT"]
+    assert "hung" in j["config"]["exchange"] and "gloo" in j["config"]["exchange"] and j["value"] > 0
 
 
 def test_bench_sizes_key_and_f64_storage():
