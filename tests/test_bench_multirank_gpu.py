@@ -16,12 +16,14 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-@pytest.mark.parametrize("n,extra", [(2, ["--host-exchange"]), (3, ["--replicated"])])
-def test_bench_under_torchrun(n, extra):
+@pytest.mark.parametrize("n,extra,hook", [(2, ["--host-exchange"], {}), (3, ["--replicated"], {}),
+                                          # the in-library attach "hangs" on every rank: deadline -> exchange over gloo, exit code 0
+                                          (2, [], {"BENCH_HANG_COMM_INIT": "1", "BENCH_COMM_INIT_TIMEOUT": "2"})])
+def test_bench_under_torchrun(n, extra, hook):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, BENCH_DIST_BACKEND="gloo")
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", **hook)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", str(n), "--steps", "24", "--warmup", "4", "--rows", "60000"] + extra
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -34,6 +36,8 @@ def test_bench_under_torchrun(n, extra):
         assert key in j, key
     assert j["n_gpus"] == n and j["steps"] == 24 and j["value"] > 0
     assert j["scaling"] == ("weak" if "--replicated" in extra else "strong")
+    if hook:
+        assert "hung" in j["config"]["exchange"]
     assert "cpu_baseline" not in j and "pnp" not in j          # rank 0 at N = 1 only
 
 
