@@ -39,6 +39,8 @@ D = 4096
 LAG = 50
 TOPK = 8
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
+READ_CEILING_GBS = 7090.0  # best PURE-READ kernel in the scan's own access shape and occupancy (scripts/probes/hbm_read_probe.hip,
+#                            profiles/r02_hbm_read_probe.txt; 7140 in any shape) -- context for roofline.frac, never its denominator
 SEED = 20190412
 
 
