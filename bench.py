@@ -605,7 +605,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "db_scan_topk", "avg_kernel_ms": avg_s * 1e3, "launches": n_launch,
                          "measured": "hipEvents around each launch on the kernel's stream, separate pass of the same ticks",
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "pure_read_ceiling": {"value": READ_CEILING_GBS, "unit": "GB/s", "frac_of_it": achieved / READ_CEILING_GBS,
+                                               "source": "profiles/r02_hbm_read_probe.txt: do-nothing reader in the scan's access shape, another box of the pool"}},
         }
         if size_plans:
             out["sizes"] = {fmt_rows(r): size_leg(chip, r, plan, params, args.inflight) for r, plan in sorted(size_plans.items())}
