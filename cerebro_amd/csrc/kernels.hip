@@ -73,6 +73,19 @@ __device__ __forceinline__ void rows_dot(const T *const (&row)[R], const T *qs, 
         for (int q = 0; q < NQ; q++) acc[rr][q] = 0.0;
     for (int base = 0; base < D; base += CH * U) {
         V v[R][U];
+        if constexpr (NT == 6) {
+            // all R*U loads of the batch issued back to back from one address register pair (immediate offsets), consumed
+            // below behind COUNTED waits: hipcc's scheduler otherwise sinks the loads next to their uses (register pressure)
+            // and the wave runs with 1-2 KiB in flight instead of U KiB
+            static_assert(FULL && U <= 8, "asm path: whole batches only");
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) {
+                const char *mid = reinterpret_cast<const char *>(row[rr] + base + e0) + 4096;
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(v[rr][u]) : "v"(mid), "n"(u * 1024 - 4096) : "memory");
+            }
+        } else {
 #pragma unroll
         for (int rr = 0; rr < R; rr++) {
 #pragma unroll
@@ -81,7 +94,8 @@ __device__ __forceinline__ void rows_dot(const T *const (&row)[R], const T *qs, 
                 if (FULL || e < D) v[rr][u] = stream_load<NT>(reinterpret_cast<const V *>(row[rr] + e));
             }
         }
-        if constexpr (NT >= 2) {   // inline-asm loads: the compiler does not track them
+        }
+        if constexpr (NT >= 2 && NT != 6) {   // inline-asm loads: the compiler does not track them
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int rr = 0; rr < R; rr++)
@@ -91,6 +105,11 @@ __device__ __forceinline__ void rows_dot(const T *const (&row)[R], const T *qs, 
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int e = base + u * CH + e0;
+            if constexpr (NT == 6) {
+#pragma unroll
+                for (int rr = 0; rr < R; rr++)   // loads return in order: load (rr, u) is done once at most this many are outstanding
+                    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[rr][u]) : "n"((R - 1 - rr) * U + (U - 1 - u) < 63 ? (R - 1 - rr) * U + (U - 1 - u) : 63) : "memory");
+            }
             if (FULL || e < D) {
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
@@ -153,21 +172,36 @@ __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
 #pragma unroll
     for (int q = 0; q < NQ; q++) { my_s[q] = -INFINITY; my_i[q] = -1; thr_s[q] = -INFINITY; thr_i[q] = -1; }
 
-    const int64_t tw = (int64_t)gridDim.x * wpb;
-    // each wave owns rows w, w+tw, ... ; R of them are in flight together (R independent accumulator sets)
-    for (int64_t r0 = (int64_t)blockIdx.x * wpb + wave; r0 < a.n_rows; r0 += tw * R) {
+    // Row -> wave map: the DB prefix is cut into chunks of C consecutive rows.  Every wave starts on chunk g (its global wave
+    // index) and then takes the next unclaimed chunk from a device-wide counter (one relaxed atomic per chunk, fetched while
+    // the current chunk is being scanned, so its latency is never waited for).  All waves together still read ONE window of
+    // ~tw*C consecutive rows that slides through the DB -- the access pattern that measured best -- but a wave that gets less
+    // bandwidth (waves drift apart by a few % over a long scan: XCDs are not equidistant from the HBM stacks) simply claims
+    // fewer chunks, so all waves run dry within one chunk time of each other instead of a tail of 2.6 % of the launch.
+    // a.sched == nullptr (or chunk_rows == 0) selects the static map: chunks g, g+tw, g+2tw, ...
+    // The result does not depend on the map: each row's dot product is computed by one wave in the fixed lane order, and the
+    // top-K under a total order is the same set whatever the partition.
+    const int64_t tw = (int64_t)gridDim.x * wpb, gw = (int64_t)blockIdx.x * wpb + wave;
+    const int C = a.chunk_rows > 0 && a.sched ? a.chunk_rows : 1;
+    const bool dynamic = a.chunk_rows > 0 && a.sched;
+    const int64_t n_chunks = (a.n_rows + C - 1) / C;
+    for (int64_t chunk = gw; chunk < n_chunks;) {
+        unsigned claimed = 0;
+        if (dynamic && lane == 0) claimed = __hip_atomic_fetch_add(a.sched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t c_first = chunk * C, c_end = c_first + C < a.n_rows ? c_first + C : a.n_rows;
+    for (int64_t r0 = c_first; r0 < c_end; r0 += R) {
         const T *row[R];
         double acc[R][NQ];
 #pragma unroll
         for (int rr = 0; rr < R; rr++) {
-            const int64_t r = r0 + rr * tw;
-            row[rr] = row_base<T>(a, r < a.n_rows ? r : r0);   // clamp (result of a clamped row is discarded)
+            const int64_t r = r0 + rr;
+            row[rr] = row_base<T>(a, r < c_end ? r : r0);   // clamp (result of a clamped row is discarded)
         }
         rows_dot<T, NQ, U, FULL, NT, R>(row, qs, D, lane, acc);
 #pragma unroll
         for (int rr = 0; rr < R; rr++) {
-            const int64_t r = r0 + rr * tw;
-            if (r >= a.n_rows) break;   // wave-uniform
+            const int64_t r = r0 + rr;
+            if (r >= c_end) break;   // wave-uniform
 #pragma unroll
             for (int q = 0; q < NQ; q++) acc[rr][q] = butterfly_sum(acc[rr][q]);
             const int64_t gi = r * a.idx_mul + a.idx_add;
@@ -190,9 +224,18 @@ __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
             }
         }
     }
+        chunk = dynamic ? tw + (int64_t)__builtin_amdgcn_readfirstlane(claimed) : chunk + tw;
+    }
 
     // ---- block merge: wpb sorted lists of K per query -> one sorted list of K, by waves 0..NQ-1 ----
     __syncthreads();  // all waves done with qs; reuse LDS
+    if (dynamic && tid == 0) {   // the last workgroup to get here leaves both counters at zero for the next launch on this slot
+        const unsigned done = __hip_atomic_fetch_add(a.sched + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(a.sched, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.sched + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     chip_topk_entry *cand = reinterpret_cast<chip_topk_entry *>(smem);  // [wpb][NQ][K]
     if (lane < K) {
 #pragma unroll
@@ -255,25 +298,29 @@ static int launch_scan_t(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, siz
                                              : launch_scan_k<T, NQ, U, false, NT, R>(c, s, a, grid, lds, block);
 }
 
-// scan_variant (CHIP_SCAN_VARIANT, tuning/A-B only): 0 = production (U=8, non-temporal loads, 1 row in flight per wave)
+// Load path of K1.  Production (scan_variant 0): 4 x 16-B non-temporal loads per lane issued back to back from inline asm and
+// consumed behind counted waits (rows_dot, NT == 6) -- with compiler-scheduled loads (variant 1, the round-1 kernel: U = 8
+// builtin loads) hipcc sinks each load next to its use and a wave runs with 1-2 KiB in flight at 110 VGPRs; the asm form
+// keeps 4 KiB per wave in flight at 66 VGPRs (short scans +5-7 %, 1M rows equal: profiles/r02_scan_load_path.txt).  Rows
+// whose length is not a whole number of 4-load batches (D * elem % 4096 != 0) take the builtin path.
+// CHIP_SCAN_VARIANT >= 2: further A/B variants, only in builds with -DCHIP_SCAN_TUNING_VARIANTS.
 template <typename T, int NQ>
 static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds, int block)
 {
 #ifdef CHIP_SCAN_TUNING_VARIANTS
     switch (c->scan_variant) {
-        case 1: return launch_scan_t<T, NQ, 4, 1, 1>(c, s, a, grid, lds, block);
         case 2: return launch_scan_t<T, NQ, 16, 1, 1>(c, s, a, grid, lds, block);
         case 3: return launch_scan_t<T, NQ, 8, 0, 1>(c, s, a, grid, lds, block);
-        case 4: return launch_scan_t<T, NQ, 4, 1, 2>(c, s, a, grid, lds, block);
-        case 5: return launch_scan_t<T, NQ, 8, 1, 2>(c, s, a, grid, lds, block);
-        case 6: return launch_scan_t<T, NQ, 4, 0, 2>(c, s, a, grid, lds, block);
+        case 4: return launch_scan_t<T, NQ, 4, 1, 1>(c, s, a, grid, lds, block);
         case 7: return launch_scan_t<T, NQ, 8, 2, 1>(c, s, a, grid, lds, block);
         case 8: return launch_scan_t<T, NQ, 8, 3, 1>(c, s, a, grid, lds, block);
         case 9: return launch_scan_t<T, NQ, 8, 4, 1>(c, s, a, grid, lds, block);
         case 10: return launch_scan_t<T, NQ, 8, 5, 1>(c, s, a, grid, lds, block);
+        case 11: if ((int64_t)a.D * sizeof(T) % 8192 == 0) return launch_scan_k<T, NQ, 8, true, 6, 1>(c, s, a, grid, lds, block); break;
         default: break;
     }
 #endif
+    if (c->scan_variant != 1 && (int64_t)a.D * sizeof(T) % 4096 == 0) return launch_scan_k<T, NQ, 4, true, 6, 1>(c, s, a, grid, lds, block);
     return launch_scan_t<T, NQ, 8, 1, 1>(c, s, a, grid, lds, block);
 }
 
