@@ -142,7 +142,6 @@ void ctx_destroy(chip_ctx *c)
     batch_destroy(c);
     for (void *p : c->segs) (void)hipFree(p);
     if (c->seg_table_dev) (void)hipFree(c->seg_table_dev);
-    if (c->sched_dev) (void)hipFree(c->sched_dev);
     if (c->ring_dev) (void)hipFree(c->ring_dev);
     if (c->stage_dev) (void)hipFree(c->stage_dev);
     if (c->flags_dev) (void)hipFree(c->flags_dev);
@@ -197,9 +196,6 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     c->scan_blocks_per_cu = env_int("CHIP_SCAN_BPC", 2);
     if (c->scan_blocks_per_cu < 1) c->scan_blocks_per_cu = 1;
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);
-    c->scan_chunk = env_int("CHIP_SCAN_CHUNK", 0);
-    CHIP_HIP(c, hipMalloc(&c->sched_dev, (size_t)Ctx::kRing * Ctx::kSchedStride * sizeof(uint32_t)));
-    CHIP_HIP(c, hipMemset(c->sched_dev, 0, (size_t)Ctx::kRing * Ctx::kSchedStride * sizeof(uint32_t)));
     // a sharded ctx gets three small kernels per tick through its ctx stream underneath the scans: keep slots free for them
     c->scan_reserve = env_int("CHIP_SCAN_RESERVE", c->nranks > 1 ? 4 : 0);
     c->max_grid = 512;  // K2 (one 512-thread workgroup) keeps one partial list per thread
@@ -290,8 +286,6 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
     a.idx_mul = c->nranks;
     a.idx_add = c->nranks == 1 ? 0 : c->rank;
     a.partial = c->partial_dev[b];
-    a.sched = c->sched_dev + (size_t)b * Ctx::kSchedStride;
-    a.chunk_rows = c->scan_chunk;
     const int grid = scan_grid_for(c, a.n_rows, nq);
 
     // The merge that last read this buffer ran kRing ticks ago; only when it is not already complete (a stalled ctx

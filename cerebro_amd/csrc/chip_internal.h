@@ -25,8 +25,6 @@ struct ScanArgs {
     const void *q[CHIP_MAX_NQ];     // query descriptors (device, storage type, D each, 16-B aligned)
     int64_t idx_mul, idx_add;       // global index = local * idx_mul + idx_add  (round-robin shard map)
     chip_topk_entry *partial;       // [gridDim.x][NQ][K]
-    uint32_t *sched = nullptr;      // db_scan_topk's chunk counter [0] and finished-workgroup counter [1] (zero between launches)
-    int32_t chunk_rows = 0;         // rows per claimed chunk; 0 = static round-robin map
 };
 
 struct MergeArgs {
@@ -141,9 +139,6 @@ struct Ctx {
     int32_t scan_blocks_per_cu = 2;
     int32_t scan_reserve = 0;
     int32_t scan_variant = 0;
-    int32_t scan_chunk = 0;                     // rows per dynamically claimed chunk of db_scan_topk (0 = static map)
-    uint32_t *sched_dev = nullptr;              // [kRing][kSchedStride] chunk / finished-workgroup counters, zero between launches
-    static constexpr int kSchedStride = 64;     // one 256-B line per ring slot
 
     // --- profiling ---
     bool prof_on = false;

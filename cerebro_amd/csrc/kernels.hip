@@ -153,6 +153,7 @@ __device__ __forceinline__ const T *row_base(const ScanArgs &a, int64_t r)
 template <typename T, int NQ, int U, bool FULL, int NT, int R>
 __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
 {
+    static_assert(R == 1, "one row per wave at a time");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T *qs = reinterpret_cast<T *>(smem);  // [NQ][D]
     const int D = a.D;
@@ -172,70 +173,41 @@ __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
 #pragma unroll
     for (int q = 0; q < NQ; q++) { my_s[q] = -INFINITY; my_i[q] = -1; thr_s[q] = -INFINITY; thr_i[q] = -1; }
 
-    // Row -> wave map: the DB prefix is cut into chunks of C consecutive rows.  Every wave starts on chunk g (its global wave
-    // index) and then takes the next unclaimed chunk from a device-wide counter (one relaxed atomic per chunk, fetched while
-    // the current chunk is being scanned, so its latency is never waited for).  All waves together still read ONE window of
-    // ~tw*C consecutive rows that slides through the DB -- the access pattern that measured best -- but a wave that gets less
-    // bandwidth (waves drift apart by a few % over a long scan: XCDs are not equidistant from the HBM stacks) simply claims
-    // fewer chunks, so all waves run dry within one chunk time of each other instead of a tail of 2.6 % of the launch.
-    // a.sched == nullptr (or chunk_rows == 0) selects the static map: chunks g, g+tw, g+2tw, ...
-    // The result does not depend on the map: each row's dot product is computed by one wave in the fixed lane order, and the
-    // top-K under a total order is the same set whatever the partition.
-    const int64_t tw = (int64_t)gridDim.x * wpb, gw = (int64_t)blockIdx.x * wpb + wave;
-    const int C = a.chunk_rows > 0 && a.sched ? a.chunk_rows : 1;
-    const bool dynamic = a.chunk_rows > 0 && a.sched;
-    const int64_t n_chunks = (a.n_rows + C - 1) / C;
-    for (int64_t chunk = gw; chunk < n_chunks;) {
-        unsigned claimed = 0;
-        if (dynamic && lane == 0) claimed = __hip_atomic_fetch_add(a.sched, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int64_t c_first = chunk * C, c_end = c_first + C < a.n_rows ? c_first + C : a.n_rows;
-    for (int64_t r0 = c_first; r0 < c_end; r0 += R) {
-        const T *row[R];
-        double acc[R][NQ];
+    // Row -> wave map: wave g (global index) owns rows g, g + tw, g + 2 tw, ... -- adjacent waves read adjacent rows and all
+    // waves together read ONE window of tw consecutive rows that slides through the DB.  Measured alternatives, all slower or
+    // not worth their machinery: a contiguous run of rows per wave / per workgroup / per XCD (-3 .. -6 %);
+    // chunks claimed from a device-wide counter so that the XCDs that get less HBM bandwidth claim fewer (same-address atomics
+    // sustain ~85 M/s and VMEM returns in order, so the claiming wave's row loads wait for its atomic: -2 %); a static 3-5 %
+    // skew of the row share between even and odd XCDs (+0.5 .. +1.9 % depending on the box).
+    const int64_t tw = (int64_t)gridDim.x * wpb;
+    for (int64_t r = (int64_t)blockIdx.x * wpb + wave; r < a.n_rows; r += tw) {
+        const T *row[1] = {row_base<T>(a, r)};
+        double acc[1][NQ];
+        rows_dot<T, NQ, U, FULL, NT, 1>(row, qs, D, lane, acc);
 #pragma unroll
-        for (int rr = 0; rr < R; rr++) {
-            const int64_t r = r0 + rr;
-            row[rr] = row_base<T>(a, r < c_end ? r : r0);   // clamp (result of a clamped row is discarded)
-        }
-        rows_dot<T, NQ, U, FULL, NT, R>(row, qs, D, lane, acc);
+        for (int q = 0; q < NQ; q++) acc[0][q] = butterfly_sum(acc[0][q]);
+        const int64_t gi = r * a.idx_mul + a.idx_add;
 #pragma unroll
-        for (int rr = 0; rr < R; rr++) {
-            const int64_t r = r0 + rr;
-            if (r >= c_end) break;   // wave-uniform
-#pragma unroll
-            for (int q = 0; q < NQ; q++) acc[rr][q] = butterfly_sum(acc[rr][q]);
-            const int64_t gi = r * a.idx_mul + a.idx_add;
-#pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                const double s = acc[rr][q];
-                if (key_gt(s, gi, thr_s[q], thr_i[q])) {  // wave-uniform, rare after warm-up; NaN never enters
-                    const bool worse = key_gt(s, gi, my_s[q], my_i[q]);
-                    const unsigned long long m = __ballot(worse) & ((1ull << K) - 1ull);
-                    const int pos = __builtin_ctzll(m);
-                    const double up_s = __shfl_up(my_s[q], 1, 64);
-                    const int64_t up_i = __shfl_up(my_i[q], 1, 64);
-                    if (lane < K) {
-                        if (lane > pos) { my_s[q] = up_s; my_i[q] = up_i; }
-                        else if (lane == pos) { my_s[q] = s; my_i[q] = gi; }
-                    }
-                    thr_s[q] = __shfl(my_s[q], K - 1, 64);
-                    thr_i[q] = __shfl(my_i[q], K - 1, 64);
+        for (int q = 0; q < NQ; q++) {
+            const double s = acc[0][q];
+            if (key_gt(s, gi, thr_s[q], thr_i[q])) {  // wave-uniform, rare after warm-up; NaN never enters
+                const bool worse = key_gt(s, gi, my_s[q], my_i[q]);
+                const unsigned long long m = __ballot(worse) & ((1ull << K) - 1ull);
+                const int pos = __builtin_ctzll(m);
+                const double up_s = __shfl_up(my_s[q], 1, 64);
+                const int64_t up_i = __shfl_up(my_i[q], 1, 64);
+                if (lane < K) {
+                    if (lane > pos) { my_s[q] = up_s; my_i[q] = up_i; }
+                    else if (lane == pos) { my_s[q] = s; my_i[q] = gi; }
                 }
+                thr_s[q] = __shfl(my_s[q], K - 1, 64);
+                thr_i[q] = __shfl(my_i[q], K - 1, 64);
             }
         }
-    }
-        chunk = dynamic ? tw + (int64_t)__builtin_amdgcn_readfirstlane(claimed) : chunk + tw;
     }
 
     // ---- block merge: wpb sorted lists of K per query -> one sorted list of K, by waves 0..NQ-1 ----
     __syncthreads();  // all waves done with qs; reuse LDS
-    if (dynamic && tid == 0) {   // the last workgroup to get here leaves both counters at zero for the next launch on this slot
-        const unsigned done = __hip_atomic_fetch_add(a.sched + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == gridDim.x - 1) {
-            __hip_atomic_store(a.sched, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.sched + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     chip_topk_entry *cand = reinterpret_cast<chip_topk_entry *>(smem);  // [wpb][NQ][K]
     if (lane < K) {
 #pragma unroll
