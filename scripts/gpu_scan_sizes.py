@@ -1,4 +1,7 @@
-"""SCRATCH: K1 timing at several sizes for the current env (one process per configuration)."""
+"""Pipelined tick rate of db_scan_topk at 1M / 500k / 125k / 100k / 10k rows for the CURRENT environment (CHIP_SCAN_* knobs,
+CHIP_LIB=<path> to time another build of the library) -- run ONE process per configuration: contexts created later in a process
+share hardware queues with the earlier ones and time slower.  Prints a checksum of a few query results so that A/B variants
+can be seen to agree.  Used for profiles/r02_scan_load_path.txt."""
 import os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
