@@ -196,6 +196,7 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     c->scan_blocks_per_cu = env_int("CHIP_SCAN_BPC", 2);
     if (c->scan_blocks_per_cu < 1) c->scan_blocks_per_cu = 1;
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);
+    c->scan_overlap_bytes = (double)env_int("CHIP_SCAN_OVERLAP_GIB", 8) * 1024 * 1024 * 1024;
     // a sharded ctx gets three small kernels per tick through its ctx stream underneath the scans: keep slots free for them
     c->scan_reserve = env_int("CHIP_SCAN_RESERVE", c->nranks > 1 ? 4 : 0);
     c->max_grid = 512;  // K2 (one 512-thread workgroup) keeps one partial list per thread
@@ -273,7 +274,7 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
     // 125k 317 -> 308, 500k 1191 -> 1157; at 1M the gain is < 1 %, and launches that overlap would no longer have a
     // meaningful per-launch duration for the roofline, so long scans and profiled runs stay on one stream).  Anything that
     // uploads its queries on s_scan first stays on s_scan.
-    const bool short_scan = (double)local_count(c, k) * c->D * c->elem <= 8.0 * 1024 * 1024 * 1024;
+    const bool short_scan = (double)local_count(c, k) * c->D * c->elem <= c->scan_overlap_bytes;
     hipStream_t s_scan = (tick && short_scan && !c->prof_on && c->s_scan2 && (c->n_enqueued & 1)) ? c->s_scan2 : c->s_scan;
     ScanArgs a;
     a.seg_table = c->seg_table_dev;

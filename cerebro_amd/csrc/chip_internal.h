@@ -139,6 +139,7 @@ struct Ctx {
     int32_t scan_blocks_per_cu = 2;
     int32_t scan_reserve = 0;
     int32_t scan_variant = 0;
+    double scan_overlap_bytes = 8.0 * 1024 * 1024 * 1024;   // launches up to this size alternate between the two scan streams (CHIP_SCAN_OVERLAP_GIB)
 
     // --- profiling ---
     bool prof_on = false;
