@@ -10,7 +10,7 @@ def run(n=120, seed=11):
     rng = np.random.default_rng(seed)
     bad = []
     for it in range(n):
-        D = int(rng.choice([4, 8, 60, 252, 256, 260, 1000, 1024, 2048, 4096, 4100, 8192]))
+        D = int(rng.choice([4, 8, 60, 252, 256, 260, 1000, 1024, 2048, 3072, 4096, 4100, 5120, 8192]))   # multiples of 1024: the asm load path
         N = int(rng.integers(1, 3000)) if D <= 4096 else int(rng.integers(1, 600))
         kind = it % 4
         if kind == 0: db = rng.standard_normal((N, D)).astype(np.float32)
@@ -108,7 +108,7 @@ def run_f64_and_groups(n=40, seed=23):
     for it in range(n):
         f64 = it % 2 == 0
         G = int(rng.choice([0, 0, 1, 2, 3, 5, 8]))                     # 0 = plain ctx
-        D = int(rng.choice([4, 60, 252, 256, 1000, 1024, 4096] + ([6824] if f64 else [8192])))
+        D = int(rng.choice([4, 60, 252, 256, 512, 1000, 1024, 1536, 4096] + ([6824] if f64 else [3072, 8192])))   # whole 4-KiB batches (asm loads) and ragged rows
         N = int(rng.integers(60, 1500)) if D <= 4096 else int(rng.integers(60, 300))
         kind = it % 4
         if kind == 0: db = rng.standard_normal((N, D))
