@@ -321,12 +321,13 @@ int scan_grid_for(const Ctx *c, int64_t n_rows, int nq)
     scan_shape(c, nq, &block, &bpc);
     const int wpb = block / 64;
     int64_t want = (n_rows + wpb - 1) / wpb;
-    // scan_reserve leaves workgroup slots free for the small kernels: a full grid holds every CU's registers (2 x 8 waves x
-    // 110 VGPRs), so a merge (or the RCCL all-gather kernel) launched underneath a running scan waits for a scan workgroup to
-    // retire -- and grid-stride workgroups retire only at the END of the scan.  Reserving 4 slots cuts the merge's wait from
-    // ~1.7 ms to ~30 us at 1M rows for -0.15 % throughput.  Default: 0 on a plain ctx (throughput is the headline and a lone
-    // synchronous tick has nothing running underneath it), 4 on a sharded ctx, whose ctx stream must get local merge ->
-    // all-gather -> global merge through under every scan.  CHIP_SCAN_RESERVE overrides.
+    // scan_reserve leaves workgroup slots free for the small kernels.  With the round-1 load path a full grid held every
+    // CU's registers (2 x 8 waves x 110 VGPRs), so a merge (or the RCCL all-gather kernel) launched underneath a running scan
+    // waited for a scan workgroup to retire -- and grid-stride workgroups retire only at the END of the scan: reserving 4 slots
+    // cut the merge's wait from ~1.7 ms to ~30 us at 1M rows.  At 66 VGPRs and 96 of 160 KiB LDS per CU our own merges fit
+    // next to a full grid (reserve 0 and 4 measure the same at 125k rows); the reserve stays on where an exchange is attached
+    // because the collective's kernel is not ours to size.  Default: 0 on a plain ctx, 4 on a sharded ctx / group
+    // sub-context.  CHIP_SCAN_RESERVE overrides.
     int64_t cap = (int64_t)c->n_cus * bpc - c->scan_reserve;
     if (cap > c->max_grid) cap = c->max_grid;
     if (want > cap) want = cap;
