@@ -28,6 +28,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128;
 constexpr int CT_LD = BN + 1;   // score tile in LDS [128][129]
+// DB tile of one stage in LDS: 16 blocks of 8 rows x 32 floats (one LDS-DMA instruction each: 1 KiB, lane-linear), block b
+// placed at b * kBBlock + (b & 3) floats -- rotated by 0..3 floats, which the LDS-DMA honours (its destination base only needs
+// 4-byte alignment: scripts/probes/glds_align_probe.hip) -- 4 floats of padding per block keep the rotated blocks apart.
+constexpr int kBBlock = 8 * 32 + 4;
+constexpr int kBTile = 16 * kBBlock;
+__device__ __forceinline__ constexpr int b_row_off(int row) { return (row >> 3) * kBBlock + ((row >> 3) & 3) + (row & 7) * 32; }
 
 struct BatchArgs {
     const float *const *seg_table;
@@ -81,12 +87,14 @@ __device__ __forceinline__ void list_push(TopList &L, int K, float s, int32_t ro
 //                  (Qt[qtile][chunk][k 0..31][row 0..127], written once per call by transpose_queries), so the DMA is a linear
 //                  16 KiB copy per chunk and lane (fr, fk) reads A[R + fr][2 kk + fk] at float (2 kk + fk) * 128 + R + fr:
 //                  32 consecutive floats per half-wave -- conflict-free ds_read_b32, two k-steps per ds_read2st64_b32.
-//   B (DB rows)  : row-major in global memory (fixed), [128 rows][8 slots of 16 B] per stage, unpadded (the DMA destination
-//                  is lane-linear), slots XOR-swizzled on both sides (slot p of row r holds floats [4 k4, 4 k4 + 4) with
-//                  k4 = p ^ ((r >> 1) & 7): the loader picks its SOURCE address accordingly).  Lane (fr, fk) reads floats
-//                  [fk] and [2 + fk] of its row's slot with ONE ds_read2_b32 -- a column read over unpadded 128-B rows is
-//                  inherently 4-way bank-conflicted (32 rows share 8 slots), which costs LDS cycles that are idle anyway
-//                  (16 such reads per wave per 64 MFMAs) instead of issue slots, which are not.
+//   B (DB rows)  : row-major in global memory (fixed): per stage 16 blocks of [8 rows][8 slots of 16 B], one LDS-DMA
+//                  instruction each (the destination is lane-linear), slots XOR-swizzled on both sides (slot p of row r holds
+//                  floats [4 k4, 4 k4 + 4) with k4 = p ^ (r & 7): the loader picks its SOURCE address accordingly) and block
+//                  b ROTATED by b & 3 floats (b_row_off).  Lane (fr, fk) reads floats [fk] and [2 + fk] of its row's slot with
+//                  ONE ds_read2_b32; the 32 rows of a half-wave are 4 blocks x 8 rows = 4 rotations x 8 swizzled slots = 32
+//                  distinct banks.  (Without the rotation a column read over 128-B rows is 4-way bank-conflicted whatever the
+//                  slot swizzle -- 32 rows, 8 slots, one float offset: round 2 ran that way until the probe showed the
+//                  destination base of an LDS-DMA may be any multiple of 4 bytes.)
 // The LDS-DMA is issued from inline asm ON PURPOSE: hipcc tracks the builtin form and, not knowing which stage a load fills,
 // drains ALL of them (s_waitcnt vmcnt(0)) at every barrier.  Untracked, the loads of the next NST-1 chunks stay in flight
 // across barriers and the loop waits with counted s_waitcnt vmcnt(8 (NST-2)): vmcnt retires in order, so "at most n
@@ -130,8 +138,8 @@ template <int KC, int NST>
 __global__ __launch_bounds__(256) void db_gemm_topk(BatchArgs a)
 {
     static_assert(KC == 32, "one K-chunk = 8 slots of 4 floats per DB row");
-    constexpr int TILE = BM * KC;        // floats per operand tile of one stage (16 KiB)
-    constexpr int STAGE = 2 * TILE;      // A tile then B tile
+    constexpr int TILE = BM * KC;        // floats of the A tile of one stage (16 KiB)
+    constexpr int STAGE = TILE + kBTile; // A tile then B tile (16 blocks of 8 rows, kBBlock floats apart)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *S0 = reinterpret_cast<float *>(smem);        // stage s: A = S0 + s*STAGE, B = A + TILE
     float *Ct = reinterpret_cast<float *>(smem);         // [128][CT_LD] (aliases the stages after the K loop)
@@ -155,16 +163,15 @@ __global__ __launch_bounds__(256) void db_gemm_topk(BatchArgs a)
     const int n_chunks = D / KC;
     // A loader: the chunk image is contiguous (16 KiB): wave w, pass u copies bytes [(4 u + w) * 1024, + 1024)
     const float *const a_src = a.Qt + ((int64_t)blockIdx.y * n_chunks) * TILE + (wave * 64 + lane) * 4;
-    // B loader: pass u, wave w, lane i -> row u*32 + w*8 + (i >> 3), slot p = i & 7, source floats [4 k4, 4 k4 + 4), k4 = p ^ ((row >> 1) & 7)
+    // B loader: pass u, wave w, lane i -> row u*32 + w*8 + (i >> 3) (= row i >> 3 of 8-row block 4 u + w), slot p = i & 7,
+    // source floats [4 k4, 4 k4 + 4), k4 = p ^ (row & 7)
     const int l_row = wave * 8 + (lane >> 3), l_p = lane & 7;
-    int l_k4[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) l_k4[u] = (l_p ^ (((u * 32 + l_row) >> 1) & 7)) * 4;
+    const int l_k4 = (l_p ^ (lane >> 3)) * 4;
     // fragment map
     const int fr = lane & 31, fk = lane >> 5;
     const int a_off = fk * 128 + wm * 64 + fr;                        // + (2 kk) * 128 per k-step, + 32 for the second row block
     const int rb0 = wn * 64 + fr, rb1 = rb0 + 32;
-    const int b_off0 = TILE + rb0 * KC + fk, b_off1 = TILE + rb1 * KC + fk, sw0 = (rb0 >> 1) & 7, sw1 = (rb1 >> 1) & 7;
+    const int b_off0 = TILE + b_row_off(rb0) + fk, b_off1 = TILE + b_row_off(rb1) + fk, sw0 = rb0 & 7, sw1 = rb1 & 7;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr(S0));
 
     for (int64_t n0 = part_lo; n0 < part_hi; n0 += BN) {
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256) void db_gemm_topk(BatchArgs a)
         for (int u = 0; u < 4; u++) {
             const int64_t br = n0 + u * 32 + l_row;
             const int64_t brc = br < a.n_rows ? br : 0;   // rows past the end: any valid row (their columns are never scanned)
-            brow[u] = a.seg_table[brc >> a.seg_shift] + (brc & a.seg_mask) * (int64_t)D + l_k4[u];
+            brow[u] = a.seg_table[brc >> a.seg_shift] + (brc & a.seg_mask) * (int64_t)D + l_k4;
         }
         f32x16 acc[2][2];
 #pragma unroll
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256) void db_gemm_topk(BatchArgs a)
         auto stage_load_one = [&](int c, int j) {
             const uint32_t st = lds_base + (uint32_t)((c % NST) * STAGE) * 4u;
             const int u = j >> 1;
-            if (j & 1) glds16(brow[u] + c * KC, st + (uint32_t)(TILE + (u * 32 + wave * 8) * KC) * 4u);
+            if (j & 1) glds16(brow[u] + c * KC, st + (uint32_t)(TILE + b_row_off(u * 32 + wave * 8)) * 4u);
             else glds16(a_src + (int64_t)c * TILE + u * 1024, st + (uint32_t)((4 * u + wave) * 256) * 4u);
         };
         auto stage_load = [&](int c) {
@@ -411,7 +418,7 @@ extern "C" int chip_query_batch_f32(chip_ctx *c, int64_t k, const float *queries
     a.n_rows = n_rows; a.D = D; a.Q = st->Q; a.Qt = st->Qt; a.Qpad = Qpad; a.K = topk; a.rows_per_part = rows_per_part;
     a.idx_mul = c->nranks; a.idx_add = c->nranks == 1 ? 0 : c->rank; a.partial = st->partial;
     constexpr int KCsel = 32;
-    const size_t lds_gemm = sizeof(float) * (size_t)nst * 2 * BM * KCsel /* stages x (A + B) */, lds_ct = sizeof(float) * BM * CT_LD;
+    const size_t lds_gemm = sizeof(float) * (size_t)nst * (BM * KCsel + kBTile) /* stages x (A + B) */, lds_ct = sizeof(float) * BM * CT_LD;
     const size_t lds = lds_gemm > lds_ct ? lds_gemm : lds_ct;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->prof_on) {
