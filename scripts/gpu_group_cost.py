@@ -70,4 +70,6 @@ for res in ("0", "4"):
 del os.environ["CHIP_SCAN_RESERVE"]
 run("group of one device over RCCL (ncclCommInitAll)", lambda: capi.Chip(D, capacity_hint=ls[-1], devices=[0]))
 run("group of 8 sub-contexts on one device (8 x 15.6k rows each, copy exchange)", lambda: capi.Chip(D, capacity_hint=ls[-1], devices=[0] * 8))
-print(json.dumps(out, indent=1))
+sys.stdout.flush()
+print(json.dumps(out, indent=1), flush=True)
+os.dup2(2, 1)   # whatever C stdio still holds (the RCCL banner) leaves through stderr, not after the JSON
