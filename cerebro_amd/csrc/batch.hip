@@ -26,13 +26,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128;
-constexpr int CT_LD = BN + 1;   // score tile in LDS [128][129]
+constexpr int BM = 128;              // queries are padded to a multiple of the small tile
+constexpr int CT_LD = 128 + 1;      // score tile in LDS [tile queries][129]: 128 DB rows per epilogue pass
 // DB tile of one stage in LDS: 16 blocks of 8 rows x 32 floats (one LDS-DMA instruction each: 1 KiB, lane-linear), block b
 // placed at b * kBBlock + (b & 3) floats -- rotated by 0..3 floats, which the LDS-DMA honours (its destination base only needs
 // 4-byte alignment: scripts/probes/glds_align_probe.hip) -- 4 floats of padding per block keep the rotated blocks apart.
 constexpr int kBBlock = 8 * 32 + 4;
-constexpr int kBTile = 16 * kBBlock;
+constexpr int kMaxQTiles = 4096;    // query tiles per call (grid.y); 4096 x 128 queries
 __device__ __forceinline__ constexpr int b_row_off(int row) { return (row >> 3) * kBBlock + ((row >> 3) & 3) + (row & 7) * 32; }
 
 struct BatchArgs {
@@ -45,28 +45,31 @@ struct BatchArgs {
     const float *Qt;        // the same queries as K-chunk-major transposed tiles: [Qpad/128][D/32][32][128]
     int32_t Qpad;
     int32_t K;
-    int64_t rows_per_part;  // multiple of BN
+    uint32_t *tile_ctr;     // [query tiles] next unclaimed DB tile (zeroed before the launch)
     int64_t idx_mul, idx_add;
     chip_topk_entry *partial;  // [P][Qpad][K]
 };
 
 __device__ __forceinline__ bool fkey_gt(float s, int32_t i, float s2, int32_t i2) { return s > s2 || (s == s2 && i > i2); }
 
-struct TopList {  // sorted (score desc, local row desc); empty slots (-inf, -1)
-    float s[CHIP_MAX_TOPK];
-    int32_t r[CHIP_MAX_TOPK];
+template <int KL>
+struct TopList {  // sorted (score desc, local row desc); empty slots (-inf, -1); KL = capacity (8 or CHIP_MAX_TOPK): the
+    float s[KL];  // lists live in registers across the whole K loop, next to 64..128 accumulator registers
+    int32_t r[KL];
 };
 
-__device__ __forceinline__ void list_init(TopList &L)
+template <int KL>
+__device__ __forceinline__ void list_init(TopList<KL> &L)
 {
 #pragma unroll
-    for (int j = 0; j < CHIP_MAX_TOPK; j++) { L.s[j] = -INFINITY; L.r[j] = -1; }
+    for (int j = 0; j < KL; j++) { L.s[j] = -INFINITY; L.r[j] = -1; }
 }
-__device__ __forceinline__ void list_push(TopList &L, int K, float s, int32_t row)
+template <int KL>
+__device__ __forceinline__ void list_push(TopList<KL> &L, int K, float s, int32_t row)
 {
     // caller checked fkey_gt(s,row, L.s[K-1], L.r[K-1]); static-index insertion (no dynamic register indexing)
 #pragma unroll
-    for (int j = CHIP_MAX_TOPK - 1; j >= 1; j--) {
+    for (int j = KL - 1; j >= 1; j--) {
         if (j < K) {
             const bool above = fkey_gt(s, row, L.s[j - 1], L.r[j - 1]);       // new entry belongs above slot j-1
             const bool here = fkey_gt(s, row, L.s[j], L.r[j]) && !above;       // exactly at slot j
@@ -75,6 +78,15 @@ __device__ __forceinline__ void list_push(TopList &L, int K, float s, int32_t ro
         }
     }
     if (fkey_gt(s, row, L.s[0], L.r[0])) { L.s[0] = s; L.r[0] = row; }
+}
+// the current K-th best of a list (K <= KL, run-time)
+template <int KL>
+__device__ __forceinline__ void list_kth(const TopList<KL> &L, int K, float &ts, int32_t &tr)
+{
+    ts = L.s[0]; tr = L.r[0];
+#pragma unroll
+    for (int j = 1; j < KL; j++)
+        if (j < K) { ts = L.s[j]; tr = L.r[j]; }
 }
 
 // LDS-DMA tile staging (cdna_hip_programming.md 3, rule 21): global_load_lds_dwordx4 copies 16 bytes per lane straight from
@@ -120,71 +132,85 @@ __device__ __forceinline__ void wait_loads_and_barrier(int chunks_in_flight)
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Qt[qtile][chunk][k][row] <- Q[qtile * 128 + row][chunk * KC + k]   (one thread per element; Q is a few MB at most)
-__global__ __launch_bounds__(256) void transpose_queries(const float *__restrict__ Q, float *__restrict__ Qt, int Qpad, int D)
+// Qt[qtile][chunk][k][row] <- Q[qtile * TM + row][chunk * KC + k], TM = rows of a query tile (128 or 256)
+// (one thread per element; Q is a few MB at most)
+__global__ __launch_bounds__(256) void transpose_queries(const float *__restrict__ Q, float *__restrict__ Qt, int Qpad, int D, int tm_shift)
 {
     constexpr int KC = 32;
     const int64_t n = (int64_t)Qpad * D;
+    const int TM = 1 << tm_shift;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int row = (int)(i & 127);
-        const int k = (int)((i >> 7) & (KC - 1));
-        const int64_t t = i >> 12;                       // (qtile, chunk) flattened: chunk fastest
+        const int row = (int)(i & (TM - 1));
+        const int k = (int)((i >> tm_shift) & (KC - 1));
+        const int64_t t = i >> (tm_shift + 5);           // (qtile, chunk) flattened: chunk fastest
         const int chunk = (int)(t % (D / KC)), qt = (int)(t / (D / KC));
-        Qt[i] = Q[(int64_t)(qt * 128 + row) * D + chunk * KC + k];
+        Qt[i] = Q[(int64_t)(qt * TM + row) * D + chunk * KC + k];
     }
 }
 
-template <int KC, int NST>
-__global__ __launch_bounds__(256) void db_gemm_topk(BatchArgs a)
+// WN = waves along the DB rows of a tile (2 or 4); a wave owns WN x 2 MFMA 32x32 blocks (64 WN queries x 64 DB rows), the
+// workgroup tile is 64 WN x 64 WN (128 x 128 with 4 waves, 256 x 256 with 8), 2 x WN waves, 8 LDS-DMA per wave per chunk either way.
+template <int KC, int NST, int WN, int KL>
+__global__ __launch_bounds__(128 * WN) void db_gemm_topk(BatchArgs a)
 {
     static_assert(KC == 32, "one K-chunk = 8 slots of 4 floats per DB row");
-    constexpr int TILE = BM * KC;        // floats of the A tile of one stage (16 KiB)
-    constexpr int STAGE = TILE + kBTile; // A tile then B tile (16 blocks of 8 rows, kBBlock floats apart)
+    static_assert(WN == 2 || WN == 4, "tile 128 x 128 or 256 x 256");
+    constexpr int TM = 64 * WN, TN = 64 * WN;            // tile: queries x DB rows
+    constexpr int NT = 128 * WN, WAVES = 2 * WN;          // threads, waves
+    constexpr int TILE = TM * KC;                         // floats of the A tile of one stage
+    constexpr int BTILE = (TN / 8) * kBBlock;             // DB tile: TN / 8 blocks of 8 rows, kBBlock floats apart
+    constexpr int STAGE = TILE + BTILE;                   // A tile then B tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *S0 = reinterpret_cast<float *>(smem);        // stage s: A = S0 + s*STAGE, B = A + TILE
-    float *Ct = reinterpret_cast<float *>(smem);         // [128][CT_LD] (aliases the stages after the K loop)
+    float *Ct = reinterpret_cast<float *>(smem);         // [TM][CT_LD] (aliases the stages after the K loop)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int D = a.D, K = a.K;
-    const int q0 = blockIdx.y * BM;
-    const int64_t part_lo = (int64_t)blockIdx.x * a.rows_per_part;
-    int64_t part_hi = part_lo + a.rows_per_part;
-    if (part_hi > a.n_rows) part_hi = a.n_rows;
+    const int q0 = blockIdx.y * TM;
+    // DB tiles are handed out dynamically: workgroup x of a query tile starts on DB tile x and then takes the next unclaimed one
+    // from a counter (one atomic per tile, ~1 ms of work; fetched at the start of the tile, read at its end).  With a static
+    // split 3907 tiles over 256 workgroups cost 16 tile times on every CU; claimed tiles cost 15.26.  The lists a workgroup
+    // keeps do not care which tiles fed them: the merged top-K is the same set whatever the assignment.
+    __shared__ unsigned next_tile_slot;
+    const int64_t n_tiles = (a.n_rows + TN - 1) / TN;
 
-    // Top-k of the tile scores: ALL 256 threads take part -- thread t owns query q0 + (t & 127) over the column half (t >> 7)
-    // of every tile, with its sorted list in registers; the two lists of a query are folded into one at the end of the kernel.
+    // Top-k of the tile scores: ALL threads take part -- thread t owns query q0 + (t % TM) over the 64-column half (t / TM)
+    // of every 128-column epilogue pass, with its sorted list in registers; the two lists of a query are folded at the end.
     // (Round 1 had 64 owner threads scan 2 x 128 columns while the other three waves -- and, in lockstep, the other workgroup
     // of the CU -- waited.)
-    const int oq = tid & 127, och = tid >> 7;
-    TopList L;
+    const int oq = tid & (TM - 1), och = tid / TM;
+    TopList<KL> L;
     list_init(L);
 
     const int n_chunks = D / KC;
-    // A loader: the chunk image is contiguous (16 KiB): wave w, pass u copies bytes [(4 u + w) * 1024, + 1024)
+    // A loader: the chunk image is contiguous (TM * 128 B): pass u, wave w copies bytes [(u * WAVES + w) * 1024, + 1024)
     const float *const a_src = a.Qt + ((int64_t)blockIdx.y * n_chunks) * TILE + (wave * 64 + lane) * 4;
-    // B loader: pass u, wave w, lane i -> row u*32 + w*8 + (i >> 3) (= row i >> 3 of 8-row block 4 u + w), slot p = i & 7,
+    // B loader: pass u, wave w, lane i -> 8-row block u * WAVES + w, row i >> 3 of it, slot p = i & 7,
     // source floats [4 k4, 4 k4 + 4), k4 = p ^ (row & 7)
     const int l_row = wave * 8 + (lane >> 3), l_p = lane & 7;
     const int l_k4 = (l_p ^ (lane >> 3)) * 4;
     // fragment map
     const int fr = lane & 31, fk = lane >> 5;
-    const int a_off = fk * 128 + wm * 64 + fr;                        // + (2 kk) * 128 per k-step, + 32 for the second row block
+    const int a_off = fk * TM + wm * (32 * WN) + fr;                  // + kk * 2 TM per k-step, + 32 i for row block i
     const int rb0 = wn * 64 + fr, rb1 = rb0 + 32;
     const int b_off0 = TILE + b_row_off(rb0) + fk, b_off1 = TILE + b_row_off(rb1) + fk, sw0 = rb0 & 7, sw1 = rb1 & 7;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr(S0));
 
-    for (int64_t n0 = part_lo; n0 < part_hi; n0 += BN) {
+    for (int64_t tile = blockIdx.x; tile < n_tiles;) {
+        const int64_t n0 = tile * TN;
+        unsigned claimed = 0;
+        if (tid == 0) claimed = __hip_atomic_fetch_add(a.tile_ctr + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float *brow[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int64_t br = n0 + u * 32 + l_row;
+            const int64_t br = n0 + u * (8 * WAVES) + l_row;
             const int64_t brc = br < a.n_rows ? br : 0;   // rows past the end: any valid row (their columns are never scanned)
             brow[u] = a.seg_table[brc >> a.seg_shift] + (brc & a.seg_mask) * (int64_t)D + l_k4;
         }
-        f32x16 acc[2][2];
+        f32x16 acc[WN][2];
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < WN; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -194,14 +220,13 @@ __global__ __launch_bounds__(256) void db_gemm_topk(BatchArgs a)
         auto stage_load_one = [&](int c, int j) {
             const uint32_t st = lds_base + (uint32_t)((c % NST) * STAGE) * 4u;
             const int u = j >> 1;
-            if (j & 1) glds16(brow[u] + c * KC, st + (uint32_t)(TILE + b_row_off(u * 32 + wave * 8)) * 4u);
-            else glds16(a_src + (int64_t)c * TILE + u * 1024, st + (uint32_t)((4 * u + wave) * 256) * 4u);
+            if (j & 1) glds16(brow[u] + c * KC, st + (uint32_t)(TILE + b_row_off((u * WAVES + wave) * 8)) * 4u);
+            else glds16(a_src + (int64_t)c * TILE + u * (WAVES * 256), st + (uint32_t)((u * WAVES + wave) * 256) * 4u);
         };
         auto stage_load = [&](int c) {
 #pragma unroll
             for (int j = 0; j < 8; j++) stage_load_one(c, j);
         };
-        __syncthreads();              // the previous tile's epilogue no longer reads Ct (aliases the stages)
 #pragma unroll
         for (int c = 0; c < NST - 1; c++)
             if (c < n_chunks) stage_load(c);
@@ -214,35 +239,41 @@ __global__ __launch_bounds__(256) void db_gemm_topk(BatchArgs a)
             // chunk c + NST - 1 goes to the stage last read in iteration c-1 (barrier since).  With 4 stages its 8 LDS-DMA
             // instructions are spread over the 8 MFMA groups below (issued in one burst they keep the lone wave of a SIMD from
             // issuing MFMAs for ~300 cycles per chunk); with 2 stages they must go out at once -- the chunk is needed at the end
-            // of this iteration, and the other workgroup's wave fills the issue gap (measured: 119.4 burst vs 114.8 spread).
+            // of this iteration, and the other wave of the SIMD fills the issue gap (measured: 119.4 burst vs 114.8 spread).
             const bool prefetch = c + NST - 1 < n_chunks;
             if (NST == 2 && prefetch) stage_load(c + NST - 1);
-            // fragments of k-steps (2 k4, 2 k4 + 1) in f[k4 & 1]; the next pair is read before this pair's 8 MFMAs are issued
-            float f[2][8];
+            // fragments of k-steps (2 k4, 2 k4 + 1) in f[k4 & 1]: [2 i + t] = A row block i, [2 WN + 2 j + t] = B block j;
+            // the next pair is read before this pair's 4 WN MFMAs are issued
+            float f[2][2 * WN + 4];
             auto rd = [&](int k4, float *d) {
-                d[0] = St[a_off + (2 * k4) * 256];      d[1] = St[a_off + (2 * k4 + 1) * 256];
-                d[2] = St[a_off + 32 + (2 * k4) * 256]; d[3] = St[a_off + 32 + (2 * k4 + 1) * 256];
+#pragma unroll
+                for (int i = 0; i < WN; i++) {
+                    d[2 * i] = St[a_off + 32 * i + (2 * k4) * (2 * TM)];
+                    d[2 * i + 1] = St[a_off + 32 * i + (2 * k4 + 1) * (2 * TM)];
+                }
                 const int p0 = (k4 ^ sw0) << 2, p1 = (k4 ^ sw1) << 2;
-                d[4] = St[b_off0 + p0]; d[5] = St[b_off0 + p0 + 2];
-                d[6] = St[b_off1 + p1]; d[7] = St[b_off1 + p1 + 2];
+                d[2 * WN] = St[b_off0 + p0];     d[2 * WN + 1] = St[b_off0 + p0 + 2];
+                d[2 * WN + 2] = St[b_off1 + p1]; d[2 * WN + 3] = St[b_off1 + p1 + 2];
             };
             rd(0, f[0]);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // the 4 reads of the first pair
+            __builtin_amdgcn_sched_group_barrier(0x100, WN + 2, 0);  // the reads of the first pair
 #pragma unroll
             for (int k4 = 0; k4 < KC / 4; k4++) {
                 if (NST > 2 && prefetch) stage_load_one(c + NST - 1, k4);
                 if (k4 + 1 < KC / 4) rd(k4 + 1, f[(k4 + 1) & 1]);
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
-                    const float a0 = f[k4 & 1][t], a1 = f[k4 & 1][2 + t], b0 = f[k4 & 1][4 + t], b1 = f[k4 & 1][6 + t];
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                    const float b0 = f[k4 & 1][2 * WN + t], b1 = f[k4 & 1][2 * WN + 2 + t];
+#pragma unroll
+                    for (int i = 0; i < WN; i++) {
+                        const float av = f[k4 & 1][2 * i + t];
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[i][1], 0, 0, 0);
+                    }
                 }
-                // keep the order "reads of the next pair, then this pair's 8 MFMAs" through the scheduler
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 DS reads
-                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMA
+                // keep the order "reads of the next pair, then this pair's MFMAs" through the scheduler
+                __builtin_amdgcn_sched_group_barrier(0x100, WN + 2, 0);   // DS reads (ds_read2)
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * WN, 0);   // MFMA
             }
             // chunk c+1 has landed (everything but the NST-2 newest chunks), every wave is done reading stage c % NST
             {
@@ -251,63 +282,65 @@ __global__ __launch_bounds__(256) void db_gemm_topk(BatchArgs a)
                 wait_loads_and_barrier(newer < 0 ? 0 : newer);
             }
         }
-        // ---- epilogue: the 128 x 128 score tile through LDS (the two stages are free: the K loop ended with a barrier);
-        // C/D layout of the MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-        const int ncols = (part_hi - n0) < BN ? (int)(part_hi - n0) : BN;
+        // ---- epilogue: the score tile through LDS, 128 DB rows (two of the WN wave columns) per pass (the stages are free:
+        // the K loop ended with a barrier); C/D layout of the MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+        const int ncols = (a.n_rows - n0) < TN ? (int)(a.n_rows - n0) : TN;
 #pragma unroll
-        for (int it = 0; it < 2; it++)
+        for (int h = 0; h < WN / 2; h++) {
+            if (h > 0) __syncthreads();   // the previous pass's scan is done with Ct
+            if ((wn >> 1) == h) {
 #pragma unroll
-            for (int jt = 0; jt < 2; jt++)
+                for (int it = 0; it < WN; it++)
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int row = wm * 64 + it * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);   // query within the tile
-                    const int col = wn * 64 + jt * 32 + (lane & 31);                                 // DB row within the tile
-                    Ct[row * CT_LD + col] = acc[it][jt][e];
-                }
-        __syncthreads();
-        {
-            float ts = L.s[0];
-            int32_t tr = L.r[0];
+                    for (int jt = 0; jt < 2; jt++)
 #pragma unroll
-            for (int j = 1; j < CHIP_MAX_TOPK; j++)
-                if (j < K) { ts = L.s[j]; tr = L.r[j]; }   // current K-th best
-            const int c_hi = ncols < (och + 1) * 64 ? ncols : (och + 1) * 64;
+                        for (int e = 0; e < 16; e++) {
+                            const int row = wm * (32 * WN) + it * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);   // query within the tile
+                            const int col = (wn & 1) * 64 + jt * 32 + (lane & 31);                                  // DB row within the pass
+                            Ct[row * CT_LD + col] = acc[it][jt][e];
+                        }
+            }
+            __syncthreads();
+            float ts;
+            int32_t tr;
+            list_kth(L, K, ts, tr);
+            const int pass_cols = ncols - h * 128;         // columns of this pass that exist
+            const int c_hi = pass_cols < (och + 1) * 64 ? pass_cols : (och + 1) * 64;
             for (int c = och * 64; c < c_hi; c++) {
                 const float s = Ct[oq * CT_LD + c];
-                const int32_t row = (int32_t)(n0 + c);
+                const int32_t row = (int32_t)(n0 + h * 128 + c);
                 if (fkey_gt(s, row, ts, tr)) {   // NaN never enters
                     list_push(L, K, s, row);
-                    ts = L.s[0]; tr = L.r[0];
-#pragma unroll
-                    for (int j = 1; j < CHIP_MAX_TOPK; j++)
-                        if (j < K) { ts = L.s[j]; tr = L.r[j]; }
+                    list_kth(L, K, ts, tr);
                 }
             }
         }
+        // next tile: published by thread 0, read by everyone after the barrier that also ends this tile's use of Ct
+        if (tid == 0) next_tile_slot = gridDim.x + claimed;
+        __syncthreads();
+        tile = next_tile_slot;
     }
     // fold the two column-half lists of a query into one (through LDS, once per workgroup): one list per (partition, query)
     __syncthreads();
-    float *const Ls = reinterpret_cast<float *>(smem);                 // [128][CHIP_MAX_TOPK]
-    int32_t *const Lr = reinterpret_cast<int32_t *>(Ls + 128 * CHIP_MAX_TOPK);
+    float *const Ls = reinterpret_cast<float *>(smem);                 // [TM][KL]
+    int32_t *const Lr = reinterpret_cast<int32_t *>(Ls + TM * KL);
     if (och == 1) {
 #pragma unroll
-        for (int j = 0; j < CHIP_MAX_TOPK; j++) { Ls[oq * CHIP_MAX_TOPK + j] = L.s[j]; Lr[oq * CHIP_MAX_TOPK + j] = L.r[j]; }
+        for (int j = 0; j < KL; j++) { Ls[oq * KL + j] = L.s[j]; Lr[oq * KL + j] = L.r[j]; }
     }
     __syncthreads();
     if (och == 0) {
         for (int j = 0; j < K; j++) {
-            const float s = Ls[oq * CHIP_MAX_TOPK + j];
-            const int32_t row = Lr[oq * CHIP_MAX_TOPK + j];
-            float ts = L.s[0];
-            int32_t tr = L.r[0];
-#pragma unroll
-            for (int jj = 1; jj < CHIP_MAX_TOPK; jj++)
-                if (jj < K) { ts = L.s[jj]; tr = L.r[jj]; }
+            const float s = Ls[oq * KL + j];
+            const int32_t row = Lr[oq * KL + j];
+            float ts;
+            int32_t tr;
+            list_kth(L, K, ts, tr);
             if (row >= 0 && fkey_gt(s, row, ts, tr)) list_push(L, K, s, row);
         }
         chip_topk_entry *dst = a.partial + ((int64_t)blockIdx.x * a.Qpad + q0 + oq) * K;
 #pragma unroll
-        for (int j = 0; j < CHIP_MAX_TOPK; j++)
+        for (int j = 0; j < KL; j++)
             if (j < K) {
                 chip_topk_entry e;
                 e.score = (double)L.s[j];
@@ -315,6 +348,7 @@ __global__ __launch_bounds__(256) void db_gemm_topk(BatchArgs a)
                 dst[j] = e;
             }
     }
+    (void)NT;
 }
 
 // one workgroup per 4 queries: merge the P partition lists
@@ -331,6 +365,7 @@ __global__ __launch_bounds__(512) void topk_merge_batch(BatchMergeArgs a)
 
 struct BatchState {
     float *Q = nullptr, *Qt = nullptr;
+    uint32_t *tile_ctr = nullptr;     // one counter per query tile (kMaxQTiles)
     chip_topk_entry *partial = nullptr, *out = nullptr, *h_out = nullptr;
     int64_t cap_q = 0, cap_partial = 0, cap_out = 0;
 };
@@ -339,7 +374,7 @@ void batch_destroy(Ctx *c)
 {
     BatchState *st = static_cast<BatchState *>(c->batch_state);
     if (!st) return;
-    (void)hipFree(st->Q); (void)hipFree(st->Qt); (void)hipFree(st->partial); (void)hipFree(st->out); (void)hipHostFree(st->h_out);
+    (void)hipFree(st->Q); (void)hipFree(st->Qt); (void)hipFree(st->tile_ctr); (void)hipFree(st->partial); (void)hipFree(st->out); (void)hipHostFree(st->h_out);
     delete st;
     c->batch_state = nullptr;
 }
@@ -369,20 +404,19 @@ extern "C" int chip_query_batch_f32(chip_ctx *c, int64_t k, const float *queries
     const int D = c->D;
     const int Qpad = (Q + BM - 1) / BM * BM;
     const int64_t n_rows = local_count(c, k);
-    const int qtiles = Qpad / BM;
-    // partitions of the prefix: `wgs` workgroups per CU in total, at least one 128-row tile each, at most 512 lists.
-    // Stages of the LDS-DMA pipeline: 2 (64 KiB per workgroup, two workgroups per CU) or 4 (128 KiB, one per CU); CHIP_BATCH_STAGES
-    // is a tuning knob, the default is the measured best.
-    const int nst = env_int("CHIP_BATCH_STAGES", 2) >= 4 ? 4 : 2;
-    const int wgs = nst == 4 ? 1 : 2;
-    int64_t tiles = (n_rows + BN - 1) / BN;
+    // Tile shape: 256 x 256 with 8 waves (one workgroup per CU: 16 MFMAs per 6 fragment reads, one barrier per 128 MFMAs, the DB
+    // streamed once per 256 queries) when the padded query count is a multiple of 256, else 128 x 128 with 4 waves.
+    // CHIP_BATCH_TILE=128 forces the small tile; CHIP_BATCH_STAGES=4 selects its 4-stage / one-workgroup-per-CU variant.
+    const bool wide = Qpad % 256 == 0 && env_int("CHIP_BATCH_TILE", 256) >= 256;
+    const int TM = wide ? 256 : BM, TN = TM;
+    const int qtiles = Qpad / TM;
+    const int nst = !wide && env_int("CHIP_BATCH_STAGES", 2) >= 4 ? 4 : 2;
+    const int wgs = wide || nst == 4 ? 1 : 2;            // workgroups per CU
+    int64_t tiles = (n_rows + TN - 1) / TN;
     if (tiles < 1) tiles = 1;
-    int64_t P = (wgs * (int64_t)c->n_cus + qtiles - 1) / qtiles;
+    int64_t P = (wgs * (int64_t)c->n_cus + qtiles - 1) / qtiles;   // workgroups per query tile (each ends with one list per query): at most 512
     if (P > tiles) P = tiles;
     if (P > 512) P = 512;
-    if (P < 1) P = 1;
-    const int64_t rows_per_part = ((tiles + P - 1) / P) * BN;
-    P = (n_rows + rows_per_part - 1) / rows_per_part;
     if (P < 1) P = 1;
 
     hipStream_t s = c->s_scan;
@@ -404,21 +438,25 @@ extern "C" int chip_query_batch_f32(chip_ctx *c, int64_t k, const float *queries
         CHIP_HIP(c, hipHostMalloc(&st->h_out, sizeof(chip_topk_entry) * (size_t)Qpad * topk, hipHostMallocDefault));
         st->cap_out = (int64_t)Qpad * topk;
     }
+    if (!st->tile_ctr) CHIP_HIP(c, hipMalloc(&st->tile_ctr, sizeof(uint32_t) * kMaxQTiles));
+    if (qtiles > kMaxQTiles) return CHIP_ERR_UNSUPPORTED;
+    CHIP_HIP(c, hipMemsetAsync(st->tile_ctr, 0, sizeof(uint32_t) * kMaxQTiles, s));
     CHIP_HIP(c, hipMemsetAsync(st->Q, 0, sizeof(float) * (size_t)Qpad * D, s));
     CHIP_HIP(c, hipMemcpyAsync(st->Q, queries, sizeof(float) * (size_t)Q * D, hipMemcpyHostToDevice, s));
     {   // K-chunk-major transposed image of the query tiles (what the A-side LDS-DMA copies linearly)
         int64_t g = ((int64_t)Qpad * D + 255) / 256;
         if (g > (int64_t)c->n_cus * 8) g = (int64_t)c->n_cus * 8;
-        hipLaunchKernelGGL(transpose_queries, dim3((unsigned)g), dim3(256), 0, s, st->Q, st->Qt, Qpad, D);
+        hipLaunchKernelGGL(transpose_queries, dim3((unsigned)g), dim3(256), 0, s, st->Q, st->Qt, Qpad, D, wide ? 8 : 7);
         CHIP_HIP(c, hipGetLastError());
     }
 
     BatchArgs a;
     a.seg_table = reinterpret_cast<const float *const *>(c->seg_table_dev); a.seg_shift = c->seg_shift; a.seg_mask = c->seg_rows - 1;
-    a.n_rows = n_rows; a.D = D; a.Q = st->Q; a.Qt = st->Qt; a.Qpad = Qpad; a.K = topk; a.rows_per_part = rows_per_part;
+    a.n_rows = n_rows; a.D = D; a.Q = st->Q; a.Qt = st->Qt; a.Qpad = Qpad; a.K = topk; a.tile_ctr = st->tile_ctr;
     a.idx_mul = c->nranks; a.idx_add = c->nranks == 1 ? 0 : c->rank; a.partial = st->partial;
     constexpr int KCsel = 32;
-    const size_t lds_gemm = sizeof(float) * (size_t)nst * (BM * KCsel + kBTile) /* stages x (A + B) */, lds_ct = sizeof(float) * BM * CT_LD;
+    const size_t lds_gemm = sizeof(float) * (size_t)nst * ((size_t)TM * KCsel + (size_t)(TN / 8) * kBBlock) /* stages x (A + B) */;
+    const size_t lds_ct = sizeof(float) * (size_t)TM * CT_LD;
     const size_t lds = lds_gemm > lds_ct ? lds_gemm : lds_ct;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->prof_on) {
@@ -426,16 +464,18 @@ extern "C" int chip_query_batch_f32(chip_ctx *c, int64_t k, const float *queries
             for (int i = 0; i < 2; i++) { hipEvent_t e; CHIP_HIP(c, hipEventCreate(&e)); c->prof_ev.push_back(e); }
         e0 = c->prof_ev[c->prof_used]; e1 = c->prof_ev[c->prof_used + 1];
         c->prof_used += 2;
-        c->prof_bytes_last = (double)n_rows * D * 4.0 * qtiles;
+        c->prof_bytes_last = (double)n_rows * D * 4.0 * qtiles;   // the DB is streamed once per query tile
         CHIP_HIP(c, hipEventRecord(e0, s));
     }
-    if (nst == 4) {
-        CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_gemm_topk<KCsel, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((db_gemm_topk<KCsel, 4>), dim3((unsigned)P, (unsigned)qtiles), dim3(256), lds, s, a);
-    } else {
-        CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_gemm_topk<KCsel, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((db_gemm_topk<KCsel, 2>), dim3((unsigned)P, (unsigned)qtiles), dim3(256), lds, s, a);
-    }
+    auto launch = [&](auto kernel, int threads) -> int {
+        CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)P, (unsigned)qtiles), dim3(threads), lds, s, a);
+        return CHIP_OK;
+    };
+    int lrc;
+    if (topk <= 8) lrc = wide ? launch(db_gemm_topk<KCsel, 2, 4, 8>, 512) : nst == 4 ? launch(db_gemm_topk<KCsel, 4, 2, 8>, 256) : launch(db_gemm_topk<KCsel, 2, 2, 8>, 256);
+    else lrc = wide ? launch(db_gemm_topk<KCsel, 2, 4, CHIP_MAX_TOPK>, 512) : nst == 4 ? launch(db_gemm_topk<KCsel, 4, 2, CHIP_MAX_TOPK>, 256) : launch(db_gemm_topk<KCsel, 2, 2, CHIP_MAX_TOPK>, 256);
+    if (lrc != CHIP_OK) return lrc;
     CHIP_HIP(c, hipGetLastError());
     if (e1) CHIP_HIP(c, hipEventRecord(e1, s));
     BatchMergeArgs m;

@@ -241,6 +241,90 @@ static void run8(int blocks, int iters, const char *name)
     hipFree(out); hipFree(src);
 }
 
+
+// mode 10/11: the same 128 x 64 per-wave tile with EIGHT waves per workgroup (workgroup tile 256 x 256, two waves per SIMD that
+//             meet at the same barrier), two stages of 64 KiB, 8 LDS-DMA per wave and one counted barrier per 128 MFMAs
+template <int MODE>
+__global__ __launch_bounds__(512) void k10(float *out, int iters, const float *src)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *S = reinterpret_cast<float *>(smem);   // 2 stages x (A [32 k][256 rows] + B [256 rows][32]) = 2 x 16384 floats
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 2 * 16384; i += 512) S[i] = (float)(i % 7) * 0.125f;
+    __syncthreads();
+    f32x16 acc[4][2];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 2; j++) for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+    const int fr = lane & 31, fk = lane >> 5, wm = wave >> 2, wn = wave & 3;
+    const int a_off = fk * 256 + wm * 128 + fr;
+    const int rb0 = wn * 64 + fr, rb1 = rb0 + 32;
+    const int b_off0 = 8192 + rb0 * 32 + fk, b_off1 = 8192 + rb1 * 32 + fk, sw0 = (rb0 >> 1) & 7, sw1 = (rb1 >> 1) & 7;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(const __attribute__((address_space(3))) void *)S);
+    const float *g = src + (size_t)(blockIdx.x % 16) * 16384 + (tid & 255) * 4;
+    for (int it = 0; it < iters; it++) {
+        const float *St = S + (it & 1) * 16384;
+        if (MODE == 11) {
+            const unsigned st = lds_base + (unsigned)(((it + 1) & 1) * 16384 + wave * 256) * 4u;
+#pragma unroll
+            for (int u = 0; u < 8; u++) glds16(g + u * 2048, st + u * 8192u);
+        }
+        float f[2][12];
+        auto rd = [&](int k4, float *d) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { d[2 * i] = St[a_off + 32 * i + (2 * k4) * 512]; d[2 * i + 1] = St[a_off + 32 * i + (2 * k4 + 1) * 512]; }
+            const int p0 = (k4 ^ sw0) << 2, p1 = (k4 ^ sw1) << 2;
+            d[8] = St[b_off0 + p0]; d[9] = St[b_off0 + p0 + 2];
+            d[10] = St[b_off1 + p1]; d[11] = St[b_off1 + p1 + 2];
+        };
+        rd(0, f[0]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int k4 = 0; k4 < 8; k4++) {
+            if (k4 + 1 < 8) rd(k4 + 1, f[(k4 + 1) & 1]);
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const float b0 = f[k4 & 1][8 + t], b1 = f[k4 & 1][10 + t];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float a = f[k4 & 1][2 * i + t];
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[i][1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        }
+        if (MODE == 11) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 2; j++) for (int e = 0; e < 16; e++) s += acc[i][j][e];
+    out[blockIdx.x * 512 + tid] = s;
+}
+
+template <int MODE>
+static void run10(int blocks, int iters, const char *name)
+{
+    float *out, *src;
+    hipMalloc(&out, sizeof(float) * 512 * blocks);
+    hipMalloc(&src, sizeof(float) * 16 * 16384 + 131072);
+    hipMemset(src, 0, sizeof(float) * 16 * 16384 + 131072);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k10<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k10<MODE>, dim3(blocks), dim3(512), 131072, 0, out, 16, src);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k10<MODE>, dim3(blocks), dim3(512), 131072, 0, out, iters, src);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 8 * iters * 128.0 * 2.0 * 32 * 32 * 2;
+    printf("%-44s blocks=%4d: %8.3f ms  %7.1f TFLOP/s (%.3f of 157.3)  %s\n", name, blocks, ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3, hipGetErrorString(hipGetLastError()));
+    hipFree(out); hipFree(src);
+}
+
 template <int MODE>
 static void run3(int blocks, int iters, const char *name)
 {
@@ -368,5 +452,7 @@ int main()
     run6<7>(256, iters, "  + LDS-DMA + counted barrier per 64 MFMA");
     run8<8>(256, iters / 2, "128x64 per wave (16 MFMA per 6 reads), no DMA");
     run8<9>(256, iters / 2, "  + 12 LDS-DMA + barrier per 128 MFMA");
+    run10<10>(256, iters / 4, "8 waves x 128x64 (two waves per SIMD), no DMA");
+    run10<11>(256, iters / 4, "  + 8 LDS-DMA + barrier per 128 MFMA");
     return 0;
 }
