@@ -9,12 +9,17 @@
 // belongs on the matrix cores: v_mfma_f32_32x32x2_f32 is exact fp32 (bit-for-bit a k-ordered fmaf chain,
 // cdna_hip_programming.md 3) at the 157 TFLOP/s vector rate.
 //
-// K_B db_gemm_topk : grid (P partitions of the DB prefix) x (Qpad/128 query tiles), 256 threads = 4 waves (2x2), each
-//   wave owns a 64x64 block of the 128 (queries) x 128 (DB rows) tile as 2x2 MFMA 32x32 accumulators.  K is streamed in
-//   chunks of 32 through LDS (row stride 33 floats: conflict-free ds_read_b32 fragment reads).  After the full K loop the
-//   tile is transposed through the same LDS in two 64-query halves and 64 "owner" threads (one per query) scan the 128
-//   new scores against their register-resident sorted top-K list.  Per partition and query one sorted list is written;
-//   the lists are merged by topk_merge_batch (the shared merge_sorted_lists).
+// K_B db_gemm_topk<KC, NST, WN, KL> : grid (P workgroups) x (query tiles).  Tile = 64 WN queries x 64 WN DB rows on 2 x WN waves,
+//   each wave owning WN x 2 MFMA 32x32 accumulators (64 WN queries x 64 DB rows):
+//     WN = 4: 256 x 256 on 8 waves, one workgroup per CU -- 16 MFMAs per 6 fragment reads, one workgroup barrier per 128 MFMAs,
+//             the DB streamed once per 256 queries; used when the padded query count is a multiple of 256 (0.81 of the fp32
+//             matrix peak at Q = 256 x 1M rows);
+//     WN = 2: 128 x 128 on 4 waves, two workgroups per CU (0.78), for everything else.
+//   K is streamed in chunks of 32 through a two-stage LDS ring filled by LDS-DMA (see "LDS-DMA tile staging" below).  DB tiles
+//   are claimed from a counter (one atomic per ~1 ms tile).  After the K loop of a tile its scores go through the same LDS, 128
+//   DB rows per pass, and ALL threads scan them against register-resident sorted top-K lists (thread = query x 64-column half;
+//   KL = list capacity, 8 or 16).  One sorted list per workgroup and query is written; topk_merge_batch (the shared
+//   merge_sorted_lists) merges them.
 #include "chip_internal.h"
 #include "topk_merge.h"
 #include <cmath>
@@ -417,6 +422,8 @@ extern "C" int chip_query_batch_f32(chip_ctx *c, int64_t k, const float *queries
     int64_t P = (wgs * (int64_t)c->n_cus + qtiles - 1) / qtiles;   // workgroups per query tile (each ends with one list per query): at most 512
     if (P > tiles) P = tiles;
     if (P > 512) P = 512;
+    const int cap_wgs = env_int("CHIP_BATCH_WGS", 0);   // diagnosis / tests: fewer workgroups, i.e. many claimed tiles each
+    if (cap_wgs > 0 && P > cap_wgs) P = cap_wgs;
     if (P < 1) P = 1;
 
     hipStream_t s = c->s_scan;

@@ -16,7 +16,8 @@ def check(chip, db, k, q, K):
     assert np.array_equal(got_s.view(np.uint32), want_s.astype(np.float32).view(np.uint32))     # bit-exact fp32 scores
 
 
-@pytest.mark.parametrize("D,N,Q", [(32, 300, 5), (512, 1500, 64), (1024, 3000, 200), (4096, 2000, 130)])
+# Q -> padded to 128s; a multiple of 256 takes the 256 x 256 / 8-wave tile, anything else the 128 x 128 / 4-wave one
+@pytest.mark.parametrize("D,N,Q", [(32, 300, 5), (512, 1500, 64), (1024, 3000, 200), (4096, 2000, 130), (256, 2600, 300), (64, 1500, 512)])
 def test_batch_parity(D, N, Q):
     plants, loops, ties = scenarios.loop_plants(N, 4, seed=D + Q)
     db = scenarios.build_db(7 * D, N, D, plants)
@@ -26,7 +27,7 @@ def test_batch_parity(D, N, Q):
     with capi.Chip(D) as chip:
         chip.append_f32(db)
         for K in (1, 8, 16):
-            for k in (0, 1, 127, 128, 129, N - 50, N):
+            for k in (0, 1, 127, 128, 129, 255, 256, 257, N - 50, N):
                 check(chip, db, k, q, K)
         if ties:
             s, t1, t2 = ties[0]
@@ -64,3 +65,20 @@ def test_batch_sharded_lists_are_consistent():
     for qi in range(Q):
         cand = sorted(((float(s), int(i)) for ps, pi in parts for s, i in zip(ps[qi], pi[qi]) if i >= 0), key=lambda t: (-t[0], -t[1]))[:8]
         assert [c[1] for c in cand] == list(want_i[qi])
+
+
+@pytest.mark.parametrize("Q,wgs", [(256, 1), (256, 3), (100, 2), (600, 2)])
+def test_batch_claimed_tiles(Q, wgs, monkeypatch):
+    """DB tiles are claimed from a counter by the workgroups of a query tile; with the normal grid a small DB gives every
+    workgroup one tile, so cap the grid (CHIP_BATCH_WGS) to make each workgroup walk many claimed tiles, for one and for several
+    query tiles (one counter each) and both tile shapes."""
+    D, N = 128, 5000
+    db = scenarios.build_db(11, N, D, [])
+    rng = np.random.default_rng(Q + wgs)
+    q = db[rng.choice(N, Q, replace=False)]
+    monkeypatch.setenv("CHIP_BATCH_WGS", str(wgs))
+    with capi.Chip(D) as chip:
+        chip.append_f32(db)
+        for k in (N, N - 257, 1023):
+            check(chip, db, k, q, 8)
+        check(chip, db, N, q[:40], 16)
