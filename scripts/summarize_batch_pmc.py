@@ -19,7 +19,7 @@ fetch = rows['FETCH_SIZE'][1] * 1024 * 2
 variants = (ROOT / "gpurun_out/r02/batch_variants.txt").read_text().strip().splitlines() if (ROOT / "gpurun_out/r02/batch_variants.txt").exists() else []
 md = ["# rocprofv3 PMC passes on the many-query MFMA kernel `db_gemm_topk` (Q = 256 x 1M x 4096), round 2", "",
       "`bash scripts/gpu_batch_pmc2.sh` (separate `--pmc` runs of `scripts/run_batch_once.py`, three launches each; no trace domain besides",
-      f"`--kernel-trace`). Kernel as shipped: `{kname}` = two LDS-DMA stages, two workgroups per CU, VALU-free fragment reads.", "",
+      f"`--kernel-trace`). Kernel as shipped: `{kname}` = 256 x 256 tile on 8 waves, two LDS-DMA stages, one workgroup per CU, VALU-free and bank-conflict-free fragment reads.", "",
       "| counter | dispatches | avg per launch |", "|---|---|---|"]
 md += [f"| {cn} | {c} | {a:.5e} |" for cn, (c, a, n) in rows.items()]
 md += ["", f"Derived: `GRBM_GUI_ACTIVE` / 8 XCDs = {gui:.3e} cycles per launch; MFMA pipe utilisation = `SQ_VALU_MFMA_BUSY_CYCLES` /",
