@@ -241,12 +241,14 @@ __global__ __launch_bounds__(128 * WN) void db_gemm_topk(BatchArgs a)
         }
         for (int c = 0; c < n_chunks; c++) {
             const float *St = S0 + (c % NST) * STAGE;
-            // chunk c + NST - 1 goes to the stage last read in iteration c-1 (barrier since).  With 4 stages its 8 LDS-DMA
-            // instructions are spread over the 8 MFMA groups below (issued in one burst they keep the lone wave of a SIMD from
-            // issuing MFMAs for ~300 cycles per chunk); with 2 stages they must go out at once -- the chunk is needed at the end
-            // of this iteration, and the other wave of the SIMD fills the issue gap (measured: 119.4 burst vs 114.8 spread).
+            // chunk c + NST - 1 goes to the stage last read in iteration c-1 (barrier since).  When its 8 LDS-DMA instructions are
+            // issued matters (a burst keeps a wave from issuing MFMAs for ~300 cycles; a late load is waited for at the barrier):
+            //   4 stages            one in front of each of the 8 MFMA groups of this iteration (the chunk is needed 3 iterations on);
+            //   2 stages, 128 tile  all 8 at once at the top (the other workgroup's wave fills the gap: 119.4 TF vs 114.8 spread);
+            //   2 stages, 256 tile  two in front of each of MFMA groups 1..4 (both waves of a SIMD belong to this workgroup and burst
+            //                       together: 0.814 of peak vs 0.792 for the burst, 0.805 for groups 0..3, 0.76 for one per group).
             const bool prefetch = c + NST - 1 < n_chunks;
-            if (NST == 2 && prefetch) stage_load(c + NST - 1);
+            if (NST == 2 && WN == 2 && prefetch) stage_load(c + NST - 1);
             // fragments of k-steps (2 k4, 2 k4 + 1) in f[k4 & 1]: [2 i + t] = A row block i, [2 WN + 2 j + t] = B block j;
             // the next pair is read before this pair's 4 WN MFMAs are issued
             float f[2][2 * WN + 4];
@@ -265,6 +267,7 @@ __global__ __launch_bounds__(128 * WN) void db_gemm_topk(BatchArgs a)
 #pragma unroll
             for (int k4 = 0; k4 < KC / 4; k4++) {
                 if (NST > 2 && prefetch) stage_load_one(c + NST - 1, k4);
+                if (NST == 2 && WN == 4 && prefetch && k4 >= 1 && k4 <= 4) { stage_load_one(c + 1, 2 * k4 - 2); stage_load_one(c + 1, 2 * k4 - 1); }
                 if (k4 + 1 < KC / 4) rd(k4 + 1, f[(k4 + 1) & 1]);
 #pragma unroll
                 for (int t = 0; t < 2; t++) {
