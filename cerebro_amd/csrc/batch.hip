@@ -24,6 +24,7 @@
 #include "topk_merge.h"
 #include <cmath>
 #include <new>
+#include <type_traits>
 
 namespace chip {
 
@@ -197,12 +198,24 @@ __global__ __launch_bounds__(128 * WN) void db_gemm_topk(BatchArgs a)
     const int l_k4 = (l_p ^ (lane >> 3)) * 4;
     // fragment map
     const int fr = lane & 31, fk = lane >> 5;
-    const int a_off = fk * TM + wm * (32 * WN) + fr;                  // + kk * 2 TM per k-step, + 32 i for row block i
     const int rb0 = wn * 64 + fr, rb1 = rb0 + 32;
     const int b_off0 = TILE + b_row_off(rb0) + fk, b_off1 = TILE + b_row_off(rb1) + fk, sw0 = rb0 & 7, sw1 = rb1 & 7;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr(S0));
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles;) {
+    // Units of work: the first n_full = floor(n_tiles / P) * P tiles are whole tiles (P = workgroups of this query tile: full
+    // rounds in which every CU is busy); what remains -- r < P tiles, the round that would leave P - r CUs idle -- is cut
+    // into query halves when 2 r <= P (each wave then owns WN / 2 x 2 blocks and the unit takes half a tile time: 15.5 instead of
+    // 16 tile times for 3907 tiles on 256 CUs).
+    const int64_t n_full = n_tiles / gridDim.x * gridDim.x;
+    const bool halves = 2 * (n_tiles - n_full) <= (int64_t)gridDim.x;
+    const int64_t n_units = halves ? n_full + 2 * (n_tiles - n_full) : n_tiles;
+    for (int64_t unit = blockIdx.x; unit < n_units;) {
+        const bool half_unit = halves && unit >= n_full;
+        const int64_t tile = half_unit ? n_full + ((unit - n_full) >> 1) : unit;
+        const int qhalf = half_unit ? (int)((unit - n_full) & 1) : 0;
+        const int nrb = half_unit ? WN / 2 : WN;                                      // 32-query row blocks per wave in this unit
+        const int qrow0 = half_unit ? qhalf * (TM / 2) + wm * (16 * WN) : wm * (32 * WN);   // first query row of this wave
+        const int a_off = fk * TM + qrow0 + fr;                        // + kk * 2 TM per k-step, + 32 i for row block i
         const int64_t n0 = tile * TN;
         unsigned claimed = 0;
         if (tid == 0) claimed = __hip_atomic_fetch_add(a.tile_ctr + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -239,57 +252,63 @@ __global__ __launch_bounds__(128 * WN) void db_gemm_topk(BatchArgs a)
             const int issued = n_chunks < NST - 1 ? n_chunks : NST - 1;
             wait_loads_and_barrier(issued - 1);   // chunk 0 has landed
         }
-        for (int c = 0; c < n_chunks; c++) {
-            const float *St = S0 + (c % NST) * STAGE;
-            // chunk c + NST - 1 goes to the stage last read in iteration c-1 (barrier since).  When its 8 LDS-DMA instructions are
-            // issued matters (a burst keeps a wave from issuing MFMAs for ~300 cycles; a late load is waited for at the barrier):
-            //   4 stages            one in front of each of the 8 MFMA groups of this iteration (the chunk is needed 3 iterations on);
-            //   2 stages, 128 tile  all 8 at once at the top (the other workgroup's wave fills the gap: 119.4 TF vs 114.8 spread);
-            //   2 stages, 256 tile  two in front of each of MFMA groups 1..4 (both waves of a SIMD belong to this workgroup and burst
-            //                       together: 0.814 of peak vs 0.792 for the burst, 0.805 for groups 0..3, 0.76 for one per group).
-            const bool prefetch = c + NST - 1 < n_chunks;
-            if (NST == 2 && WN == 2 && prefetch) stage_load(c + NST - 1);
-            // fragments of k-steps (2 k4, 2 k4 + 1) in f[k4 & 1]: [2 i + t] = A row block i, [2 WN + 2 j + t] = B block j;
-            // the next pair is read before this pair's 4 WN MFMAs are issued
-            float f[2][2 * WN + 4];
-            auto rd = [&](int k4, float *d) {
+        // the K loop, instantiated for whole tiles (NRB = WN row blocks per wave) and for query halves (NRB = WN / 2)
+        auto k_loop = [&](auto nrb_tag) {
+            constexpr int NRB = decltype(nrb_tag)::value;
+            for (int c = 0; c < n_chunks; c++) {
+                const float *St = S0 + (c % NST) * STAGE;
+                // chunk c + NST - 1 goes to the stage last read in iteration c-1 (barrier since).  When its 8 LDS-DMA instructions are
+                // issued matters (a burst keeps a wave from issuing MFMAs for ~300 cycles; a late load is waited for at the barrier):
+                //   4 stages            one in front of each of the 8 MFMA groups of this iteration (the chunk is needed 3 iterations on);
+                //   2 stages, 128 tile  all 8 at once at the top (the other workgroup's wave fills the gap: 119.4 TF vs 114.8 spread);
+                //   2 stages, 256 tile  two in front of each of MFMA groups 1..4 (both waves of a SIMD belong to this workgroup and burst
+                //                       together: 0.814 of peak vs 0.792 for the burst, 0.805 for groups 0..3, 0.76 for one per group).
+                const bool prefetch = c + NST - 1 < n_chunks;
+                if (NST == 2 && WN == 2 && prefetch) stage_load(c + NST - 1);
+                // fragments of k-steps (2 k4, 2 k4 + 1) in f[k4 & 1]: [2 i + t] = A row block i, [2 WN + 2 j + t] = B block j;
+                // the next pair is read before this pair's 4 WN MFMAs are issued
+                float f[2][2 * WN + 4];
+                auto rd = [&](int k4, float *d) {
 #pragma unroll
-                for (int i = 0; i < WN; i++) {
-                    d[2 * i] = St[a_off + 32 * i + (2 * k4) * (2 * TM)];
-                    d[2 * i + 1] = St[a_off + 32 * i + (2 * k4 + 1) * (2 * TM)];
-                }
-                const int p0 = (k4 ^ sw0) << 2, p1 = (k4 ^ sw1) << 2;
-                d[2 * WN] = St[b_off0 + p0];     d[2 * WN + 1] = St[b_off0 + p0 + 2];
-                d[2 * WN + 2] = St[b_off1 + p1]; d[2 * WN + 3] = St[b_off1 + p1 + 2];
-            };
-            rd(0, f[0]);
-            __builtin_amdgcn_sched_group_barrier(0x100, WN + 2, 0);  // the reads of the first pair
-#pragma unroll
-            for (int k4 = 0; k4 < KC / 4; k4++) {
-                if (NST > 2 && prefetch) stage_load_one(c + NST - 1, k4);
-                if (NST == 2 && WN == 4 && prefetch && k4 >= 1 && k4 <= 4) { stage_load_one(c + 1, 2 * k4 - 2); stage_load_one(c + 1, 2 * k4 - 1); }
-                if (k4 + 1 < KC / 4) rd(k4 + 1, f[(k4 + 1) & 1]);
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    const float b0 = f[k4 & 1][2 * WN + t], b1 = f[k4 & 1][2 * WN + 2 + t];
-#pragma unroll
-                    for (int i = 0; i < WN; i++) {
-                        const float av = f[k4 & 1][2 * i + t];
-                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[i][0], 0, 0, 0);
-                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[i][1], 0, 0, 0);
+                    for (int i = 0; i < NRB; i++) {
+                        d[2 * i] = St[a_off + 32 * i + (2 * k4) * (2 * TM)];
+                        d[2 * i + 1] = St[a_off + 32 * i + (2 * k4 + 1) * (2 * TM)];
                     }
+                    const int p0 = (k4 ^ sw0) << 2, p1 = (k4 ^ sw1) << 2;
+                    d[2 * WN] = St[b_off0 + p0];     d[2 * WN + 1] = St[b_off0 + p0 + 2];
+                    d[2 * WN + 2] = St[b_off1 + p1]; d[2 * WN + 3] = St[b_off1 + p1 + 2];
+                };
+                rd(0, f[0]);
+                __builtin_amdgcn_sched_group_barrier(0x100, NRB + 2, 0);  // the reads of the first pair
+#pragma unroll
+                for (int k4 = 0; k4 < KC / 4; k4++) {
+                    if (NST > 2 && prefetch) stage_load_one(c + NST - 1, k4);
+                    if (NST == 2 && WN == 4 && prefetch && k4 >= 1 && k4 <= 4) { stage_load_one(c + 1, 2 * k4 - 2); stage_load_one(c + 1, 2 * k4 - 1); }
+                    if (k4 + 1 < KC / 4) rd(k4 + 1, f[(k4 + 1) & 1]);
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const float b0 = f[k4 & 1][2 * WN + t], b1 = f[k4 & 1][2 * WN + 2 + t];
+#pragma unroll
+                        for (int i = 0; i < NRB; i++) {
+                            const float av = f[k4 & 1][2 * i + t];
+                            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[i][0], 0, 0, 0);
+                            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[i][1], 0, 0, 0);
+                        }
+                    }
+                    // keep the order "reads of the next pair, then this pair's MFMAs" through the scheduler
+                    __builtin_amdgcn_sched_group_barrier(0x100, NRB + 2, 0);   // DS reads (ds_read2)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NRB, 0);   // MFMA
                 }
-                // keep the order "reads of the next pair, then this pair's MFMAs" through the scheduler
-                __builtin_amdgcn_sched_group_barrier(0x100, WN + 2, 0);   // DS reads (ds_read2)
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * WN, 0);   // MFMA
+                // chunk c+1 has landed (everything but the NST-2 newest chunks), every wave is done reading stage c % NST
+                {
+                    int newer = n_chunks - (c + 2);   // chunks after c+1 that have been issued: min(NST - 2, n_chunks - c - 2)
+                    if (newer > NST - 2) newer = NST - 2;
+                    wait_loads_and_barrier(newer < 0 ? 0 : newer);
+                }
             }
-            // chunk c+1 has landed (everything but the NST-2 newest chunks), every wave is done reading stage c % NST
-            {
-                int newer = n_chunks - (c + 2);   // chunks after c+1 that have been issued: min(NST - 2, n_chunks - c - 2)
-                if (newer > NST - 2) newer = NST - 2;
-                wait_loads_and_barrier(newer < 0 ? 0 : newer);
-            }
-        }
+        };
+        if (half_unit) k_loop(std::integral_constant<int, WN / 2>{});
+        else k_loop(std::integral_constant<int, WN>{});
         // ---- epilogue: the score tile through LDS, 128 DB rows (two of the WN wave columns) per pass (the stages are free:
         // the K loop ended with a barrier); C/D layout of the MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
         const int ncols = (a.n_rows - n0) < TN ? (int)(a.n_rows - n0) : TN;
@@ -298,22 +317,25 @@ __global__ __launch_bounds__(128 * WN) void db_gemm_topk(BatchArgs a)
             if (h > 0) __syncthreads();   // the previous pass's scan is done with Ct
             if ((wn >> 1) == h) {
 #pragma unroll
-                for (int it = 0; it < WN; it++)
+                for (int it = 0; it < WN; it++) {
+                    if (it >= nrb) continue;   // a query half: the upper row blocks hold nothing
 #pragma unroll
                     for (int jt = 0; jt < 2; jt++)
 #pragma unroll
                         for (int e = 0; e < 16; e++) {
-                            const int row = wm * (32 * WN) + it * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);   // query within the tile
+                            const int row = qrow0 + it * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);   // query within the tile
                             const int col = (wn & 1) * 64 + jt * 32 + (lane & 31);                                  // DB row within the pass
                             Ct[row * CT_LD + col] = acc[it][jt][e];
                         }
+                }
             }
             __syncthreads();
             float ts;
             int32_t tr;
             list_kth(L, K, ts, tr);
             const int pass_cols = ncols - h * 128;         // columns of this pass that exist
-            const int c_hi = pass_cols < (och + 1) * 64 ? pass_cols : (och + 1) * 64;
+            const bool mine = !half_unit || (oq >= qhalf * (TM / 2) && oq < (qhalf + 1) * (TM / 2));   // a query half: only its queries have scores
+            const int c_hi = !mine ? 0 : pass_cols < (och + 1) * 64 ? pass_cols : (och + 1) * 64;
             for (int c = och * 64; c < c_hi; c++) {
                 const float s = Ct[oq * CT_LD + c];
                 const int32_t row = (int32_t)(n0 + h * 128 + c);
@@ -326,7 +348,7 @@ __global__ __launch_bounds__(128 * WN) void db_gemm_topk(BatchArgs a)
         // next tile: published by thread 0, read by everyone after the barrier that also ends this tile's use of Ct
         if (tid == 0) next_tile_slot = gridDim.x + claimed;
         __syncthreads();
-        tile = next_tile_slot;
+        unit = next_tile_slot;
     }
     // fold the two column-half lists of a query into one (through LDS, once per workgroup): one list per (partition, query)
     __syncthreads();

@@ -67,7 +67,9 @@ def test_batch_sharded_lists_are_consistent():
         assert [c[1] for c in cand] == list(want_i[qi])
 
 
-@pytest.mark.parametrize("Q,wgs", [(256, 1), (256, 3), (100, 2), (600, 2)])
+# 5000 rows = 20 tiles of 256 / 40 tiles of 128.  The last, partial round of tiles is cut into query halves when that fills
+# the grid better (2 * (tiles % wgs) <= wgs): (256, 8): 16 whole tiles + 4 x 2 halves; (100, 16): 32 + 8 x 2; (512, 6): 18 + 2 x 2
+@pytest.mark.parametrize("Q,wgs", [(256, 1), (256, 3), (100, 2), (600, 2), (256, 8), (100, 16), (512, 6), (256, 19)])
 def test_batch_claimed_tiles(Q, wgs, monkeypatch):
     """DB tiles are claimed from a counter by the workgroups of a query tile; with the normal grid a small DB gives every
     workgroup one tile, so cap the grid (CHIP_BATCH_WGS) to make each workgroup walk many claimed tiles, for one and for several
@@ -79,6 +81,6 @@ def test_batch_claimed_tiles(Q, wgs, monkeypatch):
     monkeypatch.setenv("CHIP_BATCH_WGS", str(wgs))
     with capi.Chip(D) as chip:
         chip.append_f32(db)
-        for k in (N, N - 257, 1023):
+        for k in (N, N - 257, 4097, 1023):
             check(chip, db, k, q, 8)
         check(chip, db, N, q[:40], 16)
