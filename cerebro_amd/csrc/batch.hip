@@ -12,7 +12,7 @@
 // K_B db_gemm_topk<KC, NST, WN, KL> : grid (P workgroups) x (query tiles).  Tile = 64 WN queries x 64 WN DB rows on 2 x WN waves,
 //   each wave owning WN x 2 MFMA 32x32 accumulators (64 WN queries x 64 DB rows):
 //     WN = 4: 256 x 256 on 8 waves, one workgroup per CU -- 16 MFMAs per 6 fragment reads, one workgroup barrier per 128 MFMAs,
-//             the DB streamed once per 256 queries; used when the padded query count is a multiple of 256 (0.81 of the fp32
+//             the DB streamed once per 256 queries; used when the padded query count is a multiple of 256 (0.84 of the fp32
 //             matrix peak at Q = 256 x 1M rows);
 //     WN = 2: 128 x 128 on 4 waves, two workgroups per CU (0.78), for everything else.
 //   K is streamed in chunks of 32 through a two-stage LDS ring filled by LDS-DMA (see "LDS-DMA tile staging" below).  DB tiles
