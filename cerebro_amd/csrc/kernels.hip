@@ -274,7 +274,7 @@ static int launch_scan_t(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, siz
 // consumed behind counted waits (rows_dot, NT == 6) -- with compiler-scheduled loads (variant 1, the round-1 kernel: U = 8
 // builtin loads) hipcc sinks each load next to its use and a wave runs with 1-2 KiB in flight at 110 VGPRs; the asm form
 // keeps 4 KiB per wave in flight at 66 VGPRs (short scans +5-7 %, 1M rows equal: profiles/r02_scan_load_path.txt).  Rows
-// whose length is not a whole number of 4-load batches (D * elem % 4096 != 0) take the builtin path.
+// of whole 2 KiB batches use 2 loads per batch (D = 1536: +6 %); anything else (D * elem % 2048 != 0) takes the builtin path.
 // CHIP_SCAN_VARIANT >= 2: further A/B variants, only in builds with -DCHIP_SCAN_TUNING_VARIANTS.
 template <typename T, int NQ>
 static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds, int block)
@@ -292,7 +292,11 @@ static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, siz
         default: break;
     }
 #endif
-    if (c->scan_variant != 1 && (int64_t)a.D * sizeof(T) % 4096 == 0) return launch_scan_k<T, NQ, 4, true, 6, 1>(c, s, a, grid, lds, block);
+    if (c->scan_variant != 1) {   // rows of whole 4 KiB / 2 KiB batches (one load per batch measured slower than the builtin path)
+        const int64_t row_bytes = (int64_t)a.D * sizeof(T);
+        if (row_bytes % 4096 == 0) return launch_scan_k<T, NQ, 4, true, 6, 1>(c, s, a, grid, lds, block);
+        if (row_bytes % 2048 == 0) return launch_scan_k<T, NQ, 2, true, 6, 1>(c, s, a, grid, lds, block);
+    }
     return launch_scan_t<T, NQ, 8, 1, 1>(c, s, a, grid, lds, block);
 }
 
