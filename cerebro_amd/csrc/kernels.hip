@@ -377,7 +377,7 @@ __global__ __launch_bounds__(512) void db_scan_scores(ScanArgs a, double *out)
     for (int64_t r = (int64_t)blockIdx.x * wpb + wave; r < a.n_rows; r += tw) {
         const T *row[1] = {row_base<T>(a, r)};
         double acc[1][1];
-        rows_dot<T, 1, 4, FULL, 1, 1>(row, qs, a.D, lane, acc);
+        rows_dot<T, 1, 4, FULL, FULL ? 6 : 1, 1>(row, qs, a.D, lane, acc);   // whole 4 KiB batches: the asm load path of K1
         const double s = butterfly_sum(acc[0][0]);
         if (lane == 0) out[r] = s;
     }
