@@ -287,7 +287,8 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
     a.idx_mul = c->nranks;
     a.idx_add = c->nranks == 1 ? 0 : c->rank;
     a.partial = c->partial_dev[b];
-    const int grid = scan_grid_for(c, a.n_rows, nq);
+    a.q64 = scan_q64(c, nq, !short_scan) ? 1 : 0;
+    const int grid = scan_grid_for(c, a.n_rows, nq, a.q64 != 0);
 
     // The merge that last read this buffer ran kRing ticks ago; only when it is not already complete (a stalled ctx
     // stream) does the scan stream need a barrier packet -- in steady state this costs nothing.

@@ -25,6 +25,7 @@ struct ScanArgs {
     const void *q[CHIP_MAX_NQ];     // query descriptors (device, storage type, D each, 16-B aligned)
     int64_t idx_mul, idx_add;       // global index = local * idx_mul + idx_add  (round-robin shard map)
     chip_topk_entry *partial;       // [gridDim.x][NQ][K]
+    int32_t q64 = 0;                // queries staged in LDS as fp64 (scan_q64)
 };
 
 struct MergeArgs {
@@ -43,7 +44,8 @@ struct Ctx;
 // kernels.hip
 int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid);
 int launch_merge(Ctx *c, hipStream_t s, const MergeArgs &a, int nq);
-int scan_grid_for(const Ctx *c, int64_t n_rows, int nq);
+int scan_grid_for(const Ctx *c, int64_t n_rows, int nq, bool q64);
+bool scan_q64(const Ctx *c, int nq, bool long_scan);
 int launch_scores(Ctx *c, hipStream_t s, const ScanArgs &a, double *out_dev);   // K1s: all scores of one query, out[local row]
 int launch_store_rows(Ctx *c, hipStream_t s, const void *src, int src_elem, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring);
 int launch_synth(Ctx *c, hipStream_t s, int64_t first_global, int64_t n, uint64_t seed,

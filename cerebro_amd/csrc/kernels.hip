@@ -73,7 +73,7 @@ __device__ __forceinline__ void rows_dot(const T *const (&row)[R], const T *qs, 
         for (int q = 0; q < NQ; q++) acc[rr][q] = 0.0;
     for (int base = 0; base < D; base += CH * U) {
         V v[R][U];
-        if constexpr (NT == 6) {
+        if constexpr (NT == 6 || NT == 8) {
             // all R*U loads of the batch issued back to back from one address register pair (immediate offsets), consumed
             // below behind COUNTED waits: hipcc's scheduler otherwise sinks the loads next to their uses (register pressure)
             // and the wave runs with 1-2 KiB in flight instead of U KiB
@@ -95,7 +95,7 @@ __device__ __forceinline__ void rows_dot(const T *const (&row)[R], const T *qs, 
             }
         }
         }
-        if constexpr (NT >= 2 && NT != 6) {   // inline-asm loads: the compiler does not track them
+        if constexpr (NT >= 2 && NT != 6 && NT != 8) {   // inline-asm loads: the compiler does not track them
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int rr = 0; rr < R; rr++)
@@ -105,11 +105,29 @@ __device__ __forceinline__ void rows_dot(const T *const (&row)[R], const T *qs, 
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int e = base + u * CH + e0;
-            if constexpr (NT == 6) {
+            if constexpr (NT == 6 || NT == 8) {
 #pragma unroll
                 for (int rr = 0; rr < R; rr++)   // loads return in order: load (rr, u) is done once at most this many are outstanding
                     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[rr][u]) : "n"((R - 1 - rr) * U + (U - 1 - u) < 63 ? (R - 1 - rr) * U + (U - 1 - u) : 63) : "memory");
             }
+            if constexpr (NT == 8) {
+                // queries staged as fp64 (scan_q64): per 64 vectors of 4 elements [64 x (d0, d1)][64 x (d2, d3)] = 2 KiB,
+                // read as two conflict-free 16-B loads per lane; the products are the same exact fp64 values as (double)w * (double)v
+                const char *q64 = reinterpret_cast<const char *>(qs);
+                const int t = e >> 2;                                   // vector index of this lane
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const char *blk = q64 + (size_t)q * D * 8 + (size_t)(t >> 6) * 2048 + (t & 63) * 16;
+                    const f64x2 wl = *reinterpret_cast<const f64x2 *>(blk), wh = *reinterpret_cast<const f64x2 *>(blk + 1024);
+#pragma unroll
+                    for (int rr = 0; rr < R; rr++) {
+                        acc[rr][q] = __builtin_fma(wl[0], (double)v[rr][u][0], acc[rr][q]);
+                        acc[rr][q] = __builtin_fma(wl[1], (double)v[rr][u][1], acc[rr][q]);
+                        acc[rr][q] = __builtin_fma(wh[0], (double)v[rr][u][2], acc[rr][q]);
+                        acc[rr][q] = __builtin_fma(wh[1], (double)v[rr][u][3], acc[rr][q]);
+                    }
+                }
+            } else
             if (FULL || e < D) {
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
@@ -164,7 +182,21 @@ __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
     const int wpb = blockDim.x >> 6;
 
     // stage the query descriptors once per block (L2-resident after the first block)
-    stage_queries<T, NQ>(a, qs, tid, blockDim.x);
+    if constexpr (NT == 8) {
+        char *q64 = reinterpret_cast<char *>(smem);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const float *src = static_cast<const float *>(a.q[q]);
+            for (int t = tid; t < (a.D >> 2); t += blockDim.x) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(src + 4 * t);
+                char *blk = q64 + (size_t)q * a.D * 8 + (size_t)(t >> 6) * 2048 + (t & 63) * 16;
+                *reinterpret_cast<f64x2 *>(blk) = (f64x2){(double)w[0], (double)w[1]};
+                *reinterpret_cast<f64x2 *>(blk + 1024) = (f64x2){(double)w[2], (double)w[3]};
+            }
+        }
+    } else {
+        stage_queries<T, NQ>(a, qs, tid, blockDim.x);
+    }
     __syncthreads();
 
     // per-wave running top-K: lane j < K holds the j-th best (score desc, index desc)
@@ -292,6 +324,9 @@ static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, siz
         default: break;
     }
 #endif
+    if constexpr (sizeof(T) == 4) {
+        if (a.q64) return launch_scan_k<T, NQ, 4, true, 8, 1>(c, s, a, grid, lds, block);   // scan_q64() said so (float rows only)
+    }
     if (c->scan_variant != 1) {   // rows of whole 4 KiB / 2 KiB batches (one load per batch measured slower than the builtin path)
         const int64_t row_bytes = (int64_t)a.D * sizeof(T);
         if (row_bytes % 4096 == 0) return launch_scan_k<T, NQ, 4, true, 6, 1>(c, s, a, grid, lds, block);
@@ -304,25 +339,35 @@ static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, siz
 // 2 workgroups x 512 threads per CU while two copies fit in the 160 KiB (D = 4096 fp32: 48 KiB each), else 1 x 1024 threads
 // (D = 8192 fp32, the reference's default model, or D = 4096 fp64: 96 KiB) -- the same 16 waves per CU either way
 // (measured: 6.7 TB/s vs 5.5 with 512 x 1).  CHIP_SCAN_BLOCK / CHIP_SCAN_BPC override (tuning only).
-static size_t scan_lds_bytes(const Ctx *c, int nq, int K, int block)
+static size_t scan_lds_bytes(const Ctx *c, int nq, int K, int block, bool q64)
 {
-    const size_t lds_q = (size_t)nq * c->D * c->elem;
+    const size_t lds_q = (size_t)nq * c->D * (q64 ? 8 : c->elem);
     const size_t lds_m = (size_t)(block / 64) * nq * K * sizeof(chip_topk_entry);
     return lds_q > lds_m ? lds_q : lds_m;
 }
 
-static void scan_shape(const Ctx *c, int nq, int *block, int *bpc)
+static void scan_shape(const Ctx *c, int nq, bool q64, int *block, int *bpc)
 {
     if (c->scan_block > 0) { *block = c->scan_block; *bpc = c->scan_blocks_per_cu; return; }
-    const bool two_fit = 2 * (scan_lds_bytes(c, nq, CHIP_MAX_TOPK, 512) + 1024) <= 160 * 1024;
+    const bool two_fit = 2 * (scan_lds_bytes(c, nq, CHIP_MAX_TOPK, 512, q64) + 1024) <= 160 * 1024;
     *block = two_fit ? 512 : 1024;
     *bpc = two_fit ? 2 : 1;
 }
 
-int scan_grid_for(const Ctx *c, int64_t n_rows, int nq)
+// Queries staged in LDS as fp64 (NT == 8: no per-row conversion of the query side, 21 instead of 34 VALU instructions per KiB
+// of DB) for LONG scans of float rows: 8 bytes per query element make it one 1024-thread workgroup per CU, whose per-launch
+// cost (96 KiB of staging per workgroup) only pays off on launches long enough to run alone on the scan stream -- measured
+// +1.0-1.1 % at 750k / 1M rows, -0.5 .. -6 % at 500k .. 100k rows.  Same arithmetic, same bits.  CHIP_SCAN_VARIANT=1 / 7 disable it.
+bool scan_q64(const Ctx *c, int nq, bool long_scan)
+{
+    return long_scan && c->elem == 4 && c->scan_variant != 1 && c->scan_variant != 7 && (int64_t)c->D * 4 % 4096 == 0 &&
+           (size_t)nq * c->D * 8 <= 150 * 1024;
+}
+
+int scan_grid_for(const Ctx *c, int64_t n_rows, int nq, bool q64)
 {
     int block, bpc;
-    scan_shape(c, nq, &block, &bpc);
+    scan_shape(c, nq, q64, &block, &bpc);
     const int wpb = block / 64;
     int64_t want = (n_rows + wpb - 1) / wpb;
     // scan_reserve leaves workgroup slots free for the small kernels.  With the round-1 load path a full grid held every
@@ -354,8 +399,8 @@ static int launch_scan_T(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int g
 int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid)
 {
     int block, bpc;
-    scan_shape(c, nq, &block, &bpc);
-    const size_t lds = scan_lds_bytes(c, nq, a.K, block);
+    scan_shape(c, nq, a.q64 != 0, &block, &bpc);
+    const size_t lds = scan_lds_bytes(c, nq, a.K, block, a.q64 != 0);
     if (lds > 160 * 1024 || grid > 512) return CHIP_ERR_UNSUPPORTED;  // K2 holds one partial list per thread
     return c->elem == 8 ? launch_scan_T<double>(c, s, a, nq, grid, lds, block) : launch_scan_T<float>(c, s, a, nq, grid, lds, block);
 }

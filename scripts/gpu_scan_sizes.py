@@ -19,7 +19,8 @@ chip = capi.Chip(D, capacity_hint=1_001_500)
 chip.append_synthetic(1_001_500, bench.SEED, [(1_000_200, 4321, 1), (1_000_201, 99_000, 1)])
 got = [chip.query_rows(k, [1_000_200, 1_000_201, 1_000_202], 8) for k in (1_000_000, 100_003, 777, 17)]
 chk = hash(tuple(np.concatenate([np.concatenate([a[0].view(np.int64).ravel(), a[1].ravel()]) for a in got]).tolist()))
-for rows, n in ((1_000_000, 110), (500_000, 200), (125_000, 300), (100_000, 300), (10_000, 600)):
+sizes = os.environ.get("SIZES")
+for rows, n in ([(int(x), max(60, min(600, 120_000_000 // int(x)))) for x in sizes.split(",")] if sizes else ((1_000_000, 110), (500_000, 200), (125_000, 300), (100_000, 300), (10_000, 600))):
     ls = [rows + bench.LAG + 3 * i for i in range(n)]
     chip.loop_reset()
     bench.run_ticks(chip, ls[:20], params, 16)
