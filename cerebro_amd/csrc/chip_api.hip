@@ -196,6 +196,10 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     c->scan_blocks_per_cu = env_int("CHIP_SCAN_BPC", 2);
     if (c->scan_blocks_per_cu < 1) c->scan_blocks_per_cu = 1;
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);
+    c->scan_rows = env_int("CHIP_SCAN_ROWS", 0);
+    c->tick_same_stream = env_int("CHIP_TICK_SAME_STREAM", 1) != 0;
+    c->scan_rows_auto_max = env_int("CHIP_SCAN_ROWS_AUTO_MAX", 8);
+    c->scan_plain_bytes = (double)env_int("CHIP_SCAN_PLAIN_MIB", 192) * 1024 * 1024;
     c->scan_overlap_bytes = (double)env_int("CHIP_SCAN_OVERLAP_GIB", 8) * 1024 * 1024 * 1024;
     // a sharded ctx gets three small kernels per tick through its ctx stream underneath the scans: keep slots free for them
     c->scan_reserve = env_int("CHIP_SCAN_RESERVE", c->nranks > 1 ? 4 : 0);
@@ -266,7 +270,7 @@ int ctx_create(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device,
 // [nq][K]; res (optional) the decision record of Cerebro.cpp:1056.  Consecutive calls pipeline: scans run back to
 // back on s_scan while the previous merge (and whatever the caller enqueues after it on the ctx stream) proceeds.
 int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, int64_t l,
-                       const chip_dot_params *p, chip_topk_entry *out, chip_tick_result *res, bool tick)
+                       const chip_dot_params *p, chip_topk_entry *out, chip_tick_result *res, bool tick, hipStream_t *merge_stream)
 {
     const int b = (int)(c->n_enqueued++ % Ctx::kRing);
     // Ticks (queries already resident) over a short prefix alternate between two scan streams so that the ramp-down of
@@ -289,6 +293,8 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
     a.partial = c->partial_dev[b];
     a.q64 = scan_q64(c, nq, !short_scan) ? 1 : 0;
     const int grid = scan_grid_for(c, a.n_rows, nq, a.q64 != 0);
+    a.rows_form = scan_rows_form(c, a.n_rows, nq, grid, a.q64 != 0);
+    a.plain_loads = (double)a.n_rows * c->D * c->elem <= c->scan_plain_bytes ? 1 : 0;
 
     // The merge that last read this buffer ran kRing ticks ago; only when it is not already complete (a stalled ctx
     // stream) does the scan stream need a barrier packet -- in steady state this costs nothing.
@@ -311,9 +317,19 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
     int rc = launch_scan(c, s_scan, a, nq, grid);
     if (rc != CHIP_OK) return rc;
     if (e1) CHIP_HIP(c, hipEventRecord(e1, s_scan));
-    CHIP_HIP(c, hipEventRecord(c->ev_scan[b], s_scan));
-    if (c->ring_dev) c->last_scan_ev[s_scan == c->s_scan2 ? 1 : 0] = c->ev_scan[b];   // caller holds ring_mu (RingGuard)
-    CHIP_HIP(c, hipStreamWaitEvent(c->s_query, c->ev_scan[b], 0));
+    // Short ticks of a plain single-GPU ctx keep the merge on the scan's OWN stream: the tick is then two launches and two event
+    // records on one stream (no cross-stream event pair), and because consecutive ticks alternate between the two scan streams,
+    // merge(i) still overlaps scan(i+1).  At 10k rows the tick is host-enqueue-bound otherwise (round 2: 21-34 us of API calls per
+    // tick against a ~20 us kernel).  Anything with an exchange, an external ctx stream or profiling keeps the ctx-stream merge.
+    const bool same_stream = tick && short_scan && !c->prof_on && c->nranks == 1 && !c->xchg && !c->parent && c->own_query_stream &&
+                             c->s_scan2 && merge_stream && c->tick_same_stream;
+    hipStream_t s_merge = same_stream ? s_scan : c->s_query;
+    if (merge_stream) *merge_stream = s_merge;
+    if (!same_stream) {
+        CHIP_HIP(c, hipEventRecord(c->ev_scan[b], s_scan));
+        if (c->ring_dev) c->last_scan_ev[s_scan == c->s_scan2 ? 1 : 0] = c->ev_scan[b];   // caller holds ring_mu (RingGuard)
+        CHIP_HIP(c, hipStreamWaitEvent(c->s_query, c->ev_scan[b], 0));
+    }
 
     MergeArgs m;
     m.in = c->partial_dev[b];
@@ -324,9 +340,9 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
     m.l = l;
     m.locality = p ? p->locality : 0;
     m.thresh = p ? p->thresh : 0.0;
-    rc = launch_merge(c, c->s_query, m, nq);
+    rc = launch_merge(c, s_merge, m, nq);
     if (rc != CHIP_OK) return rc;
-    CHIP_HIP(c, hipEventRecord(c->ev_merged[b], c->s_query));
+    CHIP_HIP(c, hipEventRecord(c->ev_merged[b], s_merge));
     return CHIP_OK;
 }
 
@@ -438,9 +454,10 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
         RingGuard rg(c);
         rc = query_row_ptrs(c, rows, 3, l, q);
         if (rc != CHIP_OK) return rc;
-        rc = enqueue_scan_merge(c, k, q, 3, CHIP_DEFAULT_TOPK, l, p, nullptr, s.dev, true);
+        hipStream_t s_done = c->s_query;
+        rc = enqueue_scan_merge(c, k, q, 3, CHIP_DEFAULT_TOPK, l, p, nullptr, s.dev, true, &s_done);
         if (rc != CHIP_OK) return rc;
-        CHIP_HIP(c, hipEventRecord(s.done, c->s_query));
+        CHIP_HIP(c, hipEventRecord(s.done, s_done));
         s.immediate = false;
         s.in_flight = true;
     }
@@ -809,7 +826,7 @@ static int query_common(chip_ctx *c, int64_t k, const int64_t *query_rows, const
     rc = query_rows ? query_row_ptrs(c, query_rows, nq, n, q) : upload_query_vectors(c, vectors, vec_elem, nq, q);
     if (rc != CHIP_OK) return rc;
     if (c->xchg) return xchg_query(c, k, q, nq, topk, scores, idx);   // every rank must make the same call
-    rc = enqueue_scan_merge(c, k, q, nq, topk, 0, nullptr, c->topk_dev, nullptr, false);
+    rc = enqueue_scan_merge(c, k, q, nq, topk, 0, nullptr, c->topk_dev, nullptr, false, nullptr);
     if (rc != CHIP_OK) return rc;
     return sync_topk_out(c, nq, topk, scores, idx);
 }
@@ -917,7 +934,7 @@ int chip_scan_local(chip_ctx *c, int64_t l, const chip_dot_params *p, int32_t to
     // scan on s_scan, then (behind an event) the local merge on the ctx stream writes this rank's 3 x topk list to
     // dev_out: everything the caller enqueues next on the ctx stream (the all-gather) is ordered after it, while the
     // next tick's scan is free to start as soon as this scan ends.
-    rc = enqueue_scan_merge(c, k, q, 3, topk, l, nullptr, (chip_topk_entry *)dev_out, nullptr, true);
+    rc = enqueue_scan_merge(c, k, q, 3, topk, l, nullptr, (chip_topk_entry *)dev_out, nullptr, true, nullptr);
     if (rc == CHIP_OK) c->last_l = l;  // :1098
     return rc;
 }

@@ -26,6 +26,8 @@ struct ScanArgs {
     int64_t idx_mul, idx_add;       // global index = local * idx_mul + idx_add  (round-robin shard map)
     chip_topk_entry *partial;       // [gridDim.x][NQ][K]
     int32_t q64 = 0;                // queries staged in LDS as fp64 (scan_q64)
+    int32_t rows_form = 0;          // > 0: row-batched kernel with this many rows per wave in flight (scan_rows_form)
+    int32_t plain_loads = 0;        // row-batched kernel: temporal loads (the prefix fits the Infinity Cache and is re-read every tick)
 };
 
 struct MergeArgs {
@@ -46,6 +48,7 @@ int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid);
 int launch_merge(Ctx *c, hipStream_t s, const MergeArgs &a, int nq);
 int scan_grid_for(const Ctx *c, int64_t n_rows, int nq, bool q64);
 bool scan_q64(const Ctx *c, int nq, bool long_scan);
+int scan_rows_form(const Ctx *c, int64_t n_rows, int nq, int grid, bool q64);
 int launch_scores(Ctx *c, hipStream_t s, const ScanArgs &a, double *out_dev);   // K1s: all scores of one query, out[local row]
 int launch_store_rows(Ctx *c, hipStream_t s, const void *src, int src_elem, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring);
 int launch_synth(Ctx *c, hipStream_t s, int64_t first_global, int64_t n, uint64_t seed,
@@ -141,6 +144,10 @@ struct Ctx {
     int32_t scan_blocks_per_cu = 2;
     int32_t scan_reserve = 0;
     int32_t scan_variant = 0;
+    bool tick_same_stream = true;  // short ticks of a plain ctx: merge on the scan's stream (CHIP_TICK_SAME_STREAM=0 disables)
+    int32_t scan_rows = 0;        // CHIP_SCAN_ROWS: 0 = auto, 1..3 = row-batched kernel with that R for every scan, -1 = never
+    double scan_plain_bytes = 192.0 * 1024 * 1024;   // prefixes up to this size are read with temporal loads (CHIP_SCAN_PLAIN_MIB)
+    int32_t scan_rows_auto_max = 8;   // auto: row-batched kernel while a wave owns at most this many rows (CHIP_SCAN_ROWS_AUTO_MAX)
     double scan_overlap_bytes = 8.0 * 1024 * 1024 * 1024;   // launches up to this size alternate between the two scan streams (CHIP_SCAN_OVERLAP_GIB)
 
     // --- profiling ---
@@ -194,7 +201,7 @@ int ctx_read_row(Ctx *c, int64_t g, int64_t total, void *out);          // one r
 int query_row_ptrs(Ctx *c, const int64_t *rows, int nq, int64_t n_global, const void **q);
 int upload_query_vectors(Ctx *c, const void *queries, int src_elem, int nq, const void **q);   // -> qvec_dev (on s_scan)
 int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, int64_t l, const chip_dot_params *p,
-                       chip_topk_entry *out, chip_tick_result *res, bool tick);
+                       chip_topk_entry *out, chip_tick_result *res, bool tick, hipStream_t *merge_stream);
 int merge_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, const void *dev_gathered, int32_t n_lists, int32_t topk, Slot &s);
 int merge_enqueue_out(Ctx *c, const void *dev_gathered, int32_t n_lists, int nq, int32_t topk, chip_topk_entry *out);
 int tick_prepare(int64_t rows_global, int64_t last_l, int64_t l, const chip_dot_params *p, int32_t *status, int64_t *k_out);

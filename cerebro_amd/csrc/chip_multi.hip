@@ -83,7 +83,7 @@ int xchg_tick_enqueue(Ctx *c, int64_t l, int64_t k, const chip_dot_params *p, Sl
     int rc = query_row_ptrs(c, rows, 3, l, q);
     if (rc != CHIP_OK) return rc;
     const int b = (int)(x->n++ % kXRing);
-    rc = enqueue_scan_merge(c, k, q, 3, K, l, nullptr, x->local(b), nullptr, true);   // scan streams -> local merge on the ctx stream
+    rc = enqueue_scan_merge(c, k, q, 3, K, l, nullptr, x->local(b), nullptr, true, nullptr);   // scan streams -> local merge on the ctx stream
     if (rc != CHIP_OK) return rc;
     CHIP_NCCL(c, ncclAllGather(x->local(b), x->gathered(b), sizeof(chip_topk_entry) * 3 * K, ncclChar, x->comm, c->s_query));
     return merge_enqueue_slot(c, l, p, x->gathered(b), x->world, K, s);               // merge + decision (:1035-1056), every rank
@@ -93,7 +93,7 @@ int xchg_query(Ctx *c, int64_t k, const void *const *q, int nq, int K, double *s
 {
     Exchange *x = c->xchg;
     const int b = (int)(x->n++ % kXRing);
-    int rc = enqueue_scan_merge(c, k, q, nq, K, 0, nullptr, x->local(b), nullptr, false);
+    int rc = enqueue_scan_merge(c, k, q, nq, K, 0, nullptr, x->local(b), nullptr, false, nullptr);
     if (rc != CHIP_OK) return rc;
     CHIP_NCCL(c, ncclAllGather(x->local(b), x->gathered(b), sizeof(chip_topk_entry) * nq * K, ncclChar, x->comm, c->s_query));
     rc = merge_enqueue_out(c, x->gathered(b), x->world, nq, K, c->topk_dev);
@@ -299,7 +299,7 @@ static int sub_scan(Group *G, int g, const GroupScan &j, int b)
     const size_t list = (size_t)j.nq * j.K;
     const bool direct = G->transport == CHIP_EXCHANGE_COPY && G->same_dev[(size_t)g];   // straight into the root's gather buffer
     chip_topk_entry *dst = direct ? root->xchg->gathered(b) + (size_t)g * list : x->local(b);
-    rc = enqueue_scan_merge(c, j.k, q, j.nq, j.K, j.l, nullptr, dst, nullptr, j.tick);
+    rc = enqueue_scan_merge(c, j.k, q, j.nq, j.K, j.l, nullptr, dst, nullptr, j.tick, nullptr);
     if (rc != CHIP_OK) return rc;
     if (G->transport == CHIP_EXCHANGE_RCCL) {
         // one thread per device, each on its own communicator of the clique: the classic multi-threaded NCCL layout (no group call)

@@ -168,6 +168,86 @@ __device__ __forceinline__ const T *row_base(const ScanArgs &a, int64_t r)
     return static_cast<const T *>(a.seg_table[r >> a.seg_shift]) + (r & a.seg_mask) * (int64_t)a.D;
 }
 
+// Per-wave running top-K of one query: lane j < K holds the j-th best (score desc, index desc); (thr_s, thr_i) = the K-th.
+// Offering a candidate is wave-uniform and rare after warm-up; NaN never enters.
+__device__ __forceinline__ void wave_topk_offer(double s, int64_t gi, int K, int lane, double &my_s, int64_t &my_i, double &thr_s, int64_t &thr_i)
+{
+    if (key_gt(s, gi, thr_s, thr_i)) {
+        const bool worse = key_gt(s, gi, my_s, my_i);
+        const unsigned long long m = __ballot(worse) & ((1ull << K) - 1ull);
+        const int pos = __builtin_ctzll(m);
+        const double up_s = __shfl_up(my_s, 1, 64);
+        const int64_t up_i = __shfl_up(my_i, 1, 64);
+        if (lane < K) {
+            if (lane > pos) { my_s = up_s; my_i = up_i; }
+            else if (lane == pos) { my_s = s; my_i = gi; }
+        }
+        thr_s = __shfl(my_s, K - 1, 64);
+        thr_i = __shfl(my_i, K - 1, 64);
+    }
+}
+
+// Block merge: wpb sorted lists of K per query -> one sorted list of K per query in a.partial[blockIdx.x], by waves 0..NQ-1.
+template <int NQ>
+__device__ __forceinline__ void block_merge_store(const ScanArgs &a, char *smem, const double (&my_s)[NQ], const int64_t (&my_i)[NQ],
+                                                  int K, int lane, int wave, int wpb)
+{
+    __syncthreads();  // all waves done with the staged queries; reuse LDS
+    chip_topk_entry *cand = reinterpret_cast<chip_topk_entry *>(smem);  // [wpb][NQ][K]
+    if (lane < K) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            chip_topk_entry t;
+            t.score = my_s[q];
+            t.idx = my_i[q];
+            cand[(wave * NQ + q) * K + lane] = t;
+        }
+    }
+    __syncthreads();
+    for (int q = wave; q < NQ; q += wpb) {
+        const int ncand = wpb * K;  // <= 16 waves * 16 = 256 -> at most 4 per lane
+        double cs[4];
+        int64_t ci[4];
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const int c = lane + 64 * h;
+            if (c < ncand) {
+                const chip_topk_entry t = cand[((c / K) * NQ + q) * K + (c % K)];
+                cs[h] = t.score;
+                ci[h] = t.idx;
+            } else { cs[h] = -INFINITY; ci[h] = -1; }
+        }
+        chip_topk_entry *outp = a.partial + ((int64_t)blockIdx.x * NQ + q) * K;
+        for (int j = 0; j < K; j++) {
+            double bs = cs[0];
+            int64_t bi = ci[0];
+#pragma unroll
+            for (int h = 1; h < 4; h++)
+                if (key_gt(cs[h], ci[h], bs, bi)) { bs = cs[h]; bi = ci[h]; }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const double os = __shfl_xor(bs, m, 64);
+                const int64_t oi = __shfl_xor(bi, m, 64);
+                if (key_gt(os, oi, bs, bi)) { bs = os; bi = oi; }
+            }
+#pragma unroll
+            for (int h = 0; h < 4; h++)
+                if (ci[h] == bi && cs[h] == bs) { cs[h] = -INFINITY; ci[h] = -1; }
+            if (lane == 0) { chip_topk_entry t; t.score = bs; t.idx = bi; outp[j] = t; }
+        }
+    }
+}
+
+// The same for a WAVE-UNIFORM row through the scalar cache: the table is read with s_load (constant address space; entries of
+// published rows never change), so the lookup neither costs a vector-memory round trip nor touches vmcnt.
+template <typename T>
+__device__ __forceinline__ const T *row_base_uniform(const ScanArgs &a, int64_t r)
+{
+    typedef const uint64_t __attribute__((address_space(4))) *ctab;
+    const uint64_t seg = ((ctab)(uintptr_t)a.seg_table)[r >> a.seg_shift];
+    return reinterpret_cast<const T *>((uintptr_t)seg) + (r & a.seg_mask) * (int64_t)a.D;
+}
+
 template <typename T, int NQ, int U, bool FULL, int NT, int R>
 __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
 {
@@ -220,36 +300,76 @@ __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
         for (int q = 0; q < NQ; q++) acc[0][q] = butterfly_sum(acc[0][q]);
         const int64_t gi = r * a.idx_mul + a.idx_add;
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            const double s = acc[0][q];
-            if (key_gt(s, gi, thr_s[q], thr_i[q])) {  // wave-uniform, rare after warm-up; NaN never enters
-                const bool worse = key_gt(s, gi, my_s[q], my_i[q]);
-                const unsigned long long m = __ballot(worse) & ((1ull << K) - 1ull);
-                const int pos = __builtin_ctzll(m);
-                const double up_s = __shfl_up(my_s[q], 1, 64);
-                const int64_t up_i = __shfl_up(my_i[q], 1, 64);
-                if (lane < K) {
-                    if (lane > pos) { my_s[q] = up_s; my_i[q] = up_i; }
-                    else if (lane == pos) { my_s[q] = s; my_i[q] = gi; }
-                }
-                thr_s[q] = __shfl(my_s[q], K - 1, 64);
-                thr_i[q] = __shfl(my_i[q], K - 1, 64);
-            }
-        }
+        for (int q = 0; q < NQ; q++) wave_topk_offer(acc[0][q], gi, K, lane, my_s[q], my_i[q], thr_s[q], thr_i[q]);
     }
 
-    // ---- block merge: wpb sorted lists of K per query -> one sorted list of K, by waves 0..NQ-1 ----
-    __syncthreads();  // all waves done with qs; reuse LDS
-    chip_topk_entry *cand = reinterpret_cast<chip_topk_entry *>(smem);  // [wpb][NQ][K]
-    if (lane < K) {
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            chip_topk_entry t;
-            t.score = my_s[q];
-            t.idx = my_i[q];
-            cand[(wave * NQ + q) * K + lane] = t;
+    block_merge_store<NQ>(a, smem, my_s, my_i, K, lane, wave, wpb);
+}
+
+// ------------------------------------------------------------------------------------------------ K1, row-batched form
+// The same scan with R rows per wave in flight at once and the loads issued as ONE continuous stream (round 3): a wave walks
+// the (pass, 4 KiB batch, load slot u) sequence of its rows and re-issues slot u for the NEXT batch as soon as the fmas that
+// read slot u of the current batch have been issued, so R x 4 KiB per wave stay in flight for the whole scan instead of
+// draining to zero at every batch (db_scan_topk above).  Three things follow for SHORT prefixes (BASELINE config 2: 10 003 rows
+// over 4096 waves = 2.4 rows per wave, which the one-row kernel walks as 12 dependent 4 KiB batches per wave):
+//   * R = 3 turns a wave's whole share into one pass of 4 batches with 12 KiB in flight;
+//   * the queries are staged by LDS-DMA (global_load_lds_dwordx4, no staging VGPRs), issued BEFORE the first row loads and
+//     waited for with a counted vmcnt, so the first 12 KiB of DB rows are already on their way while the queries land;
+//   * each query element is converted to fp64 once per R rows (R = 3: 20 instead of 28 VALU instructions per KiB of DB).
+// Arithmetic and order per (row, query) are those of rows_dot: lane L accumulates elements j*CH + N*L + c, j ascending, into
+// one fp64 accumulator by fma, then the xor butterfly -- bit-identical scores, same (score desc, index desc) lists.
+// Loads use the SGPR-base form (row base in an SGPR pair, one shared 32-bit lane offset), immediate offsets u * 1 KiB.
+// Requires whole 4 KiB batches (D * sizeof(T) % 4096 == 0) and queries that are 16-B aligned rows of D elements.
+__device__ __forceinline__ uint32_t lds_byte_addr(const void *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+// 16 bytes per lane, global -> LDS at (wave-uniform LDS base in M0) + lane * 16; M0 is saved and restored around the load
+__device__ __forceinline__ void glds16_q(const void *gsrc_lane, uint32_t lds_base_wave_uniform)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(lds_base_wave_uniform)
+                 : "memory");
+}
+
+// a wave-uniform pointer the compiler cannot prove uniform (it came out of the segment table) -> SGPR pair
+template <typename P>
+__device__ __forceinline__ const P *uniform_ptr(const P *p)
+{
+    const uint64_t b = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+    return reinterpret_cast<const P *>((uintptr_t)(((uint64_t)hi << 32) | lo));
+}
+
+// The running top-K lists of the row-batched kernel live in LDS ([wave][query][CHIP_MAX_TOPK] entries behind the staged
+// queries), only the admission threshold (the K-th entry) stays in SGPRs: after warm-up an offer is rare, and lists held in
+// VGPRs (as in db_scan_topk) would cost 4 NQ registers of a kernel that keeps R x 16 of them in flight as load targets.
+__device__ __forceinline__ void wave_topk_offer_lds(double s, int64_t gi, int K, int lane, chip_topk_entry *list, double &thr_s, int64_t &thr_i)
+{
+    if (key_gt(s, gi, thr_s, thr_i)) {   // wave-uniform; NaN never enters
+        chip_topk_entry me, up;
+        me.score = -INFINITY; me.idx = -1; up = me;
+        if (lane < K) { me = list[lane]; if (lane > 0) up = list[lane - 1]; }
+        const bool worse = key_gt(s, gi, me.score, me.idx);
+        const unsigned long long m = __ballot(worse) & ((1ull << K) - 1ull);
+        const int pos = __builtin_ctzll(m);
+        if (lane < K) {
+            if (lane > pos) me = up;
+            else if (lane == pos) { me.score = s; me.idx = gi; }
+            list[lane] = me;      // every read of the old list precedes this write in program order (one wave, in-order LDS)
         }
+        thr_s = readlane_f64(me.score, K - 1);
+        thr_i = readlane_i64(me.idx, K - 1);
     }
+}
+
+// Block merge over the LDS lists: wpb sorted lists of K per query -> one sorted list of K per query in a.partial[blockIdx.x].
+template <int NQ>
+__device__ __forceinline__ void block_merge_lists(const ScanArgs &a, const chip_topk_entry *lists, int K, int lane, int wave, int wpb)
+{
     __syncthreads();
     for (int q = wave; q < NQ; q += wpb) {
         const int ncand = wpb * K;  // <= 16 waves * 16 = 256 -> at most 4 per lane
@@ -259,7 +379,7 @@ __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
         for (int h = 0; h < 4; h++) {
             const int c = lane + 64 * h;
             if (c < ncand) {
-                const chip_topk_entry t = cand[((c / K) * NQ + q) * K + (c % K)];
+                const chip_topk_entry t = lists[((c / K) * NQ + q) * CHIP_MAX_TOPK + (c % K)];
                 cs[h] = t.score;
                 ci[h] = t.idx;
             } else { cs[h] = -INFINITY; ci[h] = -1; }
@@ -283,6 +403,206 @@ __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
             if (lane == 0) { chip_topk_entry t; t.score = bs; t.idx = bi; outp[j] = t; }
         }
     }
+}
+
+// Load targets of db_scan_topk_rows.  The loads are issued from inline asm and consumed behind counted s_waitcnt -- a register
+// that the compiler believed "defined" at the load statement could be copied or spilled by it BEFORE the wait (it happened: the
+// first version of this kernel, with "=v" outputs, got v_mov copies of in-flight registers at a control-flow merge).  So the
+// targets are PHYSICAL registers the compiler does not own: the kernel is compiled with amdgpu_num_vgpr(kRowsVgprBase / 2) -- on
+// gfx950's unified VGPR/AGPR file hipcc (ROCm 7.2) takes that attribute as HALF the ArchVGPR budget (measured: 24 -> 48, 32 -> 64,
+// 40 -> 80 registers, spilling beyond) -- which leaves v[kRowsVgprBase ..] to the asm statements; a load names its target
+// literally, and the statement that waits for it also moves the data (converted to fp64 for float rows) into compiler-owned
+// outputs -- wait and first read are one asm block.  tests/test_codeobj_registers.py disassembles the built library and checks
+// the partition: nothing but these loads writes v[80..127], nothing but the take statements reads them.
+constexpr int kRowsVgprBase = 80;
+#define CHIP_ROWS_CLOBBERS                                                                                                      \
+    "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97",   \
+    "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", \
+    "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+
+// slot (u, rr) of an R-row batch -> v[base : base + 3]
+template <int R> __host__ __device__ constexpr int rows_slot_reg(int u, int rr) { return kRowsVgprBase + 4 * (u * R + rr); }
+
+template <bool NTL, int REG, int OFF>
+__device__ __forceinline__ void rows_issue(uint32_t voff, const void *row_uniform)
+{
+    if constexpr (NTL)   // non-temporal: a stream that is read once (prefixes beyond the Infinity Cache)
+        asm volatile("global_load_dwordx4 v[%2:%3], %0, %1 offset:%4 nt" ::"v"(voff), "s"(row_uniform), "n"(REG), "n"(REG + 3), "n"(OFF) : "memory");
+    else                 // temporal: a prefix that fits the 256 MiB Infinity Cache is re-read by every tick
+        asm volatile("global_load_dwordx4 v[%2:%3], %0, %1 offset:%4" ::"v"(voff), "s"(row_uniform), "n"(REG), "n"(REG + 3), "n"(OFF) : "memory");
+}
+
+// wait until at most CNT vector-memory operations are outstanding, then hand one 8-byte HALF (H = 0, 1) of the slot's 16 bytes
+// to the compiler as fp64: two elements of a float row, one of a double row (halves keep the compiler-side live set small)
+template <int REG, int CNT, int H>
+__device__ __forceinline__ void rows_take(double (&d)[2], float)
+{
+    asm volatile("s_waitcnt vmcnt(%2)\n\tv_cvt_f64_f32 %0, v[%3]\n\tv_cvt_f64_f32 %1, v[%4]"
+                 : "=&v"(d[0]), "=&v"(d[1])
+                 : "n"(CNT), "n"(REG + 2 * H), "n"(REG + 2 * H + 1)
+                 : "memory");
+}
+template <int REG, int CNT, int H>
+__device__ __forceinline__ void rows_take(double (&d)[2], double)
+{
+    asm volatile("s_waitcnt vmcnt(%1)\n\tv_mov_b64 %0, v[%2:%3]" : "=&v"(d[0]) : "n"(CNT), "n"(REG + 2 * H), "n"(REG + 2 * H + 1) : "memory");
+    d[1] = 0.0;
+}
+
+template <typename T, int NQ, int R, bool NTL>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase / 2))) void db_scan_topk_rows(ScanArgs a)
+{
+    typedef typename Vec16<T>::type V;
+    constexpr int N = Vec16<T>::N, CH = 64 * N, U = 4;
+    static_assert(kRowsVgprBase + 16 * R <= 128, "load targets beyond the 128 VGPRs of a 16-waves-per-CU kernel");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    asm volatile("" ::: CHIP_ROWS_CLOBBERS);                       // makes the code object allocate the asm-owned registers
+    const T *qs = reinterpret_cast<const T *>(smem);  // [NQ][D]
+    const int D = a.D;
+    const int K = a.K;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wpb = blockDim.x >> 6;
+    const int64_t tw = (int64_t)gridDim.x * wpb;
+    const int64_t g = (int64_t)blockIdx.x * wpb + wave;           // this wave's first row (same row -> wave map as db_scan_topk)
+    const int nb = D / (CH * U);                                   // 4 KiB batches per row
+    const int npass = g < a.n_rows ? (int)((a.n_rows - 1 - g) / (R * tw)) + 1 : 0;
+    const int total = npass * nb;                                  // batches this wave consumes (wave-uniform)
+
+    // ---- queries -> LDS by LDS-DMA, 1 KiB per wave-instruction, chunks dealt round robin to the waves ----
+    {
+        const int cpq = (int)((size_t)D * sizeof(T) / 1024);
+        const uint32_t lds0 = lds_byte_addr(smem);
+        for (int i = wave; i < NQ * cpq; i += wpb) {
+            const int q = i / cpq, ch = i - q * cpq;
+            glds16_q(static_cast<const char *>(a.q[q]) + (size_t)ch * 1024 + lane * 16, lds0 + (uint32_t)i * 1024u);
+        }
+    }
+
+    const T *row[R];                                               // bases of the rows the NEXT issue reads (wave-uniform, SGPRs)
+    const uint32_t lane_off = (uint32_t)(lane * 16);
+    auto set_rows = [&](int pass) {
+        const int64_t r0 = g + (int64_t)pass * R * tw;
+#pragma unroll
+        for (int rr = 0; rr < R; rr++) {
+            const int64_t r = r0 + rr * tw;
+            row[rr] = uniform_ptr(row_base_uniform<T>(a, r < a.n_rows ? r : r0));   // a missing row re-reads the pass's first row; its result is dropped
+        }
+    };
+    // load slot u of every row of the batch at byte offset byte_off of the rows
+#define CHIP_ROWS_ISSUE_SLOT(u, byte_off)                                                                               \
+    do {                                                                                                                \
+        const uint32_t vo_ = (byte_off) + lane_off;                                                                     \
+        rows_issue<NTL, rows_slot_reg<R>(u, 0), (u) * 1024>(vo_, row[0]);                                               \
+        if constexpr (R > 1) rows_issue<NTL, rows_slot_reg<R>(u, R > 1 ? 1 : 0), (u) * 1024>(vo_, row[R > 1 ? 1 : 0]);  \
+        if constexpr (R > 2) rows_issue<NTL, rows_slot_reg<R>(u, R > 2 ? 2 : 0), (u) * 1024>(vo_, row[R > 2 ? 2 : 0]);  \
+    } while (0)
+
+    if (total > 0) {
+        set_rows(0);
+        CHIP_ROWS_ISSUE_SLOT(0, 0u); CHIP_ROWS_ISSUE_SLOT(1, 0u); CHIP_ROWS_ISSUE_SLOT(2, 0u); CHIP_ROWS_ISSUE_SLOT(3, 0u);
+        // the LDS-DMA loads are older than the R*U row loads: "at most R*U outstanding" == the queries have landed
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(R * U) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // running top-K lists: LDS behind the queries (this wave's NQ lists are touched by this wave only)
+    chip_topk_entry *lists = reinterpret_cast<chip_topk_entry *>(smem + (size_t)NQ * D * sizeof(T));
+    chip_topk_entry *mylists = lists + (size_t)wave * NQ * CHIP_MAX_TOPK;
+    double thr_s[NQ];
+    int64_t thr_i[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        thr_s[q] = -INFINITY; thr_i[q] = -1;
+        if (lane < CHIP_MAX_TOPK) { chip_topk_entry t; t.score = -INFINITY; t.idx = -1; mylists[q * CHIP_MAX_TOPK + lane] = t; }
+    }
+
+    double acc[R][NQ];
+#pragma unroll
+    for (int rr = 0; rr < R; rr++)
+#pragma unroll
+        for (int q = 0; q < NQ; q++) acc[rr][q] = 0.0;
+
+    // Slot u of the current batch: wait for its R loads (CNT0 + R-1-rr operations may stay outstanding behind row rr's), take the
+    // data as fp64 and run the fmas of elements base + u*CH + N*lane + c against the staged queries.  Element-major, so one
+    // query element is converted once and used by every row; per (row, query) the order is c ascending -- rows_dot's order.
+#define CHIP_ROWS_FMA_HALF(u, h, CNT0)                                                                                   \
+    do {                                                                                                                \
+        double vd_[R][2];                                                                                               \
+        rows_take<rows_slot_reg<R>(u, 0), (CNT0) + R - 1, h>(vd_[0], T());                                              \
+        if constexpr (R > 1) rows_take<rows_slot_reg<R>(u, R > 1 ? 1 : 0), (CNT0) + R - 2, h>(vd_[R > 1 ? 1 : 0], T()); \
+        if constexpr (R > 2) rows_take<rows_slot_reg<R>(u, R > 2 ? 2 : 0), (CNT0) + R - 3, h>(vd_[R > 2 ? 2 : 0], T()); \
+        _Pragma("unroll") for (int c = 0; c < N / 2; c++) {                                                             \
+            double wd_[NQ];                                                                                             \
+            _Pragma("unroll") for (int q = 0; q < NQ; q++) wd_[q] = (double)w_[q][(h) * (N / 2) + c];                   \
+            _Pragma("unroll") for (int rr = 0; rr < R; rr++)                                                            \
+                _Pragma("unroll") for (int q = 0; q < NQ; q++) acc[rr][q] = __builtin_fma(wd_[q], vd_[rr][c], acc[rr][q]); \
+        }                                                                                                               \
+    } while (0)
+#define CHIP_ROWS_FMA_SLOT(u, base, CNT0)                                                                               \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        const int e_ = (base) + (u) * CH + lane * N;                                                                    \
+        V w_[NQ];                                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < NQ; q++) w_[q] = *reinterpret_cast<const V *>(qs + q * D + e_);           \
+        CHIP_ROWS_FMA_HALF(u, 0, CNT0);                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        CHIP_ROWS_FMA_HALF(u, 1, CNT0);                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+
+    int pass = 0, b = 0;
+    for (int t = 0; t < total; t++) {
+        const int base = b * (CH * U);
+        if (t + 1 < total) {
+            // steady state: slot (u, rr) has (U-1)*R + (R-1-rr) younger loads behind it whatever u is (the slots of the next
+            // batch issued so far take the place of the slots of this batch already consumed)
+            int nbase = base + CH * U;
+            if (b + 1 == nb) { nbase = 0; set_rows(pass + 1); }
+            const uint32_t noff = (uint32_t)nbase * (uint32_t)sizeof(T);
+            CHIP_ROWS_FMA_SLOT(0, base, (U - 1) * R); CHIP_ROWS_ISSUE_SLOT(0, noff);
+            CHIP_ROWS_FMA_SLOT(1, base, (U - 1) * R); CHIP_ROWS_ISSUE_SLOT(1, noff);
+            CHIP_ROWS_FMA_SLOT(2, base, (U - 1) * R); CHIP_ROWS_ISSUE_SLOT(2, noff);
+            CHIP_ROWS_FMA_SLOT(3, base, (U - 1) * R); CHIP_ROWS_ISSUE_SLOT(3, noff);
+        } else {
+            // the wave's last batch: nothing is re-issued, the loads behind slot (u, rr) are the rest of this batch
+            CHIP_ROWS_FMA_SLOT(0, base, 3 * R);
+            CHIP_ROWS_FMA_SLOT(1, base, 2 * R);
+            CHIP_ROWS_FMA_SLOT(2, base, 1 * R);
+            CHIP_ROWS_FMA_SLOT(3, base, 0);
+        }
+        if (++b == nb) {   // the rows of this pass are complete: butterfly, offer, next pass
+            const int64_t r0 = g + (int64_t)pass * R * tw;
+#pragma unroll
+            for (int rr = 0; rr < R; rr++) {
+                const int64_t r = r0 + rr * tw;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const double s = butterfly_sum(acc[rr][q]);
+                    acc[rr][q] = 0.0;
+                    if (r < a.n_rows) wave_topk_offer_lds(s, r * a.idx_mul + a.idx_add, K, lane, mylists + q * CHIP_MAX_TOPK, thr_s[q], thr_i[q]);
+                }
+            }
+            b = 0;
+            pass++;
+        }
+    }
+#undef CHIP_ROWS_FMA_SLOT
+#undef CHIP_ROWS_FMA_HALF
+#undef CHIP_ROWS_ISSUE_SLOT
+    block_merge_lists<NQ>(a, lists, K, lane, wave, wpb);
+}
+
+template <typename T, int NQ, int R, bool NTL>
+static int launch_scan_rows(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds, int block)
+{
+    if (lds > 65536) CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_scan_topk_rows<T, NQ, R, NTL>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((db_scan_topk_rows<T, NQ, R, NTL>), dim3(grid), dim3(block), lds, s, a);
+    CHIP_HIP(c, hipGetLastError());
+    return CHIP_OK;
 }
 
 template <typename T, int NQ, int U, bool FULL, int NT, int R>
@@ -327,6 +647,14 @@ static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, siz
     if constexpr (sizeof(T) == 4) {
         if (a.q64) return launch_scan_k<T, NQ, 4, true, 8, 1>(c, s, a, grid, lds, block);   // scan_q64() said so (float rows only)
     }
+    if (a.rows_form > 0) {   // scan_rows_form() said so: whole 4 KiB batches, R rows per wave in one continuous load stream
+        const bool ntl = a.plain_loads == 0;
+        if constexpr (NQ <= 3) {   // (four queries x R > 1 rows of accumulators do not fit the compiler's 80 registers: R = 1 only)
+            if (a.rows_form >= 3) return ntl ? launch_scan_rows<T, NQ, 3, true>(c, s, a, grid, lds, block) : launch_scan_rows<T, NQ, 3, false>(c, s, a, grid, lds, block);
+            if (a.rows_form == 2) return ntl ? launch_scan_rows<T, NQ, 2, true>(c, s, a, grid, lds, block) : launch_scan_rows<T, NQ, 2, false>(c, s, a, grid, lds, block);
+        }
+        return ntl ? launch_scan_rows<T, NQ, 1, true>(c, s, a, grid, lds, block) : launch_scan_rows<T, NQ, 1, false>(c, s, a, grid, lds, block);
+    }
     if (c->scan_variant != 1) {   // rows of whole 4 KiB / 2 KiB batches (one load per batch measured slower than the builtin path)
         const int64_t row_bytes = (int64_t)a.D * sizeof(T);
         if (row_bytes % 4096 == 0) return launch_scan_k<T, NQ, 4, true, 6, 1>(c, s, a, grid, lds, block);
@@ -339,8 +667,9 @@ static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, siz
 // 2 workgroups x 512 threads per CU while two copies fit in the 160 KiB (D = 4096 fp32: 48 KiB each), else 1 x 1024 threads
 // (D = 8192 fp32, the reference's default model, or D = 4096 fp64: 96 KiB) -- the same 16 waves per CU either way
 // (measured: 6.7 TB/s vs 5.5 with 512 x 1).  CHIP_SCAN_BLOCK / CHIP_SCAN_BPC override (tuning only).
-static size_t scan_lds_bytes(const Ctx *c, int nq, int K, int block, bool q64)
+static size_t scan_lds_bytes(const Ctx *c, int nq, int K, int block, bool q64, bool rows_form = false)
 {
+    if (rows_form) return (size_t)nq * c->D * c->elem + (size_t)(block / 64) * nq * CHIP_MAX_TOPK * sizeof(chip_topk_entry);   // queries + running lists
     const size_t lds_q = (size_t)nq * c->D * (q64 ? 8 : c->elem);
     const size_t lds_m = (size_t)(block / 64) * nq * K * sizeof(chip_topk_entry);
     return lds_q > lds_m ? lds_q : lds_m;
@@ -362,6 +691,24 @@ bool scan_q64(const Ctx *c, int nq, bool long_scan)
 {
     return long_scan && c->elem == 4 && c->scan_variant != 1 && c->scan_variant != 7 && (int64_t)c->D * 4 % 4096 == 0 &&
            (size_t)nq * c->D * 8 <= 150 * 1024;
+}
+
+// Row-batched form of K1 (db_scan_topk_rows): R rows per wave in flight.  Returns R (1..3), or 0 for the one-row kernel.
+// Default policy: short scans, where a wave owns only a handful of rows and the one-row kernel is a chain of dependent
+// 4 KiB batches; CHIP_SCAN_ROWS forces R for every scan (1..3) or disables the form (-1).
+int scan_rows_form(const Ctx *c, int64_t n_rows, int nq, int grid, bool q64)
+{
+    if (q64 || c->scan_rows < 0 || c->scan_variant == 1 || (int64_t)c->D * c->elem % 4096 != 0) return 0;
+    int block, bpc;
+    scan_shape(c, nq, false, &block, &bpc);
+    if ((size_t)bpc * scan_lds_bytes(c, nq, CHIP_MAX_TOPK, block, false, true) > 160 * 1024) return 0;   // queries + LDS lists must fit
+    const int64_t waves = (int64_t)grid * (block / 64);
+    const int64_t rpw = (n_rows + waves - 1) / waves;
+    const int rmax = nq >= 4 ? 1 : 3;
+    if (c->scan_rows > 0) return c->scan_rows > rmax ? rmax : c->scan_rows;
+    if (rpw < 1) return 1;
+    if (rpw > c->scan_rows_auto_max) return 0;
+    return rpw >= rmax ? rmax : (int)rpw;
 }
 
 int scan_grid_for(const Ctx *c, int64_t n_rows, int nq, bool q64)
@@ -400,7 +747,7 @@ int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid)
 {
     int block, bpc;
     scan_shape(c, nq, a.q64 != 0, &block, &bpc);
-    const size_t lds = scan_lds_bytes(c, nq, a.K, block, a.q64 != 0);
+    const size_t lds = scan_lds_bytes(c, nq, a.K, block, a.q64 != 0, a.rows_form > 0);
     if (lds > 160 * 1024 || grid > 512) return CHIP_ERR_UNSUPPORTED;  // K2 holds one partial list per thread
     return c->elem == 8 ? launch_scan_T<double>(c, s, a, nq, grid, lds, block) : launch_scan_T<float>(c, s, a, nq, grid, lds, block);
 }

@@ -1,0 +1,114 @@
+"""Build-time guard for the row-batched scan kernel (cerebro_amd/csrc/kernels.hip, db_scan_topk_rows).
+
+Its DB-row loads are issued from inline asm into PHYSICAL registers v[80..127] that the compiler must not own (the kernel is
+compiled with amdgpu_num_vgpr so that hipcc allocates v0..v79 only) and are consumed behind counted `s_waitcnt vmcnt(n)`.
+If a toolchain change let the compiler allocate, copy or spill one of those registers, a wave would read a register whose
+load is still in flight -- silently wrong scores.  This test disassembles the gfx950 code objects of the built
+libcerebro_hip.so and checks the partition instruction by instruction (no GPU needed):
+  * the only instructions that WRITE v[80..127] are the kernel's own global_load_dwordx4;
+  * the only instructions that READ them are the v_cvt_f64_f32 / v_mov_b64 of the take statements;
+  * the steady-state loop carries no scratch (spill) traffic: a kernel may spill loop-invariant values around the loop
+    (a few dwords), never more than a small bound.
+"""
+import re
+import struct
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+SO = ROOT / "cerebro_amd" / "lib" / "libcerebro_hip.so"
+LLVM = Path("/opt/rocm/lib/llvm/bin")
+pytestmark = pytest.mark.needs_hip_build
+
+LO, HI = 80, 127
+
+
+def code_objects(tmp_path):
+    out = subprocess.run([str(LLVM / "llvm-readelf"), "-S", "-W", str(SO)], capture_output=True, text=True, check=True).stdout
+    off = size = None
+    for line in out.splitlines():
+        if ".hip_fatbin" in line:
+            f = line.split()
+            i = f.index(".hip_fatbin")
+            off, size = int(f[i + 3], 16), int(f[i + 4], 16)
+    assert off is not None, "no .hip_fatbin section"
+    data = SO.read_bytes()[off:off + size]
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    pos, paths = 0, []
+    while True:
+        p = data.find(magic, pos)
+        if p < 0:
+            break
+        (n_entries,) = struct.unpack_from("<Q", data, p + 24)
+        q = p + 32
+        for _ in range(n_entries):
+            o, s, ts = struct.unpack_from("<QQQ", data, q)
+            q += 24
+            triple = data[q:q + ts].decode()
+            q += ts
+            if "amdgcn" in triple and s > 0:
+                path = tmp_path / f"co{len(paths)}.elf"
+                path.write_bytes(data[p + o:p + o + s])
+                paths.append(path)
+        pos = p + 24
+    return paths
+
+
+def regs_of(operand):
+    """VGPR numbers named by one operand: v12, v[80:83]; anything else -> empty."""
+    m = re.fullmatch(r"v(\d+)", operand)
+    if m:
+        return [int(m.group(1))]
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", operand)
+    if m:
+        return list(range(int(m.group(1)), int(m.group(2)) + 1))
+    return []
+
+
+@pytest.mark.skipif(not (LLVM / "llvm-objdump").exists(), reason="llvm-objdump not available")
+def test_rows_kernel_register_partition(tmp_path):
+    if not SO.exists():
+        pytest.skip("libcerebro_hip.so not built")
+    kernels = {}
+    for co in code_objects(tmp_path):
+        dis = subprocess.run([str(LLVM / "llvm-objdump"), "-d", "--mcpu=gfx950", "--no-show-raw-insn", str(co)],
+                             capture_output=True, text=True, check=True).stdout
+        cur = None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                cur = m.group(1)
+                if "db_scan_topk_rows" in cur:
+                    kernels[cur] = []
+                continue
+            if cur in kernels and line.strip() and not line.startswith("Disassembly"):
+                kernels[cur].append(line.split("//")[0].strip())
+    assert len(kernels) >= 20, f"expected the db_scan_topk_rows instantiations, found {len(kernels)}"
+    for name, ins in kernels.items():
+        n_loads = n_takes = scratch = 0
+        for text in ins:
+            parts = text.split(None, 1)
+            if not parts:
+                continue
+            op = parts[0]
+            operands = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+            operands = [o.split()[0] if o else o for o in operands]      # drop modifiers (offset:.. nt)
+            if op.startswith("scratch_"):
+                scratch += 1
+            touched = [(i, r) for i, o in enumerate(operands) for r in regs_of(o) if LO <= r <= HI]
+            if not touched:
+                continue
+            if op == "global_load_dwordx4":
+                # destination is operand 0 and must be the ONLY operand in the reserved range
+                assert all(i == 0 for i, _ in touched), (name, text)
+                n_loads += 1
+            elif op in ("v_cvt_f64_f32_e32", "v_cvt_f64_f32", "v_mov_b64_e32", "v_mov_b64"):
+                # reserved registers only as the SOURCE
+                assert all(i == 1 for i, _ in touched), (name, text)
+                n_takes += 1
+            else:
+                raise AssertionError(f"{name}: compiler-owned instruction touches a reserved register: {text}")
+        assert n_loads >= 8 and n_takes >= 8, (name, n_loads, n_takes)
+        assert scratch <= 24, (name, scratch)
