@@ -304,16 +304,25 @@ def size_leg(chip, rows, plan, params, inflight, n_ticks=240, warm=20):
     run_ticks(chip, ls[warm:warm + 30], params, inflight)
     ms, cnt, _, _ = chip.profile_scan()
     chip.profile_enable(False)
-    avg_s = ms / 1e3 / max(1, cnt)
+    iso_s = ms / 1e3 / max(1, cnt)          # one launch ALONE on one stream, bracketed by hipEvents (profiled pass)
+    step_s = dt / n                          # what a tick costs in the timed loop
     alg = 4.0 * D * rows
     cache_resident = alg <= 256 * 2**20
+    # Short scans alternate between two scan streams in the timed loop (chip_api.hip enqueue_scan_merge), so consecutive launches
+    # overlap there: the rate the hardware sustains is algorithmic bytes / STEP time.  The profiled pass keeps every launch on one
+    # stream so that a per-launch duration exists at all; it includes the ramp-up / ramp-down the overlap hides and is reported
+    # next to it, never as `achieved`.
     gaps = np.diff(np.array(stamps))
-    return {"db_rows": rows, "value": n / dt, "unit": "loop-queries/s", "ms_per_step": 1e3 * dt / n,
+    return {"db_rows": rows, "value": n / dt, "unit": "loop-queries/s", "ms_per_step": 1e3 * step_s,
             "ms_per_step_median": 1e3 * float(np.median(gaps)) if gaps.size else None, "steps": n,
             "roofline": {"bound": "hbm" if not cache_resident else "hbm (NOT an HBM figure: the 164 MB prefix is Infinity-Cache resident, 256 MiB)",
-                         "achieved": alg / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / avg_s / 1e9 / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "db_scan_topk", "avg_kernel_ms": avg_s * 1e3, "launches": cnt,
-                         "algorithmic_bytes_per_launch": alg, "cache_resident": cache_resident}}
+                         "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS,
+                         "priced_from": "ms_per_step of the timed loop (launches of consecutive ticks overlap on two scan streams)",
+                         "kernel_overlap": True,
+                         "traffic": None, "kernel": "db_scan_topk_rows (row-batched form: <= 8 rows per wave)" if rows <= 8 * 4096 else "db_scan_topk",
+                         "isolated_kernel_ms": iso_s * 1e3, "isolated_kernel_note": "one launch alone on one stream between two hipEvents "
+                         "(profiled pass, no overlap): >= ms_per_step by the ramp-up / ramp-down that overlapping launches hide",
+                         "launches": cnt, "algorithmic_bytes_per_launch": alg, "cache_resident": cache_resident}}
 
 
 def main():
@@ -487,6 +496,9 @@ def main():
         exchange = {capi.CHIP_EXCHANGE_RCCL: "in-library RCCL (ncclCommInitAll, one worker thread per device)",
                     capi.CHIP_EXCHANGE_COPY: "in-library device copies (devices repeat: RCCL refuses two ranks on one device)"}[chip.info()["exchange"]]
     info = chip.info()
+    wanted_rccl = ((world > 1 and not replicated) or args.force_sharded or (group_mode and not args.same_device)) and not args.host_exchange
+    rccl_ranks = int(info.get("comm_ranks", 0))           # ncclCommCount of the communicator the library's exchange runs over
+    exchange_fallback = bool(wanted_rccl and rccl_ranks != (args.gpus if group_mode else world))
     t_fill = time.perf_counter()
     chip.append_synthetic(total_rows, SEED, plants)
     t_fill = time.perf_counter() - t_fill
@@ -596,6 +608,8 @@ def main():
                        "loop_query": "one tick of Cerebro::descrip_N__dot__descrip_0_N = 3 descriptor queries + top-k + accept rule",
                        "process_layout": "one process" if world == 1 else f"{world} processes (one per GPU)",
                        "exchange": exchange,
+                       "rccl_ranks": rccl_ranks,                    # 0 = no RCCL communicator inside the library
+                       "exchange_fallback": exchange_fallback,      # True: RCCL was asked for and did NOT carry the exchange of all ranks
                        "control_plane": (dist.get_backend() if dist is not None else None),
                        "sharding": "single GPU" if n_gpus == 1 else (f"{world} replicas of the whole DB, independent tick streams, no collective" if replicated
                                                                      else f"row round-robin over {n_gpus} GPUs + all-gather of top-k"),
@@ -624,7 +638,7 @@ def main():
                                    "sample": f"{n} ticks of 3 fp64 GEMVs over a {args.cpu_sample}-column x 4096 column-major M "
                                              f"({dt:.1f} s), scaled to {args.rows} columns; sequential-order port (one s += q[e]*col[e] "
                                              "chain per column, -O2 -ffp-contract=off: does not vectorise) -- Eigen is absent from this image, "
-                                             f"its GEMV would use packet accumulators; host has {os.cpu_count()} cores, "
+                                             f"its GEMV would use packet accumulators; host has {os.cpu_count()} logical CPUs ({usable_cpus()} usable under the cgroup quota), "
                                              "reference path is single-threaded (Eigen without OpenMP)"}
             ac_cols = max(args.cpu_sample, 200_000)      # 6.5 GB of fp64: large enough to defeat the host caches
             cols_per_s, n, dt, nt = cpu_baseline_all_cores(ac_cols, min(args.cpu_budget, 6.0))

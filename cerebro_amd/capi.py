@@ -84,7 +84,7 @@ class Info(C.Structure):
                 ("shard_count", C.c_int32), ("n_cus", C.c_int32), ("rows_global", C.c_int64),
                 ("rows_local", C.c_int64), ("capacity_local", C.c_int64), ("lossy_rows", C.c_int64),
                 ("arch", C.c_char * 32), ("storage_bytes", C.c_int32), ("n_devices", C.c_int32), ("exchange", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("comm_ranks", C.c_int32)]
 
 
 # every symbol include/cerebro_hip.h declares: name -> (restype, argtypes)

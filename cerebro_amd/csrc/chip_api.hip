@@ -156,6 +156,7 @@ void ctx_destroy(chip_ctx *c)
     if (c->topk_host) (void)hipHostFree(c->topk_host);
     if (c->qvec_dev) (void)hipFree(c->qvec_dev);
     if (c->scores_dev) (void)hipFree(c->scores_dev);
+    if (c->stamps_dev) (void)hipFree(c->stamps_dev);
     for (Slot &s : c->slots) {
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.host) (void)hipHostFree(s.host);
@@ -227,6 +228,10 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
         CHIP_HIP(c, hipHostMalloc(&s.host, sizeof(chip_tick_result), hipHostMallocDefault));
         CHIP_HIP(c, hipHostGetDevicePointer((void **)&s.dev, s.host, 0));
     }
+    if (env_int("CHIP_SCAN_STAMPS", 0)) {
+        CHIP_HIP(c, hipMalloc(&c->stamps_dev, (size_t)c->max_grid * 16 * 4 * sizeof(unsigned long long)));
+        CHIP_HIP(c, hipMemset(c->stamps_dev, 0, (size_t)c->max_grid * 16 * 4 * sizeof(unsigned long long)));
+    }
     rc = pnp_create(c);
     if (rc != CHIP_OK) return rc;
     c->cap_hint = capacity_hint;
@@ -295,6 +300,7 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
     const int grid = scan_grid_for(c, a.n_rows, nq, a.q64 != 0);
     a.rows_form = scan_rows_form(c, a.n_rows, nq, grid, a.q64 != 0);
     a.plain_loads = (double)a.n_rows * c->D * c->elem <= c->scan_plain_bytes ? 1 : 0;
+    a.stamps = c->stamps_dev;
 
     // The merge that last read this buffer ran kRing ticks ago; only when it is not already complete (a stalled ctx
     // stream) does the scan stream need a barrier packet -- in steady state this costs nothing.
@@ -985,6 +991,19 @@ int chip_get_info(const chip_ctx *c, chip_info *info)
     info->storage_bytes = r->elem;
     info->n_devices = c->group ? group_size(c) : 1;
     info->exchange = c->group ? c->group_transport : (c->xchg ? CHIP_EXCHANGE_RCCL : CHIP_EXCHANGE_NONE);
+    info->comm_ranks = exchange_comm_ranks(c->group ? r : c);
+    return CHIP_OK;
+}
+
+// Tuning aid, not part of the ABI (no declaration in cerebro_hip.h): with CHIP_SCAN_STAMPS=1 the row-batched scan kernel leaves four
+// s_memrealtime (100 MHz) stamps per wave -- entry, queries staged, rows done, block merge done -- of the most recent launch.
+int chip_debug_scan_stamps(chip_ctx *c, unsigned long long *out, int64_t n_waves)
+{
+    if (!c || !out || c->group || !c->stamps_dev || n_waves > (int64_t)c->max_grid * 16) return CHIP_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    CHIP_HIP(c, hipDeviceSynchronize());
+    CHIP_HIP(c, hipMemcpy(out, c->stamps_dev, (size_t)n_waves * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CHIP_OK;
 }
 

@@ -28,6 +28,7 @@ struct ScanArgs {
     int32_t q64 = 0;                // queries staged in LDS as fp64 (scan_q64)
     int32_t rows_form = 0;          // > 0: row-batched kernel with this many rows per wave in flight (scan_rows_form)
     int32_t plain_loads = 0;        // row-batched kernel: temporal loads (the prefix fits the Infinity Cache and is re-read every tick)
+    unsigned long long *stamps = nullptr;   // tuning only (CHIP_SCAN_STAMPS): 4 wall-clock stamps per wave of the row-batched kernel
 };
 
 struct MergeArgs {
@@ -126,6 +127,7 @@ struct Ctx {
 
     void *qvec_dev = nullptr;                 // [CHIP_MAX_NQ][D] external query vectors (storage type)
     double *scores_dev = nullptr;             // chip_query_scores scratch (grown on demand)
+    unsigned long long *stamps_dev = nullptr; // tuning only (CHIP_SCAN_STAMPS=1): [max_grid * 16 waves][4]
     int64_t scores_cap = 0;
 
     // --- sharded tick inside the library (chip_multi.hip) ---
@@ -216,6 +218,7 @@ constexpr uint32_t kCreateStoreMask = 3u;   // CHIP_CREATE_STORE_F32 | CHIP_CREA
 constexpr int kXRing = 64;                  // >= CHIP_MAX_INFLIGHT: list buffers of a tick are not reused while it is in flight
 constexpr int kListEntries = CHIP_MAX_NQ * CHIP_MAX_TOPK;
 void exchange_destroy(Ctx *c);
+int exchange_comm_ranks(const Ctx *c);      // ncclCommCount of the attached communicator, 0 if none
 void group_destroy(Ctx *c);
 // sharded ctx with an RCCL communicator attached (one process per GPU): scan -> local merge -> all-gather -> merge, all enqueued
 int xchg_tick_enqueue(Ctx *c, int64_t l, int64_t k, const chip_dot_params *p, Slot &s);

@@ -71,6 +71,13 @@ void exchange_destroy(Ctx *c)
     c->xchg = nullptr;
 }
 
+int exchange_comm_ranks(const Ctx *c)
+{
+    if (!c->xchg || !c->xchg->comm) return 0;
+    int n = 0;
+    return ncclCommCount(c->xchg->comm, &n) == ncclSuccess ? n : 0;
+}
+
 // ------------------------------------------------------------------------------------------------ one process per GPU
 // caller: tick_enqueue_slot (query_mu held, device current, tick_prepare said SCANNED)
 int xchg_tick_enqueue(Ctx *c, int64_t l, int64_t k, const chip_dot_params *p, Slot &s)

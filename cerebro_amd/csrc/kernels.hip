@@ -470,6 +470,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
     const int npass = g < a.n_rows ? (int)((a.n_rows - 1 - g) / (R * tw)) + 1 : 0;
     const int total = npass * nb;                                  // batches this wave consumes (wave-uniform)
 
+    unsigned long long *stamp = a.stamps ? a.stamps + (size_t)g * 4 : nullptr;   // tuning only
+    if (stamp && lane == 0) stamp[0] = wall_clock64();
     // ---- queries -> LDS by LDS-DMA, 1 KiB per wave-instruction, chunks dealt round robin to the waves ----
     {
         const int cpq = (int)((size_t)D * sizeof(T) / 1024);
@@ -508,6 +510,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
+    if (stamp && lane == 0) stamp[1] = wall_clock64();
     // running top-K lists: LDS behind the queries (this wave's NQ lists are touched by this wave only)
     chip_topk_entry *lists = reinterpret_cast<chip_topk_entry *>(smem + (size_t)NQ * D * sizeof(T));
     chip_topk_entry *mylists = lists + (size_t)wave * NQ * CHIP_MAX_TOPK;
@@ -592,7 +595,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
 #undef CHIP_ROWS_FMA_SLOT
 #undef CHIP_ROWS_FMA_HALF
 #undef CHIP_ROWS_ISSUE_SLOT
+    if (stamp && lane == 0) stamp[2] = wall_clock64();
     block_merge_lists<NQ>(a, lists, K, lane, wave, wpb);
+    if (stamp && lane == 0) stamp[3] = wall_clock64();
 }
 
 template <typename T, int NQ, int R, bool NTL>

@@ -309,7 +309,8 @@ typedef struct {
     int32_t storage_bytes;      /* 4 = float rows, 8 = double rows                                 */
     int32_t n_devices;          /* 1, or G of chip_create_multi (then the other fields describe devices[0]) */
     int32_t exchange;           /* CHIP_EXCHANGE_*                                                 */
-    int32_t reserved;
+    int32_t comm_ranks;         /* ranks of the RCCL communicator the exchange runs over (ncclCommCount), 0 = none: a caller
+                                   that asked for G GPUs can PROVE the collective spans G ranks (and see a copy fallback) */
 } chip_info;
 enum { CHIP_EXCHANGE_NONE = 0, CHIP_EXCHANGE_RCCL = 1, CHIP_EXCHANGE_COPY = 2 };
 int chip_get_info(const chip_ctx *ctx, chip_info *info);

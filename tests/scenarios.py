@@ -48,3 +48,16 @@ def build_db(seed: int, N: int, D: int, plants):
 def default_schedule(N: int):
     """SURVEY 8d tick schedule: l advances by exactly 3 per tick from 56 (first k > 5)."""
     return list(range(56, N + 1, 3))
+
+
+_synth_topk_cache = {}
+
+
+def cached_scan_topk_synth(seed: int, k: int, D: int, query_rows, K: int, plants, nthreads: int):
+    """oracle_lib.scan_topk_synth with a per-process cache: the full-size (1M-row) CPU-oracle scan takes tens of seconds and
+    several tests (unsharded, 8 sub-contexts on one device, real multi-GPU layouts) check the same tick against it."""
+    key = (seed, k, D, tuple(int(r) for r in query_rows), K, tuple(tuple(int(x) for x in p) for p in plants))
+    if key not in _synth_topk_cache:
+        q = oracle_lib.synth_rows(seed, list(query_rows), D, plants)
+        _synth_topk_cache[key] = oracle_lib.scan_topk_synth(seed, k, D, q, K, plants, nthreads=nthreads)
+    return _synth_topk_cache[key]

@@ -1,10 +1,16 @@
-"""Multi-GPU INSIDE the C ABI (include/cerebro_hip.h "multi-GPU inside the library"), as far as a 1-GPU box allows:
+"""Multi-GPU INSIDE the C ABI (include/cerebro_hip.h "multi-GPU inside the library").  On a 1-GPU box:
   * chip_create_multi with the device list [0]*G: the full G-way code path (G sub-contexts with their own streams, row shards,
     replicated query ring, one host worker thread each, list exchange, merge + decision on the root) -- the exchange is the
     device-copy transport because RCCL refuses two ranks on one device;
   * chip_create_multi([0]) and chip_comm_init_rank(world 1): the same paths with the RCCL communicator (ncclCommInitAll /
     ncclCommInitRank, ncclAllGather enqueued in-stream between local and global merge) at world size 1.
+  * BASELINE config 4 at FULL size (4096-D x 1M rows, 8 shards) through the same one-device group, bit-exact vs the CPU oracle.
+On a box with >= 2 GPUs (skipped otherwise -- they light up the moment the suite runs on a multi-GPU node):
+  * chip_create_multi(devices = 0..n-1): ncclCommInitAll over DISTINCT devices, ncclAllGather between the merges;
+  * one process per GPU: chip_comm_unique_id / chip_comm_init_rank under 2 real processes with the RCCL exchange;
+  both assert chip_get_info().comm_ranks == number of GPUs, i.e. that RCCL itself carried the exchange.
 The caller-visible surface is the single-GPU one: chip_db_append_*, chip_loop_tick[_enqueue/_collect], chip_query_*, PnP."""
+import os
 import numpy as np
 import pytest
 
@@ -180,3 +186,118 @@ def test_sharded_ctx_without_exchange_still_refuses_ticks():
         with pytest.raises(capi.ChipError) as e:
             chip.loop_tick(100)
         assert e.value.status == capi.CHIP_ERR_UNSUPPORTED      # host-driven exchange: chip_scan_local + chip_merge_decide
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_group_8way_1M_full_size_parity():
+    """BASELINE config 4's workload at its own size -- 4096-D x 1 000 053 rows sharded 8-way -- through chip_create_multi on ONE
+    device (8 sub-contexts, row i on sub-context i % 8, replicated query ring, device-copy exchange): the tick, the top-8 lists
+    and prefix queries are bit-exact vs the full CPU-oracle scan, exactly as test_1M_full_size_parity_and_properties checks the
+    unsharded ctx."""
+    D, N, seed = 4096, 1_000_053, 20190412
+    l = N
+    q, p = l - 1, 777_777
+    plants = [(q - j, p - j, 1) for j in range(3)] + [(p + 4, p, 2), (123_456, p - 1, 2)]
+    ncpu = os.cpu_count() or 1
+    with capi.Chip(D, capacity_hint=N, devices=[0] * 8) as chip:
+        info = chip.info()
+        assert info["n_devices"] == 8 and info["exchange"] == capi.CHIP_EXCHANGE_COPY and info["comm_ranks"] == 0
+        chip.append_synthetic(N, seed, plants)
+        assert chip.size() == N and chip.info()["rows_local"] == len(range(0, N, 8))
+        r = chip.loop_tick(l)
+        wsc, wix = scenarios.cached_scan_topk_synth(seed, l - 50, D, [l - 1, l - 2, l - 3], 8, plants, nthreads=min(ncpu, 128))
+        assert r.status == capi.CHIP_TICK_SCANNED and r.found == 1 and r.idx_curr == q and r.idx_prev == p + 4
+        assert list(r.argmax) == list(wix[:, 0]) == [p + 4, p - 1, p - 2]
+        assert [float(x).hex() for x in r.maxv] == [float(x).hex() for x in wsc[:, 0]]
+        got = chip.query_rows(l - 50, [l - 1, l - 2, l - 3], 8)
+        assert np.array_equal(got[1], wix) and np.array_equal(bits(got[0]), bits(wsc))
+        # prefixes that cut through the shards at every residue
+        for k1 in (8, 1001, 123_457, 500_003, p + 5):
+            sc, ix = chip.query_rows(k1, [l - 1, l - 2, l - 3], 8)
+            assert np.all(ix < k1) and np.all(np.diff(sc, axis=1) <= 0)
+            for qi in range(3):
+                keep = [(s, i) for s, i in zip(wsc[qi], wix[qi]) if i < k1]
+                for (s, i), gs, gi in zip(keep, sc[qi], ix[qi]):
+                    assert (s, i) == (gs, gi)
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 GPUs: ncclCommInitAll over distinct devices")
+def test_group_over_rccl_distinct_devices():
+    """chip_create_multi over the GPUs of this node (up to 8): the RCCL exchange with one rank per device."""
+    n = min(_n_gpus(), 8)
+    D, N = 1024, 2400
+    plants, loops, ties = scenarios.loop_plants(N, 6, seed=77)
+    db = scenarios.build_db(4100, N, D, plants)
+    with capi.Chip(D, devices=list(range(n))) as chip:
+        info = chip.info()
+        assert info["n_devices"] == n and info["exchange"] == capi.CHIP_EXCHANGE_RCCL and info["comm_ranks"] == n
+        chip.append_f32(db[:1000])
+        chip.append_f64(db[1000:].astype(np.float64))
+        _tick_parity(chip, db, N)
+        for nq, K in ((1, 1), (3, 8), (4, 16)):
+            rows = [N - 1, N - 2, N - 3, loops[0][1]][:nq]
+            got, want = chip.query_rows(N - 50, rows, K), oracle_lib.scan_topk(db, N - 50, db[rows], K)
+            assert np.array_equal(got[1], want[1]) and np.array_equal(bits(got[0]), bits(want[0]))
+        u = chip.query_scores(N - 50, N - 1)
+        assert np.array_equal(bits(u), bits(oracle_lib.scores(db, N - 50, db[N - 1])))
+    # BASELINE config 4's shard size on real devices: 125k rows per GPU when n == 8
+    D, N, seed = 4096, 125_000 * n + 53, 20190412
+    l = N
+    q, p = l - 1, N // 2
+    plants = [(q - j, p - j, 1) for j in range(3)] + [(p + 4, p, 2)]
+    with capi.Chip(D, capacity_hint=N, devices=list(range(n))) as chip:
+        assert chip.info()["comm_ranks"] == n
+        chip.append_synthetic(N, seed, plants)
+        r = chip.loop_tick(l)
+        wsc, wix = scenarios.cached_scan_topk_synth(seed, l - 50, D, [l - 1, l - 2, l - 3], 8, plants, nthreads=min(os.cpu_count() or 1, 128))
+        assert r.found == 1 and r.idx_prev == p + 4 and list(r.argmax) == list(wix[:, 0])
+        assert [float(x).hex() for x in r.maxv] == [float(x).hex() for x in wsc[:, 0]]
+
+
+def _rccl_rank_worker(rank, world, uid_path, ret):
+    import time
+    import torch
+    from cerebro_amd import capi as capi_
+    torch.cuda.set_device(rank)
+    D, N = 1024, 1800
+    plants, loops, ties = scenarios.loop_plants(N, 5, seed=21)
+    db = scenarios.build_db(733, N, D, plants)
+    with capi_.Chip(D, device=rank, shard_rank=rank, shard_count=world) as chip:
+        if rank == 0:
+            with open(uid_path + ".tmp", "wb") as f:
+                f.write(capi_.comm_unique_id())
+            os.replace(uid_path + ".tmp", uid_path)
+        t0 = time.time()
+        while not os.path.exists(uid_path):
+            assert time.time() - t0 < 120
+            time.sleep(0.01)
+        chip.comm_init_rank(open(uid_path, "rb").read(), world, rank)
+        info = chip.info()
+        assert info["exchange"] == capi_.CHIP_EXCHANGE_RCCL and info["comm_ranks"] == world
+        chip.append_f32(db)
+        orc = oracle_lib.LoopOracle(db)
+        n_found = 0
+        for l in scenarios.default_schedule(N):          # collective calls: every rank makes them in the same order
+            g, o = chip.loop_tick(l).as_dict(), orc.tick(l)
+            for key in ("status", "found", "idx_curr", "idx_prev", "argmax"):
+                assert g[key] == o[key], (rank, l, key, g, o)
+            assert [float(x).hex() for x in g["maxv"]] == [float(x).hex() for x in o["maxv"]]
+            n_found += g["found"]
+        got, want = chip.query_rows(N - 50, [N - 1, N - 2], 8), oracle_lib.scan_topk(db, N - 50, db[[N - 1, N - 2]], 8)
+        assert np.array_equal(got[1], want[1]) and np.array_equal(bits(got[0]), bits(want[0]))
+        ret[rank] = n_found
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 GPUs: RCCL refuses two ranks on one device")
+def test_comm_init_rank_real_processes_over_rccl(tmp_path):
+    """One process per GPU (BASELINE config 4's launch shape): ncclCommInitRank inside the library, in-stream ncclAllGather."""
+    import torch.multiprocessing as mp
+    world = min(_n_gpus(), 8)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_rank_worker, args=(world, str(tmp_path / "uid.bin"), ret), nprocs=world, join=True)
+    assert len(ret) == world and len(set(ret.values())) == 1 and next(iter(ret.values())) > 0

@@ -286,7 +286,7 @@ def test_1M_full_size_parity_and_properties():
         r = chip.loop_tick(l)
         qrows = oracle_lib.synth_rows(seed, [l - 1, l - 2, l - 3], D, plants)
         assert chip.read_rows([l - 1, l - 2, l - 3]).tobytes() == qrows.tobytes()
-        wsc, wix = oracle_lib.scan_topk_synth(seed, l - 50, D, qrows, 8, plants, nthreads=min(ncpu, 128))
+        wsc, wix = scenarios.cached_scan_topk_synth(seed, l - 50, D, [l - 1, l - 2, l - 3], 8, plants, nthreads=min(ncpu, 128))
         assert list(r.argmax) == list(wix[:, 0])
         assert [float(x).hex() for x in r.maxv] == [float(x).hex() for x in wsc[:, 0]]
         # argmax = [p+4 (later duplicate of p), p-1 (123456 is an EARLIER duplicate -> loses the tie), p-2]
