@@ -27,6 +27,8 @@ CHIP_ERR_UNSUPPORTED = -8
 CHIP_ERR_TOO_FEW_POINTS = -9
 CHIP_ERR_BUSY = -10
 CHIP_ERR_COMM = -11
+CHIP_ERR_SHARD_FAILED = -12
+CHIP_ERR_GROUP_BROKEN = -13
 
 CHIP_MAX_TOPK = 16
 CHIP_MAX_NQ = 4

@@ -30,6 +30,8 @@ const char *chip_strerror(int status)
         case CHIP_ERR_TOO_FEW_POINTS: return "fewer than 20 correspondences";
         case CHIP_ERR_BUSY: return "async slot busy or empty";
         case CHIP_ERR_COMM: return "RCCL error (see chip_last_comm_error)";
+        case CHIP_ERR_SHARD_FAILED: return "a shard could not take part in this tick / query (all ranks see this status); retry";
+        case CHIP_ERR_GROUP_BROKEN: return "multi-GPU ctx is broken by an earlier partial failure; destroy it";
     }
     return "unknown status";
 }
@@ -200,6 +202,7 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     c->scan_rows = env_int("CHIP_SCAN_ROWS", 0);
     c->tick_same_stream = env_int("CHIP_TICK_SAME_STREAM", 1) != 0;
     c->scan_rows_auto_max = env_int("CHIP_SCAN_ROWS_AUTO_MAX", 8);
+    c->scan_short_bpc = env_int("CHIP_SCAN_SHORT_BPC", 1);
     c->scan_plain_bytes = (double)env_int("CHIP_SCAN_PLAIN_MIB", 192) * 1024 * 1024;
     c->scan_overlap_bytes = (double)env_int("CHIP_SCAN_OVERLAP_GIB", 8) * 1024 * 1024 * 1024;
     // a sharded ctx gets three small kernels per tick through its ctx stream underneath the scans: keep slots free for them
@@ -431,7 +434,7 @@ void fill_immediate(chip_tick_result *r, int32_t status)
     for (int q = 0; q < 3; q++) { r->argmax[q] = -1; r->maxv[q] = -INFINITY; }
 }
 
-static int64_t published_rows(const Ctx *c)
+int64_t published_rows(const Ctx *c)
 {
     std::lock_guard<std::mutex> lk(c->mu);
     return c->rows_global;
@@ -442,8 +445,13 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
     if (s.in_flight) return CHIP_ERR_BUSY;
     int32_t status = 0;
     int64_t k = 0;
-    int rc = tick_prepare(published_rows(c), c->last_l, l, p, &status, &k);
+    // With an exchange attached the ranks may see different published lengths (each has its own appender): l > n on THIS rank is
+    // then not a reason to leave the collective call -- the rank takes part with the failure mark (xchg_tick_enqueue).
+    const int64_t n_pub = published_rows(c);
+    int rc = tick_prepare(c->xchg ? INT64_MAX : n_pub, c->last_l, l, p, &status, &k);
     if (rc != CHIP_OK) return rc;
+    s.prev_last_l = c->last_l;
+    s.last_l_ptr = &c->last_l;
     if (status != CHIP_TICK_SCANNED) {
         if (status == CHIP_TICK_TOO_SHORT) c->last_l = l;   // :1098 (the else-branch of :1022 still ends the pass)
         fill_immediate(s.host, status);
@@ -452,7 +460,7 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
         return CHIP_OK;
     }
     if (c->xchg) {   // sharded ctx with its exchange inside the library: scan -> local merge -> all-gather -> merge + decision
-        rc = xchg_tick_enqueue(c, l, k, p, s);
+        rc = xchg_tick_enqueue(c, l, k, p, s, l > n_pub);
         if (rc != CHIP_OK) return rc;
     } else {
         const int64_t rows[3] = {l - 1, l - 2, l - 3};  // v, vm, vmm (:987-989)
@@ -477,12 +485,18 @@ int tick_collect_slot(Ctx *c, Slot &s, chip_tick_result *out)
     if (!s.immediate) CHIP_HIP(c, hipEventSynchronize(s.done));
     *out = *s.host;
     s.in_flight = false;
+    if (out->status == CHIP_TICK_FAILED) {   // a shard could not take part: the tick had no effect (:1098 was not reached)
+        if (s.last_l_ptr && *s.last_l_ptr > s.prev_last_l) *s.last_l_ptr = s.prev_last_l;
+        fill_immediate(out, CHIP_TICK_FAILED);
+        return CHIP_ERR_SHARD_FAILED;
+    }
     return CHIP_OK;
 }
 
 int sync_topk_out(Ctx *c, int nq, int K, double *scores, int64_t *idx)
 {
     CHIP_HIP(c, hipStreamSynchronize(c->s_query));  // the last block stored the list into pinned host memory
+    if (c->topk_host[0].idx == -2) return CHIP_ERR_SHARD_FAILED;   // kFailedShardIdx: a shard could not take part (every rank sees it)
     for (int i = 0; i < nq * K; i++) {
         if (scores) scores[i] = c->topk_host[i].score;
         if (idx) idx[i] = c->topk_host[i].idx;
@@ -506,6 +520,85 @@ static int ring_begin_append(Ctx *c, int64_t new_total)
     return CHIP_OK;
 }
 
+// ---- append, in phases (see chip_internal.h).  The caller holds the append lock and has made the device current. ----
+int append_reserve(Ctx *c, int64_t first, int64_t n) { return ensure_capacity(c, local_count(c, first + n)); }
+
+// Upload rows [from, from + count) of the call (step > 1: every step-th row, i.e. one shard's rows) in staging-sized chunks and
+// run K3 on them.  ring: mirror into the replicated ring as well.
+static int append_pass(Ctx *c, const void *desc, int src_elem, int64_t first, int64_t from, int64_t count, int64_t step, bool ring)
+{
+    const size_t row_bytes = (size_t)c->D * src_elem;
+    const int64_t chunk_rows = (int64_t)(c->stage_bytes / row_bytes);
+    for (int64_t done = 0; done < count; done += chunk_rows) {
+        const int64_t m = (count - done) < chunk_rows ? (count - done) : chunk_rows;
+        const char *src = static_cast<const char *>(desc) + (size_t)(from + done * step) * row_bytes;
+        if (step == 1)
+            CHIP_HIP(c, hipMemcpyAsync(c->stage_dev, src, (size_t)m * row_bytes, hipMemcpyHostToDevice, c->s_append));
+        else   // one shard's rows: a strided gather out of the caller's batch, one row per pitch line
+            CHIP_HIP(c, hipMemcpy2DAsync(c->stage_dev, row_bytes, src, (size_t)step * row_bytes, row_bytes, (size_t)m, hipMemcpyHostToDevice, c->s_append));
+        const int r = launch_store_rows(c, c->s_append, c->stage_dev, src_elem, m, first + from + done * step, c->flags_dev, ring, step);
+        if (r != CHIP_OK) return r;
+        // the staging buffer is reused by the next chunk: stream order serialises copy -> kernel -> copy
+    }
+    return CHIP_OK;
+}
+
+// DB rows only (rows past the published length are invisible to queries); *bad gets the validation bits of THIS ctx's share:
+// bit0 = a value that is not float32-representable went into float rows, bit1 = NaN / Inf.
+int append_store_db(Ctx *c, const void *desc, int src_elem, int64_t first, int64_t n, bool owner_only, uint32_t *bad)
+{
+    *c->flags_host = 0;
+    CHIP_HIP(c, hipMemsetAsync(c->flags_dev, 0, sizeof(uint32_t), c->s_append));
+    int rc;
+    if (owner_only && c->nranks > 1) {
+        const int64_t G = c->nranks;
+        const int64_t i0 = ((c->rank - first) % G + G) % G;               // first row of the batch this shard owns
+        const int64_t cnt = n > i0 ? (n - i0 + G - 1) / G : 0;
+        rc = append_pass(c, desc, src_elem, first, i0, cnt, G, false);
+    } else {
+        rc = append_pass(c, desc, src_elem, first, 0, n, 1, false);
+    }
+    if (rc != CHIP_OK) return rc;
+    CHIP_HIP(c, hipMemcpyAsync(c->flags_host, c->flags_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->s_append));
+    CHIP_HIP(c, hipStreamSynchronize(c->s_append));
+    *bad = *c->flags_host;
+    return CHIP_OK;
+}
+
+// Genuinely float64 descriptors (e.g. ReljaNetVLAD's numpy WPCA output, whole_image_desc_compute_server.py:148-149): an
+// undecided, still EMPTY DB becomes a double-row DB -- as the reference's MatrixXd M (Cerebro.cpp:946).
+bool append_can_switch_to_double(const Ctx *c, int64_t first) { return c->store_auto && first == 0 && (size_t)c->D * 8 * 3 <= 160 * 1024; }
+
+int append_switch_to_double(Ctx *c, int64_t n)
+{
+    int rc = configure_storage(c, 8);
+    if (rc != CHIP_OK) return rc;
+    return ensure_capacity(c, local_count(c, c->cap_hint > n ? c->cap_hint : n));
+}
+
+void append_publish(Ctx *c, int64_t new_total, bool lossy, int64_t n)
+{
+    std::lock_guard<std::mutex> lk(c->mu);  // publish the new length only now (rows fully resident)
+    c->rows_global = new_total;
+    c->rows_local = local_count(c, c->rows_global);
+    if (lossy) c->lossy_rows += n;   // upper bound: rows of this call
+    c->store_auto = false;           // the storage type is final once the DB holds a row
+}
+
+int append_ring_publish(Ctx *c, const void *desc, int src_elem, int64_t first, int64_t n, bool lossy)
+{
+    if (c->ring_dev) {  // sharded: mirror the newest rows into the replicated ring (the DB store of owned rows is idempotent)
+        int rc = ring_begin_append(c, first + n);
+        if (rc != CHIP_OK) return rc;
+        const int64_t m = n < CHIP_RING_ROWS ? n : CHIP_RING_ROWS;
+        rc = append_pass(c, desc, src_elem, first, n - m, m, 1, true);
+        if (rc != CHIP_OK) return rc;
+        CHIP_HIP(c, hipStreamSynchronize(c->s_append));
+    }
+    append_publish(c, first + n, lossy, n);
+    return CHIP_OK;
+}
+
 int ctx_append(Ctx *c, const void *desc, int src_elem, int64_t n, uint32_t flags, int64_t *first_index)
 {
     if (!c || !desc || n < 0) return CHIP_ERR_INVALID_ARG;
@@ -514,79 +607,31 @@ int ctx_append(Ctx *c, const void *desc, int src_elem, int64_t n, uint32_t flags
     const int64_t first = published_rows(c);
     if (first_index) *first_index = first;
     if (n == 0) return CHIP_OK;
-    int rc = ensure_capacity(c, local_count(c, first + n));
+    int rc = append_reserve(c, first, n);
     if (rc != CHIP_OK) return rc;
-
-    // Upload rows [from, from+count) of this call in staging-sized chunks and run K3 on them.
-    auto pass = [&](int64_t from, int64_t count, bool ring) -> int {
-        const int64_t chunk_rows = (int64_t)(c->stage_bytes / ((size_t)c->D * src_elem));
-        for (int64_t off = from; off < from + count; off += chunk_rows) {
-            const int64_t m = (from + count - off) < chunk_rows ? (from + count - off) : chunk_rows;
-            CHIP_HIP(c, hipMemcpyAsync(c->stage_dev, static_cast<const char *>(desc) + (size_t)off * c->D * src_elem, (size_t)m * c->D * src_elem,
-                                       hipMemcpyHostToDevice, c->s_append));
-            const int r = launch_store_rows(c, c->s_append, c->stage_dev, src_elem, m, first + off, c->flags_dev, ring);
-            if (r != CHIP_OK) return r;
-            // the staging buffer is reused by the next chunk: stream order serialises copy -> kernel -> copy
-        }
-        return CHIP_OK;
-    };
-    // pass 1 writes the DB only (rows past the published length are invisible); the ring is updated after validation
+    // A ctx that is fed the whole stream by its own caller (single GPU, or one process per GPU) validates the WHOLE batch, so that
+    // every rank takes the same storage-type / rejection decision without talking to the others.
     uint32_t bad = 0;
     for (int attempt = 0; attempt < 2; attempt++) {
-        *c->flags_host = 0;
-        CHIP_HIP(c, hipMemsetAsync(c->flags_dev, 0, sizeof(uint32_t), c->s_append));
-        rc = pass(0, n, false);
+        rc = append_store_db(c, desc, src_elem, first, n, false, &bad);
         if (rc != CHIP_OK) return rc;
-        CHIP_HIP(c, hipMemcpyAsync(c->flags_host, c->flags_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, c->s_append));
-        CHIP_HIP(c, hipStreamSynchronize(c->s_append));
-        bad = *c->flags_host;
         if (bad & 2u) return CHIP_ERR_NONFINITE;
-        if (!(bad & 1u) || (flags & CHIP_APPEND_ALLOW_ROUNDING)) break;
-        // Genuinely float64 descriptors (e.g. ReljaNetVLAD's numpy WPCA output, whole_image_desc_compute_server.py:148-149):
-        // an undecided, still EMPTY DB becomes a double-row DB -- as the reference's MatrixXd M (Cerebro.cpp:946) -- and the
-        // rows are stored again, unrounded.  Anything else keeps the lossless-narrowing contract and fails.
-        if (attempt == 0 && c->store_auto && first == 0 && (size_t)c->D * 8 * 3 <= 160 * 1024) {
-            rc = configure_storage(c, 8);
-            if (rc != CHIP_OK) return rc;
-            rc = ensure_capacity(c, local_count(c, c->cap_hint > n ? c->cap_hint : n));
+        if (!(bad & 1u)) break;
+        // not float32-representable: an empty undecided DB takes the data as it is (double rows) -- also when the caller allows
+        // rounding: the flag permits rounding where it is unavoidable (a float DB that already holds rows), it does not ask for it
+        if (attempt == 0 && append_can_switch_to_double(c, first)) {
+            rc = append_switch_to_double(c, n);
             if (rc != CHIP_OK) return rc;
             continue;
         }
+        if (flags & CHIP_APPEND_ALLOW_ROUNDING) break;
         return CHIP_ERR_NOT_F32;
     }
-
-    if (c->ring_dev) {  // sharded: mirror the newest rows into the replicated ring (DB store is idempotent)
-        rc = ring_begin_append(c, first + n);
-        if (rc != CHIP_OK) return rc;
-        const int64_t m = n < CHIP_RING_ROWS ? n : CHIP_RING_ROWS;
-        rc = pass(n - m, m, true);
-        if (rc != CHIP_OK) return rc;
-        CHIP_HIP(c, hipStreamSynchronize(c->s_append));
-    }
-    {
-        std::lock_guard<std::mutex> lk(c->mu);  // publish the new length only now (rows fully resident)
-        c->rows_global = first + n;
-        c->rows_local = local_count(c, c->rows_global);
-        if (bad & 1u) c->lossy_rows += n;  // upper bound: rows of this call
-        c->store_auto = false;             // the storage type is final once the DB holds a row
-    }
-    return CHIP_OK;
+    return append_ring_publish(c, desc, src_elem, first, n, (bad & 1u) != 0);
 }
 
-int ctx_append_synthetic(Ctx *c, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant)
+int synth_generate(Ctx *c, int64_t first, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant)
 {
-    if (!c || n < 0 || n_plant < 0 || (n_plant > 0 && (!plant_dst || !plant_src || !plant_kind))) return CHIP_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> alk(c->append_mu);
-    CHIP_HIP(c, hipSetDevice(c->device));
-    const int64_t first = published_rows(c);
-    for (int64_t i = 0; i < n_plant; i++) {
-        if (plant_dst[i] < first || plant_dst[i] >= first + n || plant_src[i] < 0) return CHIP_ERR_RANGE;
-        if (i > 0 && plant_dst[i] <= plant_dst[i - 1]) return CHIP_ERR_INVALID_ARG;
-        if (plant_kind[i] != 1 && plant_kind[i] != 2) return CHIP_ERR_INVALID_ARG;
-    }
-    if (n == 0) return CHIP_OK;
-    int rc = ensure_capacity(c, local_count(c, first + n));
-    if (rc != CHIP_OK) return rc;
     int64_t *pd = nullptr, *ps = nullptr;
     int32_t *pk = nullptr;
     if (n_plant > 0) {
@@ -597,7 +642,7 @@ int ctx_append_synthetic(Ctx *c, int64_t n, uint64_t seed, const int64_t *plant_
         CHIP_HIP(c, hipMemcpyAsync(ps, plant_src, n_plant * sizeof(int64_t), hipMemcpyHostToDevice, c->s_append));
         CHIP_HIP(c, hipMemcpyAsync(pk, plant_kind, n_plant * sizeof(int32_t), hipMemcpyHostToDevice, c->s_append));
     }
-    rc = ring_begin_append(c, first + n);   // same ordering against in-flight scans as ctx_append
+    int rc = ring_begin_append(c, first + n);   // same ordering against in-flight scans as ctx_append
     if (rc == CHIP_OK) rc = launch_synth(c, c->s_append, first, n, seed, pd, ps, pk, n_plant);
     hipError_t e = hipStreamSynchronize(c->s_append);
     if (pd) (void)hipFree(pd);
@@ -605,12 +650,33 @@ int ctx_append_synthetic(Ctx *c, int64_t n, uint64_t seed, const int64_t *plant_
     if (pk) (void)hipFree(pk);
     if (rc != CHIP_OK) return rc;
     CHIP_HIP(c, e);
-    {
-        std::lock_guard<std::mutex> lk(c->mu);
-        c->rows_global = first + n;
-        c->rows_local = local_count(c, c->rows_global);
-        c->store_auto = false;
+    return CHIP_OK;
+}
+
+static int check_plants(int64_t first, int64_t n, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant)
+{
+    for (int64_t i = 0; i < n_plant; i++) {
+        if (plant_dst[i] < first || plant_dst[i] >= first + n || plant_src[i] < 0) return CHIP_ERR_RANGE;
+        if (i > 0 && plant_dst[i] <= plant_dst[i - 1]) return CHIP_ERR_INVALID_ARG;
+        if (plant_kind[i] != 1 && plant_kind[i] != 2) return CHIP_ERR_INVALID_ARG;
     }
+    return CHIP_OK;
+}
+
+int ctx_append_synthetic(Ctx *c, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant)
+{
+    if (!c || n < 0 || n_plant < 0 || (n_plant > 0 && (!plant_dst || !plant_src || !plant_kind))) return CHIP_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> alk(c->append_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    const int64_t first = published_rows(c);
+    int rc = check_plants(first, n, plant_dst, plant_src, plant_kind, n_plant);
+    if (rc != CHIP_OK) return rc;
+    if (n == 0) return CHIP_OK;
+    rc = append_reserve(c, first, n);
+    if (rc != CHIP_OK) return rc;
+    rc = synth_generate(c, first, n, seed, plant_dst, plant_src, plant_kind, n_plant);
+    if (rc != CHIP_OK) return rc;
+    append_publish(c, first + n, false, n);
     return CHIP_OK;
 }
 
@@ -813,7 +879,10 @@ static int check_query_args(chip_ctx *c, int64_t k, int32_t nq, int32_t topk, in
     if (!c) return CHIP_ERR_INVALID_ARG;
     if (nq < 1 || nq > CHIP_MAX_NQ || topk < 1 || topk > CHIP_MAX_TOPK) return CHIP_ERR_UNSUPPORTED;
     *n_global = published_rows(c);
-    if (k < 0 || k > *n_global) return CHIP_ERR_RANGE;
+    if (k < 0) return CHIP_ERR_RANGE;
+    // with an exchange attached "k beyond what THIS rank has published" is a per-rank condition: the rank takes part in the
+    // collective call with the failure mark (chip_multi.hip) instead of leaving it
+    if (k > *n_global && !(c->xchg && !c->group)) return CHIP_ERR_RANGE;
     return CHIP_OK;
 }
 
@@ -829,9 +898,14 @@ static int query_common(chip_ctx *c, int64_t k, const int64_t *query_rows, const
     CHIP_HIP(c, hipSetDevice(c->device));
     const void *q[CHIP_MAX_NQ];
     RingGuard rg(c);
+    if (c->xchg) {   // collective: every rank makes the same call; per-rank conditions become the failure mark
+        bool fail_local = k > n;
+        rc = query_rows ? xchg_fetch_rows(c, query_rows, nq, n, q, &fail_local) : upload_query_vectors(c, vectors, vec_elem, nq, q);
+        if (rc != CHIP_OK) return rc;
+        return xchg_query(c, k, q, nq, topk, scores, idx, fail_local);
+    }
     rc = query_rows ? query_row_ptrs(c, query_rows, nq, n, q) : upload_query_vectors(c, vectors, vec_elem, nq, q);
     if (rc != CHIP_OK) return rc;
-    if (c->xchg) return xchg_query(c, k, q, nq, topk, scores, idx);   // every rank must make the same call
     rc = enqueue_scan_merge(c, k, q, nq, topk, 0, nullptr, c->topk_dev, nullptr, false, nullptr);
     if (rc != CHIP_OK) return rc;
     return sync_topk_out(c, nq, topk, scores, idx);
@@ -859,13 +933,24 @@ int chip_query_scores(chip_ctx *c, int64_t k, int64_t query_row, double *u)
 {
     if (!c || !u) return CHIP_ERR_INVALID_ARG;
     const int64_t n = published_rows(c);
-    if (k < 0 || k > n || query_row < 0 || query_row >= n) return CHIP_ERR_RANGE;
+    if (k < 0 || query_row < 0) return CHIP_ERR_RANGE;
+    const bool collective = c->xchg && !c->group;
+    const bool out_of_range = k > n || query_row >= n;          // per-rank conditions when the ranks append independently
+    if (out_of_range && !collective) return CHIP_ERR_RANGE;
     if (c->group) return group_scores(c, k, query_row, u);
     std::lock_guard<std::mutex> qlk(c->query_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
     const void *q[1];
     RingGuard rg(c);
-    int rc = query_row_ptrs(c, &query_row, 1, n, q);
+    int rc;
+    if (collective) {   // the query row comes from its owner (any appended row); the broadcast is made by EVERY rank, also by one
+                        // that then finds its own arguments out of range -- leaving before it would put the communicator out of step
+        bool fail_local = false;
+        rc = xchg_fetch_rows(c, &query_row, 1, n, q, &fail_local);
+        if (rc == CHIP_OK && (fail_local || out_of_range)) rc = CHIP_ERR_RANGE;
+    } else {
+        rc = query_row_ptrs(c, &query_row, 1, n, q);
+    }
     if (rc != CHIP_OK) return rc;
     // a sharded ctx fills only the entries of the rows it owns (u[i], i % shard_count == shard_rank)
     return ctx_scores_local(c, k, q[0], u, c->nranks, c->nranks == 1 ? 0 : c->rank);

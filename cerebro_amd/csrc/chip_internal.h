@@ -51,7 +51,8 @@ int scan_grid_for(const Ctx *c, int64_t n_rows, int nq, bool q64);
 bool scan_q64(const Ctx *c, int nq, bool long_scan);
 int scan_rows_form(const Ctx *c, int64_t n_rows, int nq, int grid, bool q64);
 int launch_scores(Ctx *c, hipStream_t s, const ScanArgs &a, double *out_dev);   // K1s: all scores of one query, out[local row]
-int launch_store_rows(Ctx *c, hipStream_t s, const void *src, int src_elem, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring);
+int launch_store_rows(Ctx *c, hipStream_t s, const void *src, int src_elem, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring,
+                      int64_t row_stride = 1);
 int launch_synth(Ctx *c, hipStream_t s, int64_t first_global, int64_t n, uint64_t seed,
                  const int64_t *plant_dst_dev, const int64_t *plant_src_dev, const int32_t *plant_kind_dev, int64_t n_plant);
 
@@ -61,6 +62,8 @@ struct Slot {
     chip_tick_result *dev = nullptr;
     bool in_flight = false;
     bool immediate = false;             // result already final on host (skipped / too short)
+    int64_t prev_last_l = 0;            // last_l before this tick was enqueued ...
+    int64_t *last_l_ptr = nullptr;      // ... and where to restore it if the tick comes back CHIP_TICK_FAILED
 };
 
 struct Exchange;   // chip_multi.hip: how a sharded ctx trades its per-shard top-k lists (RCCL communicator / device copies)
@@ -149,6 +152,7 @@ struct Ctx {
     bool tick_same_stream = true;  // short ticks of a plain ctx: merge on the scan's stream (CHIP_TICK_SAME_STREAM=0 disables)
     int32_t scan_rows = 0;        // CHIP_SCAN_ROWS: 0 = auto, 1..3 = row-batched kernel with that R for every scan, -1 = never
     double scan_plain_bytes = 192.0 * 1024 * 1024;   // prefixes up to this size are read with temporal loads (CHIP_SCAN_PLAIN_MIB)
+    int32_t scan_short_bpc = 1;       // workgroups per CU of a launch over a cache-sized prefix (CHIP_SCAN_SHORT_BPC; 0 = as any other)
     int32_t scan_rows_auto_max = 8;   // auto: row-batched kernel while a wave owns at most this many rows (CHIP_SCAN_ROWS_AUTO_MAX)
     double scan_overlap_bytes = 8.0 * 1024 * 1024 * 1024;   // launches up to this size alternate between the two scan streams (CHIP_SCAN_OVERLAP_GIB)
 
@@ -198,6 +202,17 @@ struct RingGuard {   // sharded ctx: residency check .. scan event recorded, vs 
 int ctx_create(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device, int32_t rank, int32_t nranks, uint32_t flags);
 void ctx_destroy(chip_ctx *c);
 int ctx_append(Ctx *c, const void *desc, int src_elem, int64_t n, uint32_t flags, int64_t *first_index);
+// the phases of an append, for callers that must take the same decision on several contexts (group_append): reserve -> store the
+// DB rows (unpublished; owner_only: upload only the rows this shard owns) -> [switch an empty undecided DB to double rows] ->
+// mirror the newest rows into the ring and publish the length.  The caller holds the append lock.
+int append_reserve(Ctx *c, int64_t first, int64_t n);
+int append_store_db(Ctx *c, const void *desc, int src_elem, int64_t first, int64_t n, bool owner_only, uint32_t *bad);
+bool append_can_switch_to_double(const Ctx *c, int64_t first);
+int append_switch_to_double(Ctx *c, int64_t n);
+int append_ring_publish(Ctx *c, const void *desc, int src_elem, int64_t first, int64_t n, bool lossy);
+int synth_generate(Ctx *c, int64_t first, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant);
+void append_publish(Ctx *c, int64_t new_total, bool lossy, int64_t n);
+int64_t published_rows(const Ctx *c);
 int ctx_append_synthetic(Ctx *c, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant);
 int ctx_read_row(Ctx *c, int64_t g, int64_t total, void *out);          // one row, storage type, async on s_query
 int query_row_ptrs(Ctx *c, const int64_t *rows, int nq, int64_t n_global, const void **q);
@@ -221,8 +236,9 @@ void exchange_destroy(Ctx *c);
 int exchange_comm_ranks(const Ctx *c);      // ncclCommCount of the attached communicator, 0 if none
 void group_destroy(Ctx *c);
 // sharded ctx with an RCCL communicator attached (one process per GPU): scan -> local merge -> all-gather -> merge, all enqueued
-int xchg_tick_enqueue(Ctx *c, int64_t l, int64_t k, const chip_dot_params *p, Slot &s);
-int xchg_query(Ctx *c, int64_t k, const void *const *q, int nq, int K, double *scores, int64_t *idx);
+int xchg_tick_enqueue(Ctx *c, int64_t l, int64_t k, const chip_dot_params *p, Slot &s, bool fail_local);
+int xchg_query(Ctx *c, int64_t k, const void *const *q, int nq, int K, double *scores, int64_t *idx, bool fail_local);
+int xchg_fetch_rows(Ctx *c, const int64_t *rows, int nq, int64_t n_local_published, const void **q, bool *fail_local);
 // group ctx (chip_create_multi): every entry point of the header that makes sense on a group
 int group_append(Ctx *gc, const void *desc, int src_elem, int64_t n, uint32_t flags, int64_t *first_index);
 int group_append_synthetic(Ctx *gc, int64_t n, uint64_t seed, const int64_t *pd, const int64_t *ps, const int32_t *pk, int64_t n_plant);

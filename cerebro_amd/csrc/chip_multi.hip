@@ -10,8 +10,13 @@
 //     communicator or -- when devices repeat (a 1-GPU box running the G-way code path) or on request -- by device copies.
 // The payload is 384 B per shard per tick (topk 8): latency-bound, xGMI bandwidth is irrelevant.
 #include "chip_internal.h"
+#include "topk_merge.h"
 #include <rccl/rccl.h>
+#include <atomic>
 #include <condition_variable>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -40,7 +45,11 @@ struct Exchange {
     chip_topk_entry *local_ring = nullptr;      // [kXRing][kListEntries]          this shard's lists of a tick
     chip_topk_entry *gathered_ring = nullptr;   // [kXRing][world][kListEntries]   all shards' lists ([world][nq][K] packed)
     hipEvent_t ev_local[kXRing] = {};           // copy exchange: this shard's list of tick b is written
+    chip_topk_entry *failed_list = nullptr;     // [kListEntries] of (-inf, kFailedShardIdx): what a shard that cannot take part sends
     uint64_t n = 0;                             // ticks / queries exchanged so far (one-process-per-GPU layout)
+    uint64_t n_calls = 0;                       // collective calls seen by this shard (test hook below)
+    int test_fail_every = 0;                    // CHIP_TEST_FAIL_SHARD="rank:every": this shard fails its validation on every
+                                                // `every`-th collective call -- exercises the failure-mark path on a healthy box
     chip_topk_entry *local(int b) const { return local_ring + (size_t)b * kListEntries; }
     chip_topk_entry *gathered(int b) const { return gathered_ring + (size_t)b * world * kListEntries; }
 };
@@ -54,7 +63,24 @@ static int exchange_create(Ctx *c, int world, bool need_gathered)
     CHIP_HIP(c, hipMalloc(&x->local_ring, sizeof(chip_topk_entry) * kXRing * kListEntries));
     if (need_gathered) CHIP_HIP(c, hipMalloc(&x->gathered_ring, sizeof(chip_topk_entry) * kXRing * kListEntries * (size_t)world));
     for (int i = 0; i < kXRing; i++) CHIP_HIP(c, hipEventCreateWithFlags(&x->ev_local[i], hipEventDisableTiming));
+    {
+        std::vector<chip_topk_entry> mark((size_t)kListEntries);
+        for (chip_topk_entry &e : mark) { e.score = -INFINITY; e.idx = kFailedShardIdx; }
+        CHIP_HIP(c, hipMalloc(&x->failed_list, sizeof(chip_topk_entry) * kListEntries));
+        CHIP_HIP(c, hipMemcpy(x->failed_list, mark.data(), sizeof(chip_topk_entry) * kListEntries, hipMemcpyHostToDevice));
+    }
+    if (const char *t = std::getenv("CHIP_TEST_FAIL_SHARD")) {
+        int r = -1, every = 0;
+        if (std::sscanf(t, "%d:%d", &r, &every) == 2 && r == c->rank && every > 0) x->test_fail_every = every;
+    }
     return CHIP_OK;
+}
+
+// test hook: does this shard pretend its validation failed on this collective call?
+static bool test_fail_now(Exchange *x)
+{
+    x->n_calls++;
+    return x->test_fail_every > 0 && x->n_calls % (uint64_t)x->test_fail_every == 0;
 }
 
 void exchange_destroy(Ctx *c)
@@ -65,6 +91,7 @@ void exchange_destroy(Ctx *c)
     if (x->comm) (void)ncclCommDestroy(x->comm);
     if (x->local_ring) (void)hipFree(x->local_ring);
     if (x->gathered_ring) (void)hipFree(x->gathered_ring);
+    if (x->failed_list) (void)hipFree(x->failed_list);
     for (hipEvent_t e : x->ev_local)
         if (e) (void)hipEventDestroy(e);
     delete x;
@@ -79,31 +106,74 @@ int exchange_comm_ranks(const Ctx *c)
 }
 
 // ------------------------------------------------------------------------------------------------ one process per GPU
+// A rank whose own validation fails (its query rows have left its ring under a concurrent bulk append, its appender has not
+// published row l yet, ...) must NOT leave a collective call: the other ranks have enqueued their ncclAllGather and the next
+// collective of this rank would pair with it.  It takes part with the marked neutral list instead (Exchange::failed_list); the
+// merge kernel of every rank sees the mark (topk_merge.h) and the call fails with CHIP_ERR_SHARD_FAILED on all of them alike --
+// communicators never go out of step, the caller retries.  Only HIP / RCCL errors are hard.
 // caller: tick_enqueue_slot (query_mu held, device current, tick_prepare said SCANNED)
-int xchg_tick_enqueue(Ctx *c, int64_t l, int64_t k, const chip_dot_params *p, Slot &s)
+int xchg_tick_enqueue(Ctx *c, int64_t l, int64_t k, const chip_dot_params *p, Slot &s, bool fail_local)
 {
     Exchange *x = c->xchg;
     const int K = CHIP_DEFAULT_TOPK;
     const int64_t rows[3] = {l - 1, l - 2, l - 3};  // v, vm, vmm (Cerebro.cpp:987-989)
     const void *q[3];
     RingGuard rg(c);
-    int rc = query_row_ptrs(c, rows, 3, l, q);
-    if (rc != CHIP_OK) return rc;
+    if (test_fail_now(x)) fail_local = true;
+    if (!fail_local) {
+        const int vrc = query_row_ptrs(c, rows, 3, l, q);
+        if (vrc == CHIP_ERR_RANGE) fail_local = true;
+        else if (vrc != CHIP_OK) return vrc;
+    }
     const int b = (int)(x->n++ % kXRing);
-    rc = enqueue_scan_merge(c, k, q, 3, K, l, nullptr, x->local(b), nullptr, true, nullptr);   // scan streams -> local merge on the ctx stream
-    if (rc != CHIP_OK) return rc;
-    CHIP_NCCL(c, ncclAllGather(x->local(b), x->gathered(b), sizeof(chip_topk_entry) * 3 * K, ncclChar, x->comm, c->s_query));
+    const chip_topk_entry *mine = x->failed_list;
+    if (!fail_local) {
+        const int rc = enqueue_scan_merge(c, k, q, 3, K, l, nullptr, x->local(b), nullptr, true, nullptr);   // scan streams -> local merge on the ctx stream
+        if (rc != CHIP_OK) return rc;
+        mine = x->local(b);
+    }
+    CHIP_NCCL(c, ncclAllGather(mine, x->gathered(b), sizeof(chip_topk_entry) * 3 * K, ncclChar, x->comm, c->s_query));
     return merge_enqueue_slot(c, l, p, x->gathered(b), x->world, K, s);               // merge + decision (:1035-1056), every rank
 }
 
-int xchg_query(Ctx *c, int64_t k, const void *const *q, int nq, int K, double *scores, int64_t *idx)
+// Query rows of a sharded ctx with an exchange: every row has exactly one owner that keeps it for good (row % world), so it is
+// BROADCAST from there into this rank's query buffer (16 KiB at D = 4096) -- any appended row can be a query row, not only the
+// newest CHIP_RING_ROWS that the tick reads from the replicated ring.  Which path a row takes must not depend on per-rank state
+// (the ranks' appenders run independently), so chip_query_rows / chip_query_scores always fetch.  *fail_local: this rank owns a
+// row it has not published yet.
+int xchg_fetch_rows(Ctx *c, const int64_t *rows, int nq, int64_t n_local_published, const void **q, bool *fail_local)
 {
     Exchange *x = c->xchg;
+    const size_t rb = (size_t)c->D * c->elem;
+    for (int i = 0; i < nq; i++) {
+        const int64_t g = rows[i];
+        if (g < 0) return CHIP_ERR_RANGE;                 // the same on every rank
+        const int owner = (int)(g % x->world);
+        char *dst = static_cast<char *>(c->qvec_dev) + (size_t)i * rb;
+        const void *src = dst;
+        if (owner == c->rank) {
+            if (g >= n_local_published) *fail_local = true;   // garbage goes out, and the failure mark with it
+            else src = row_ptr_host(c, local_of(c, g));
+        }
+        CHIP_NCCL(c, ncclBroadcast(src, dst, rb, ncclChar, owner, x->comm, c->s_scan));
+        q[i] = dst;
+    }
+    return CHIP_OK;
+}
+
+int xchg_query(Ctx *c, int64_t k, const void *const *q, int nq, int K, double *scores, int64_t *idx, bool fail_local)
+{
+    Exchange *x = c->xchg;
+    if (test_fail_now(x)) fail_local = true;
     const int b = (int)(x->n++ % kXRing);
-    int rc = enqueue_scan_merge(c, k, q, nq, K, 0, nullptr, x->local(b), nullptr, false, nullptr);
-    if (rc != CHIP_OK) return rc;
-    CHIP_NCCL(c, ncclAllGather(x->local(b), x->gathered(b), sizeof(chip_topk_entry) * nq * K, ncclChar, x->comm, c->s_query));
-    rc = merge_enqueue_out(c, x->gathered(b), x->world, nq, K, c->topk_dev);
+    const chip_topk_entry *mine = x->failed_list;
+    if (!fail_local) {
+        const int rc = enqueue_scan_merge(c, k, q, nq, K, 0, nullptr, x->local(b), nullptr, false, nullptr);
+        if (rc != CHIP_OK) return rc;
+        mine = x->local(b);
+    }
+    CHIP_NCCL(c, ncclAllGather(mine, x->gathered(b), sizeof(chip_topk_entry) * nq * K, ncclChar, x->comm, c->s_query));
+    const int rc = merge_enqueue_out(c, x->gathered(b), x->world, nq, K, c->topk_dev);
     if (rc != CHIP_OK) return rc;
     return sync_topk_out(c, nq, K, scores, idx);
 }
@@ -139,7 +209,16 @@ struct Group {
     std::vector<char> same_dev;        // subs[g] lives on the root's device
     int transport = CHIP_EXCHANGE_COPY;
     uint64_t n = 0;                    // ticks / queries exchanged so far
+    std::atomic<int> broken{0};        // non-zero: a call failed on SOME devices after they had diverged (rings written, lengths
+                                       // published, a collective half enqueued) -- every later call returns CHIP_ERR_GROUP_BROKEN
 };
+
+static int group_break(Group *G, int rc)
+{
+    int expect = 0;
+    G->broken.compare_exchange_strong(expect, rc);
+    return rc;
+}
 
 static void worker_main(Worker *w, int device)
 {
@@ -218,27 +297,85 @@ static void mirror_state(Ctx *gc)
 }
 
 // ------------------------------------------------------------------------------------------------ group: DB
+// M.col(_s) = desc for a group (Cerebro.cpp:1005-1006; after loadStateFromDisk the first tick copies ALL columns, :133-161 --
+// the bulk path).  Every device receives only the rows it owns (a strided gather out of the caller's batch: device g gets rows
+// i % G == g) plus the newest CHIP_RING_ROWS rows of the batch for its replicated query ring, so a cold start of 1M x 4096 moves
+// ~1x the batch over PCIe instead of Gx.  The call is phased so that the devices cannot diverge:
+//   1. reserve capacity on every device                                   -- a failure changes nothing;
+//   2. store + validate the owned rows on every device (unpublished)      -- a failure changes nothing visible;
+//   3. ONE decision from the OR of the per-device validation bits (non-finite / not float32-representable / switch the empty
+//      undecided DB to double rows everywhere and redo 1-2);
+//   4. ring update + publish the new length on every device               -- a failure here leaves devices with different
+//      lengths / rings: the group is marked broken and refuses further work.
 int group_append(Ctx *gc, const void *desc, int src_elem, int64_t n, uint32_t flags, int64_t *first_index)
 {
     if (!desc || n < 0) return CHIP_ERR_INVALID_ARG;
     Group *G = gc->group;
     std::lock_guard<std::mutex> alk(gc->append_mu);
-    // every device is fed the same stream and keeps the rows it owns (+ the replicated ring of the newest rows); the
-    // storage-type decision of an undecided DB depends on the data only, so all devices take it alike
-    std::vector<int64_t> first(G->subs.size(), -1);
-    const int rc = run_all(G, [&](int g) { return ctx_append(G->subs[g], desc, src_elem, n, flags, &first[(size_t)g]); });
-    if (first_index) *first_index = first[0];
+    if (G->broken) return CHIP_ERR_GROUP_BROKEN;
+    const int64_t first = published_rows(G->subs[0]);
+    if (first_index) *first_index = first;
+    if (n == 0) return CHIP_OK;
+    const size_t ng = G->subs.size();
+    auto on_dev = [&](int g, const std::function<int(Ctx *)> &fn) -> int {
+        Ctx *c = G->subs[(size_t)g];
+        std::lock_guard<std::mutex> lk(c->append_mu);
+        CHIP_HIP(c, hipSetDevice(c->device));
+        return fn(c);
+    };
+    std::vector<uint32_t> bad(ng, 0u);
+    uint32_t any_bad = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int rc = run_all(G, [&](int g) { return on_dev(g, [&](Ctx *c) { return append_reserve(c, first, n); }); });
+        if (rc != CHIP_OK) return rc;
+        rc = run_all(G, [&](int g) { return on_dev(g, [&](Ctx *c) { return append_store_db(c, desc, src_elem, first, n, true, &bad[(size_t)g]); }); });
+        if (rc != CHIP_OK) return rc;
+        any_bad = 0;
+        for (uint32_t b : bad) any_bad |= b;
+        if (any_bad & 2u) return CHIP_ERR_NONFINITE;
+        if (!(any_bad & 1u)) break;
+        if (attempt == 0 && append_can_switch_to_double(G->subs[0], first)) {
+            rc = run_all(G, [&](int g) { return on_dev(g, [&](Ctx *c) { return append_switch_to_double(c, n); }); });
+            if (rc != CHIP_OK) return group_break(G, rc);   // some devices may hold double rows now, others float rows
+            continue;
+        }
+        if (flags & CHIP_APPEND_ALLOW_ROUNDING) break;
+        return CHIP_ERR_NOT_F32;
+    }
+    const bool lossy = (any_bad & 1u) != 0;
+    const int rc = run_all(G, [&](int g) { return on_dev(g, [&](Ctx *c) { return append_ring_publish(c, desc, src_elem, first, n, lossy); }); });
+    if (rc != CHIP_OK) return group_break(G, rc);
     mirror_state(gc);
-    return rc;
+    return CHIP_OK;
 }
 
 int group_append_synthetic(Ctx *gc, int64_t n, uint64_t seed, const int64_t *pd, const int64_t *ps, const int32_t *pk, int64_t n_plant)
 {
     Group *G = gc->group;
     std::lock_guard<std::mutex> alk(gc->append_mu);
-    const int rc = run_all(G, [&](int g) { return ctx_append_synthetic(G->subs[g], n, seed, pd, ps, pk, n_plant); });
+    if (G->broken) return CHIP_ERR_GROUP_BROKEN;
+    if (n < 0 || n_plant < 0 || (n_plant > 0 && (!pd || !ps || !pk))) return CHIP_ERR_INVALID_ARG;
+    const int64_t first = published_rows(G->subs[0]);
+    for (int64_t i = 0; i < n_plant; i++) {
+        if (pd[i] < first || pd[i] >= first + n || ps[i] < 0) return CHIP_ERR_RANGE;
+        if (i > 0 && pd[i] <= pd[i - 1]) return CHIP_ERR_INVALID_ARG;
+        if (pk[i] != 1 && pk[i] != 2) return CHIP_ERR_INVALID_ARG;
+    }
+    if (n == 0) return CHIP_OK;
+    auto on_dev = [&](int g, const std::function<int(Ctx *)> &fn) -> int {
+        Ctx *c = G->subs[(size_t)g];
+        std::lock_guard<std::mutex> lk(c->append_mu);
+        CHIP_HIP(c, hipSetDevice(c->device));
+        return fn(c);
+    };
+    int rc = run_all(G, [&](int g) { return on_dev(g, [&](Ctx *c) { return append_reserve(c, first, n); }); });
+    if (rc != CHIP_OK) return rc;
+    // the generator writes the rings as it goes: from here on a failure on one device leaves the others ahead of it
+    rc = run_all(G, [&](int g) { return on_dev(g, [&](Ctx *c) { return synth_generate(c, first, n, seed, pd, ps, pk, n_plant); }); });
+    if (rc != CHIP_OK) return group_break(G, rc);
+    for (chip_ctx *c : G->subs) append_publish(c, first + n, false, n);
     mirror_state(gc);
-    return rc;
+    return CHIP_OK;
 }
 
 int group_read_rows(Ctx *gc, const int64_t *rows, int64_t n, void *out, int out_elem)
@@ -291,32 +428,69 @@ struct GroupScan {
     bool tick = false;
 };
 
-// device g's share: local scan -> local top-k list -> (RCCL) all-gather [-> root: merge]
-static int sub_scan(Group *G, int g, const GroupScan &j, int b)
+// Query rows of a group scan on device g.  Ticks read them from the device's replicated ring (the live path: no copy).  Any other
+// query row -- chip_query_rows / chip_query_scores, e.g. the offline all-vs-all of the faiss-style policies on a long run
+// (Cerebro.cpp:506-722) -- is fetched from the sub-context that OWNS it (row % G, which keeps it for good) into this device's
+// query buffer, on the stream the scan will run on: any appended row can be a query row, not only the newest CHIP_RING_ROWS.
+static int sub_query_rows(Group *G, int g, const GroupScan &j, const void **q)
+{
+    Ctx *c = G->subs[(size_t)g];
+    if (j.tick) return query_row_ptrs(c, j.rows, j.nq, j.n_global, q);
+    const size_t rb = (size_t)c->D * c->elem;
+    const int ng = (int)G->subs.size();
+    for (int i = 0; i < j.nq; i++) {
+        const int64_t r = j.rows[i];
+        if (r < 0 || r >= j.n_global) return CHIP_ERR_RANGE;
+        Ctx *o = G->subs[(size_t)(r % ng)];
+        const void *src = row_ptr_host(o, local_of(o, r));      // published rows never move
+        char *dst = static_cast<char *>(c->qvec_dev) + (size_t)i * rb;
+        if (o->device == c->device) CHIP_HIP(c, hipMemcpyAsync(dst, src, rb, hipMemcpyDeviceToDevice, c->s_scan));
+        else CHIP_HIP(c, hipMemcpyPeerAsync(dst, c->device, src, o->device, rb, c->s_scan));
+        q[i] = dst;
+    }
+    return CHIP_OK;
+}
+
+// device g's share: local scan -> local top-k list -> (RCCL) all-gather [-> root: merge].  A device whose validation fails (RANGE:
+// its query rows have left its ring under a concurrent bulk append) still takes part, with the marked neutral list, so that the
+// collectives of all devices stay paired; the root's merge reports the mark and the call fails as a whole (CHIP_ERR_SHARD_FAILED).
+// *hard gets set when a HIP / RCCL call failed: the devices may be out of step and the group is broken.
+static int sub_scan(Group *G, int g, const GroupScan &j, int b, std::atomic<int> *hard)
 {
     Ctx *c = G->subs[(size_t)g];
     Ctx *root = G->subs[0];
     Exchange *x = c->xchg;
     std::lock_guard<std::mutex> qlk(c->query_mu);
-    CHIP_HIP(c, hipSetDevice(c->device));
+    auto fail_hard = [&](int rc) { hard->store(1); return rc; };
+    if (hipSetDevice(c->device) != hipSuccess) return fail_hard(CHIP_ERR_HIP);
     const void *q[CHIP_MAX_NQ];
     RingGuard rg(c);
-    int rc = j.rows ? query_row_ptrs(c, j.rows, j.nq, j.n_global, q) : upload_query_vectors(c, j.vectors, j.vec_elem, j.nq, q);
-    if (rc != CHIP_OK) return rc;
+    bool soft = test_fail_now(x);
+    if (!soft) {
+        const int vrc = j.rows ? sub_query_rows(G, g, j, q) : upload_query_vectors(c, j.vectors, j.vec_elem, j.nq, q);
+        if (vrc == CHIP_ERR_RANGE || vrc == CHIP_ERR_NOT_F32 || vrc == CHIP_ERR_NONFINITE) {
+            if (!j.tick) return vrc;      // argument errors of a query are the same on every device: nothing was enqueued anywhere
+            soft = true;                  // a tick: per-device state (ring residency) -- take part with the mark
+        } else if (vrc != CHIP_OK) return fail_hard(vrc);
+    }
     const size_t list = (size_t)j.nq * j.K;
     const bool direct = G->transport == CHIP_EXCHANGE_COPY && G->same_dev[(size_t)g];   // straight into the root's gather buffer
     chip_topk_entry *dst = direct ? root->xchg->gathered(b) + (size_t)g * list : x->local(b);
-    rc = enqueue_scan_merge(c, j.k, q, j.nq, j.K, j.l, nullptr, dst, nullptr, j.tick, nullptr);
-    if (rc != CHIP_OK) return rc;
+    int rc;
+    if (!soft) rc = enqueue_scan_merge(c, j.k, q, j.nq, j.K, j.l, nullptr, dst, nullptr, j.tick, nullptr);
+    else rc = hipMemcpyAsync(dst, x->failed_list, sizeof(chip_topk_entry) * list, hipMemcpyDeviceToDevice, c->s_query) == hipSuccess ? CHIP_OK : CHIP_ERR_HIP;
+    if (rc != CHIP_OK) return fail_hard(rc);
     if (G->transport == CHIP_EXCHANGE_RCCL) {
         // one thread per device, each on its own communicator of the clique: the classic multi-threaded NCCL layout (no group call)
-        CHIP_NCCL(c, ncclAllGather(x->local(b), x->gathered(b), sizeof(chip_topk_entry) * list, ncclChar, x->comm, c->s_query));
+        const ncclResult_t nr = ncclAllGather(x->local(b), x->gathered(b), sizeof(chip_topk_entry) * list, ncclChar, x->comm, c->s_query);
+        if (nr != ncclSuccess) { c->last_comm = (int)nr; return fail_hard(CHIP_ERR_COMM); }
         if (g == 0) {
-            if (j.p) return merge_enqueue_slot(c, j.l, j.p, x->gathered(b), x->world, j.K, *j.slot);
-            return merge_enqueue_out(c, x->gathered(b), x->world, j.nq, j.K, c->topk_dev);
+            rc = j.p ? merge_enqueue_slot(c, j.l, j.p, x->gathered(b), x->world, j.K, *j.slot)
+                     : merge_enqueue_out(c, x->gathered(b), x->world, j.nq, j.K, c->topk_dev);
+            if (rc != CHIP_OK) return fail_hard(rc);
         }
     } else if (g != 0) {
-        CHIP_HIP(c, hipEventRecord(x->ev_local[b], c->s_query));
+        if (hipEventRecord(x->ev_local[b], c->s_query) != hipSuccess) return fail_hard(CHIP_ERR_HIP);
     }
     return CHIP_OK;
 }
@@ -342,10 +516,15 @@ static int root_gather_merge(Group *G, const GroupScan &j, int b)
 
 static int group_scan(Group *G, const GroupScan &j)
 {
+    if (G->broken) return CHIP_ERR_GROUP_BROKEN;
     const int b = (int)(G->n++ % kXRing);
-    int rc = run_all(G, [&](int g) { return sub_scan(G, g, j, b); });
-    if (rc != CHIP_OK) return rc;
-    if (G->transport == CHIP_EXCHANGE_COPY) rc = root_gather_merge(G, j, b);
+    std::atomic<int> hard{0};
+    int rc = run_all(G, [&](int g) { return sub_scan(G, g, j, b, &hard); });
+    if (rc != CHIP_OK) return hard.load() ? group_break(G, rc) : rc;
+    if (G->transport == CHIP_EXCHANGE_COPY) {
+        rc = root_gather_merge(G, j, b);
+        if (rc != CHIP_OK) return group_break(G, rc);
+    }
     return rc;
 }
 
@@ -354,6 +533,7 @@ int group_tick_enqueue(Ctx *gc, int64_t l, const chip_dot_params *p, int32_t slo
     Group *G = gc->group;
     Ctx *root = G->subs[0];
     std::lock_guard<std::mutex> qlk(gc->query_mu);
+    if (G->broken) return CHIP_ERR_GROUP_BROKEN;
     Slot &s = root->slots[slot];
     if (s.in_flight) return CHIP_ERR_BUSY;
     int64_t n;
@@ -365,6 +545,8 @@ int group_tick_enqueue(Ctx *gc, int64_t l, const chip_dot_params *p, int32_t slo
     int64_t k = 0;
     int rc = tick_prepare(n, gc->last_l, l, p, &status, &k);
     if (rc != CHIP_OK) return rc;
+    s.prev_last_l = gc->last_l;
+    s.last_l_ptr = &gc->last_l;
     if (status != CHIP_TICK_SCANNED) {
         if (status == CHIP_TICK_TOO_SHORT) gc->last_l = l;
         fill_immediate(s.host, status);
@@ -394,6 +576,7 @@ int group_query(Ctx *gc, int64_t k, const int64_t *rows, const void *vectors, in
     Group *G = gc->group;
     Ctx *root = G->subs[0];
     std::lock_guard<std::mutex> qlk(gc->query_mu);
+    if (G->broken) return CHIP_ERR_GROUP_BROKEN;
     GroupScan j;
     j.k = k; j.nq = nq; j.K = K; j.rows = rows; j.vectors = vectors; j.vec_elem = vec_elem;
     {
@@ -415,14 +598,16 @@ int group_scores(Ctx *gc, int64_t k, int64_t query_row, double *u)
         std::lock_guard<std::mutex> lk(gc->mu);
         n = gc->rows_global;
     }
+    if (G->broken) return CHIP_ERR_GROUP_BROKEN;
     const int ng = (int)G->subs.size();
+    GroupScan j;
+    j.nq = 1; j.rows = &query_row; j.n_global = n; j.tick = false;
     return run_all(G, [&](int g) -> int {
         Ctx *c = G->subs[(size_t)g];
         std::lock_guard<std::mutex> lk(c->query_mu);
         CHIP_HIP(c, hipSetDevice(c->device));
         const void *q[1];
-        RingGuard rg(c);
-        const int rc = query_row_ptrs(c, &query_row, 1, n, q);
+        const int rc = sub_query_rows(G, g, j, q);      // from the owner's shard into this device's query buffer (ctx_scores_local runs on s_scan too)
         if (rc != CHIP_OK) return rc;
         return ctx_scores_local(c, k, q[0], u, ng, ng == 1 ? 0 : g);   // disjoint entries of u per device
     });

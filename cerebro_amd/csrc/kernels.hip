@@ -730,6 +730,13 @@ int scan_grid_for(const Ctx *c, int64_t n_rows, int nq, bool q64)
     // because the collective's kernel is not ours to size.  Default: 0 on a plain ctx, 4 on a sharded ctx / group
     // sub-context.  CHIP_SCAN_RESERVE overrides.
     int64_t cap = (int64_t)c->n_cus * bpc - c->scan_reserve;
+    // Cache-sized prefixes (BASELINE config 2: 164 MB at 10k rows) are ticked over faster than a launch can ramp up and drain:
+    // per-wave stamps of a 10k-row launch show ~20 us of streaming at the memory system's limit inside a 33-40 us launch (spread of
+    // the wave starts, query staging, the workgroups' tails).  A launch that takes only HALF of every CU's workgroup slots lets the
+    // launches of consecutive ticks (alternating scan streams) be resident TOGETHER, so one tick streams while its neighbours ramp
+    // up / finish; 8 waves x 12 KiB in flight per CU already saturate the memory system.
+    if (bpc > 1 && c->scan_short_bpc > 0 && c->scan_short_bpc < bpc && (double)n_rows * c->D * c->elem <= c->scan_plain_bytes)
+        cap = (int64_t)c->n_cus * c->scan_short_bpc - c->scan_reserve;
     if (cap > c->max_grid) cap = c->max_grid;
     if (want > cap) want = cap;
     if (want < 1) want = 1;
@@ -836,6 +843,7 @@ struct StoreArgs {
     int32_t D;
     int32_t rank, nranks;
     int64_t first_global;
+    int64_t row_stride;  // staged row r is global row first_global + r * row_stride (1: a contiguous batch; G: one shard's rows only)
     int64_t n;
     int64_t ring_from;   // only global rows >= ring_from are mirrored into the ring (the newest CHIP_RING_ROWS)
     uint32_t *flags;
@@ -891,7 +899,7 @@ __global__ __launch_bounds__(256) void convert_rows(StoreArgs a, const S *__rest
             if (!(fabs((double)x[c]) <= 1.79769313486231570e308)) bad |= 2u;   // NaN / Inf
             else if (sizeof(T) < sizeof(S) && (S)v[c] != x[c]) bad |= 1u;        // not fp32-representable (incl. overflow)
         }
-        store_row4<T>(a, a.first_global + r, e, v);
+        store_row4<T>(a, a.first_global + r * a.row_stride, e, v);
     }
     if (bad) atomicOr(a.flags, bad);
 }
@@ -907,6 +915,7 @@ static StoreArgs make_store_args(Ctx *c, int64_t first_global, int64_t n, uint32
     a.rank = c->rank;
     a.nranks = c->nranks;
     a.first_global = first_global;
+    a.row_stride = 1;
     a.n = n;
     a.ring_from = first_global + n - CHIP_RING_ROWS;
     a.flags = flags;
@@ -923,9 +932,11 @@ static int grid_for_elems(const Ctx *c, int64_t total_threads)
 }
 
 // src_elem: 8 = float64 rows (the wire type), 4 = float rows; the destination type is the ctx's storage type
-int launch_store_rows(Ctx *c, hipStream_t s, const void *src, int src_elem, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring)
+int launch_store_rows(Ctx *c, hipStream_t s, const void *src, int src_elem, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring,
+                      int64_t row_stride)
 {
     StoreArgs a = make_store_args(c, first_global, n, flags_dev, write_ring);
+    a.row_stride = row_stride;
     const dim3 grid(grid_for_elems(c, n * (c->D / 4))), block(256);
     if (src_elem == 8 && c->elem == 4) hipLaunchKernelGGL((convert_rows<double, float>), grid, block, 0, s, a, static_cast<const double *>(src));
     else if (src_elem == 8) hipLaunchKernelGGL((convert_rows<double, double>), grid, block, 0, s, a, static_cast<const double *>(src));

@@ -22,6 +22,7 @@ __device__ __forceinline__ bool key_gt(double s, int64_t i, double s2, int64_t i
 // `in` is [n_lists][list_stride queries][K]; this workgroup merges queries q_off .. q_off+NQ-1 into out[0..NQ)[K].
 // smem: kMergeSmem bytes.
 constexpr int kMergeSmem = 28 * 1024;
+constexpr int64_t kFailedShardIdx = -2;   // index of every entry of the list a failed shard contributes (unused slots carry -1)
 constexpr int kSurvCap = CHIP_MAX_TOPK * CHIP_MAX_TOPK;  // 256
 
 __device__ __forceinline__ double readlane_f64(double v, int j)
@@ -100,6 +101,7 @@ __device__ __forceinline__ void merge_sorted_lists(const chip_topk_entry *in, in
     chip_topk_entry *T1s = surv + CHIP_MAX_NQ * kSurvCap;                                   // [NQ]
     chip_topk_entry *tops = T1s + CHIP_MAX_NQ;                                              // [NQ]
     int *cnt = reinterpret_cast<int *>(tops + CHIP_MAX_NQ);                                 // [NQ]
+    int *failed = cnt + CHIP_MAX_NQ;                                                        // a list carries the failure mark
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6, nw = blockDim.x >> 6;
 
@@ -112,6 +114,7 @@ __device__ __forceinline__ void merge_sorted_lists(const chip_topk_entry *in, in
         else { hs[q] = -INFINITY; hi[q] = -1; }
     }
     if (t < NQ) cnt[t] = 0;
+    if (t == NQ) *failed = 0;
     // ---- 2. per-wave rank of the heads; the K best of each wave go to candA[q][w*K + rank] ----
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
@@ -123,6 +126,9 @@ __device__ __forceinline__ void merge_sorted_lists(const chip_topk_entry *in, in
         if (lane < K && lane >= nvalid) { dst[lane].score = -INFINITY; dst[lane].idx = -1; }
     }
     __syncthreads();
+    // a shard that could not take part in this exchange sent the marked neutral list (kFailedShardIdx in every entry): the merge
+    // ignores its entries like any unused slot and reports the mark, so that EVERY rank fails the call alike (chip_multi.hip)
+    if (t < n_lists && hi[0] == kFailedShardIdx) *failed = 1;
     // ---- 3. T1[q] = K-th best head overall (or "everything survives" when fewer than K lists are non-empty) ----
     if (w < NQ) {
         const int q = w;
@@ -201,9 +207,10 @@ __device__ __forceinline__ void merge_sorted_lists(const chip_topk_entry *in, in
         }
     }
     __syncthreads();
+    if (out != nullptr && t == 0 && *failed) out[0].idx = kFailedShardIdx;
     if (result != nullptr && t == 0) {
         chip_tick_result res;
-        res.status = CHIP_TICK_SCANNED;
+        res.status = *failed ? CHIP_TICK_FAILED : CHIP_TICK_SCANNED;
         res.found = 0;
         res.idx_curr = -1;
         res.idx_prev = -1;

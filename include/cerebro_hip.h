@@ -42,7 +42,12 @@ enum {
     CHIP_ERR_UNSUPPORTED = -8,      /* e.g. D not a multiple of 4, topk > CHIP_MAX_TOPK, nq > CHIP_MAX_NQ  */
     CHIP_ERR_TOO_FEW_POINTS = -9,   /* PnP with < 20 correspondences (DlsPnpWithRansac.cpp:136-139 returns -1) */
     CHIP_ERR_BUSY = -10,            /* async slot still in flight / not enqueued                          */
-    CHIP_ERR_COMM = -11             /* an RCCL call failed; chip_last_comm_error() has the ncclResult_t    */
+    CHIP_ERR_COMM = -11,            /* an RCCL call failed; chip_last_comm_error() has the ncclResult_t    */
+    CHIP_ERR_SHARD_FAILED = -12,    /* a shard of a sharded DB could not take part in this tick / query (e.g. its query rows had
+                                       left its ring under a concurrent bulk append); EVERY rank gets this status for that call,
+                                       the call had no effect (last_l is not advanced) and the exchange stays in step: retry */
+    CHIP_ERR_GROUP_BROKEN = -13     /* an earlier call failed on some devices of a chip_create_multi ctx after they had
+                                       diverged (or its communicator failed): the ctx refuses further work -- destroy it */
 };
 
 #define CHIP_MAX_TOPK 16
@@ -184,7 +189,9 @@ void chip_dot_params_default(chip_dot_params *p);
 
 enum { CHIP_TICK_SKIPPED = 0,   /* l - last_l < min_new: nothing done, last_l NOT advanced (:962-966)     */
        CHIP_TICK_TOO_SHORT = 1, /* ran, but k = l - lag <= min_k (:1022 else-branch); last_l = l          */
-       CHIP_TICK_SCANNED = 2 }; /* scan + decision executed; last_l = l                                   */
+       CHIP_TICK_SCANNED = 2,   /* scan + decision executed; last_l = l                                   */
+       CHIP_TICK_FAILED = 3 };  /* sharded ticks only, never returned with CHIP_OK: a shard could not take part; the collecting
+                                   call returns CHIP_ERR_SHARD_FAILED on every rank and last_l is as before the tick       */
 
 typedef struct {
     int32_t status;      /* CHIP_TICK_*                                                                   */

@@ -20,7 +20,7 @@ import numpy as np  # noqa: E402
 import bench  # noqa: E402
 from cerebro_amd import capi  # noqa: E402
 
-KNOBS = ("CHIP_SCAN_ROWS", "CHIP_TICK_SAME_STREAM", "CHIP_SCAN_PLAIN_MIB", "CHIP_SCAN_VARIANT", "CHIP_SCAN_STREAMS", "CHIP_SCAN_ROWS_AUTO_MAX")
+KNOBS = ("CHIP_SCAN_ROWS", "CHIP_TICK_SAME_STREAM", "CHIP_SCAN_PLAIN_MIB", "CHIP_SCAN_VARIANT", "CHIP_SCAN_STREAMS", "CHIP_SCAN_ROWS_AUTO_MAX", "CHIP_SCAN_SHORT_BPC", "CHIP_SCAN_STREAMS3")
 
 
 def run_config(rows, env, n_ticks, inflight):
@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--rows", default="10000,100000")
     ap.add_argument("--ticks", type=int, default=600)
     ap.add_argument("--inflight", type=int, default=16)
-    ap.add_argument("--set", default="short", choices=["short", "long"])
+    ap.add_argument("--set", default="short", choices=["short", "long", "half"])
     args = ap.parse_args()
     short = [
         {"CHIP_SCAN_ROWS": -1, "CHIP_TICK_SAME_STREAM": 0},                                  # round-2 behaviour
@@ -86,9 +86,18 @@ def main():
         {"CHIP_SCAN_ROWS": 3},
         {"CHIP_SCAN_ROWS": -1, "CHIP_SCAN_VARIANT": 7},     # legacy kernel without the fp64 query staging
     ]
+    half = [
+        {"CHIP_SCAN_SHORT_BPC": 0},                                    # full-occupancy launches (call A's default)
+        {"CHIP_SCAN_SHORT_BPC": 1},                                    # half-occupancy launches, two ticks resident together
+        {"CHIP_SCAN_SHORT_BPC": 1, "CHIP_SCAN_ROWS": 1},
+        {"CHIP_SCAN_SHORT_BPC": 1, "CHIP_SCAN_ROWS": 2},
+        {"CHIP_SCAN_SHORT_BPC": 1, "CHIP_SCAN_PLAIN_MIB": 0},
+        {"CHIP_SCAN_SHORT_BPC": 1, "CHIP_TICK_SAME_STREAM": 0},
+        {"CHIP_SCAN_SHORT_BPC": 1, "CHIP_SCAN_ROWS": -1},              # legacy one-row kernel at half occupancy
+    ]
     for rows in [int(x) for x in args.rows.split(",")]:
         ref = None
-        for env in (short if args.set == "short" else long_):
+        for env in {"short": short, "long": long_, "half": half}[args.set]:
             try:
                 r, sig = run_config(rows, env, args.ticks, args.inflight)
             except Exception as e:  # noqa: BLE001

@@ -118,9 +118,19 @@ def test_group_8way_4096d_growth_and_pose():
         assert list(r.argmax) == list(wix[:, 0]) and [float(x).hex() for x in r.maxv] == [float(x).hex() for x in wsc[:, 0]]
         got = chip.query_rows(l - 50, [l - 1, l - 2, l - 3], 8)
         assert np.array_equal(got[1], wix) and np.array_equal(bits(got[0]), bits(wsc))
-        # the newest rows are query-able on every shard (ring), old rows are not query rows any more (documented limit)
+        # ANY appended row can be a query row of chip_query_rows / chip_query_scores: rows that have left the replicated ring are
+        # fetched from the sub-context that owns them (round 2 returned CHIP_ERR_RANGE here)
+        old_rows = [5, 4098, p]
+        oq = oracle_lib.synth_rows(seed, old_rows, D, plants)
+        for k1 in (100, 9_000, l - 50):
+            wsc2, wix2 = oracle_lib.scan_topk_synth(seed, k1, D, oq, 5, plants, nthreads=8)
+            got2 = chip.query_rows(k1, old_rows, 5)
+            assert np.array_equal(got2[1], wix2) and np.array_equal(bits(got2[0]), bits(wsc2))
+        u = chip.query_scores(3000, 5)
+        db3k = oracle_lib.synth_rows(seed, range(3000), D, plants)
+        assert np.array_equal(bits(u), bits(oracle_lib.scores(db3k, 3000, oq[0])))
         with pytest.raises(capi.ChipError) as e:
-            chip.query_rows(100, [5], 1)
+            chip.query_rows(100, [N], 1)           # not an appended row
         assert e.value.status == capi.CHIP_ERR_RANGE
         X, uv, T, inl = M.make_scene(N=200, outlier_frac=0.2, noise_px=0.5, seed=7)
         prm = capi.default_ransac_params(); prm.n_hypotheses = 64; prm.seed = 7
@@ -301,3 +311,112 @@ def test_comm_init_rank_real_processes_over_rccl(tmp_path):
     ret = mgr.dict()
     mp.spawn(_rccl_rank_worker, args=(world, str(tmp_path / "uid.bin"), ret), nprocs=world, join=True)
     assert len(ret) == world and len(set(ret.values())) == 1 and next(iter(ret.values())) > 0
+
+
+@pytest.mark.parametrize("G", [3, 8])
+def test_group_bulk_append_owner_only(G):
+    """Bulk appends that outrun the ring (the cold start after loadStateFromDisk, Cerebro.cpp:133-161,1005): every device is sent
+    only the rows it owns (+ the newest CHIP_RING_ROWS for its ring); rows read back from their owners and the ticks over them are
+    those of the oracle, for float64 and float32 wire types and batch starts at every residue."""
+    D = 256
+    sizes = [5000, 1, 4097, 7, 9001, 2]                 # > ring, tiny, ring + 1, ...
+    N = sum(sizes)
+    plants, loops, ties = scenarios.loop_plants(N, 8, seed=11 + G)
+    db = scenarios.build_db(900 + G, N, D, plants)
+    with capi.Chip(D, devices=[0] * G) as chip:
+        at = 0
+        for i, m in enumerate(sizes):
+            blk = db[at:at + m]
+            assert (chip.append_f64(blk.astype(np.float64)) if i % 2 == 0 else chip.append_f32(blk)) == at
+            at += m
+            assert chip.size() == at and chip.info()["rows_local"] == len(range(0, at, G))
+        rows = list(range(0, N, 613)) + [4095, 4096, 4097, 5000, 5001, N - 1]
+        assert chip.read_rows(rows).tobytes() == db[rows].tobytes()
+        sched = sorted(set(scenarios.default_schedule(N)[::9]) | {lp[0] for lp in loops})
+        orc = oracle_lib.LoopOracle(db)
+        for l in sched:
+            same_tick(chip.loop_tick(l), orc.tick(l))
+        # a batch with a non-finite value is rejected as a whole on every device, whichever device owns the bad row
+        bad = db[:G + 2].astype(np.float64).copy()
+        bad[G, 3] = np.nan
+        with pytest.raises(capi.ChipError) as e:
+            chip.append_f64(bad)
+        assert e.value.status == capi.CHIP_ERR_NONFINITE and chip.size() == N
+        nf32 = db[:G + 2].astype(np.float64).copy()
+        nf32[1, 0] = 0.1                                  # not float32-representable: the float DB already holds rows
+        with pytest.raises(capi.ChipError) as e:
+            chip.append_f64(nf32)
+        assert e.value.status == capi.CHIP_ERR_NOT_F32 and chip.size() == N
+        assert chip.append_f32(db[:3]) == N               # and the group is still usable
+
+
+def test_group_auto_switch_to_double_is_one_decision():
+    """An undecided group DB whose first batch holds ONE value that is not float32-representable -- owned by one device only --
+    becomes a double-row DB on every device (the decision is taken from the OR of the devices' validation bits)."""
+    D, N, G = 128, 40, 4
+    db = oracle_lib.synth_rows(3, range(N), D).astype(np.float64)
+    db[6, 17] = 0.1                                       # row 6 lives on device 2
+    with capi.Chip(D, devices=[0] * G) as chip:
+        assert chip.append_f64(db) == 0
+        assert chip.info()["storage_bytes"] == 8
+        back = chip.read_rows_f64(list(range(N))) if hasattr(chip, "read_rows_f64") else None
+        if back is not None:
+            assert back.tobytes() == db.tobytes()
+        sc, ix = chip.query_rows(N, [6], 1)
+        assert ix[0][0] == 6
+
+
+def test_failed_shard_marks_the_tick_for_everyone(monkeypatch):
+    """A shard whose own validation fails must not leave a collective tick (the others have enqueued their exchange): it takes part
+    with the marked neutral list, the merge reports the mark, the call fails with CHIP_ERR_SHARD_FAILED, last_l is as before, and
+    the NEXT tick is correct again -- the exchange never goes out of step.  CHIP_TEST_FAIL_SHARD makes shard 2 fail every 5th call."""
+    monkeypatch.setenv("CHIP_TEST_FAIL_SHARD", "2:5")
+    D, N, G = 512, 1300, 4
+    plants, loops, ties = scenarios.loop_plants(N, 5, seed=91)
+    db = scenarios.build_db(77, N, D, plants)
+    with capi.Chip(D, devices=[0] * G) as chip:
+        chip.append_f32(db)
+        orc = oracle_lib.LoopOracle(db)
+        n_failed = n_ok = 0
+        for l in scenarios.default_schedule(N):
+            before = chip.last_l()
+            try:
+                g = chip.loop_tick(l)
+            except capi.ChipError as e:
+                assert e.status == capi.CHIP_ERR_SHARD_FAILED
+                assert chip.last_l() == before             # the tick had no effect
+                n_failed += 1
+                g = chip.loop_tick(l)                       # retry: the shard takes part again
+            same_tick(g, orc.tick(l))
+            n_ok += 1
+        assert n_failed >= 10 and n_ok == len(scenarios.default_schedule(N))
+        # pipelined: the failed slot reports at collect time, the slots around it are untouched
+        sched = scenarios.default_schedule(N)[:80]
+        stateless = oracle_lib.LoopOracle(db)
+        n_failed = 0
+        for base in range(0, len(sched), 4):
+            chunk = sched[base:base + 4]
+            chip.loop_reset()
+            for s_, l in enumerate(chunk):
+                chip.loop_tick_enqueue(l, s_)
+            for s_, l in enumerate(chunk):
+                try:
+                    g = chip.loop_tick_collect(s_)
+                except capi.ChipError as e:
+                    assert e.status == capi.CHIP_ERR_SHARD_FAILED
+                    n_failed += 1
+                    continue
+                stateless.state.last_l = 0
+                same_tick(g, stateless.tick(l))
+        assert n_failed >= 10
+        # queries carry the mark too
+        seen = 0
+        for _ in range(12):
+            try:
+                got = chip.query_rows(N - 50, [N - 1], 4)
+                want = oracle_lib.scan_topk(db, N - 50, db[[N - 1]], 4)
+                assert np.array_equal(got[1], want[1])
+            except capi.ChipError as e:
+                assert e.status == capi.CHIP_ERR_SHARD_FAILED
+                seen += 1
+        assert seen >= 1
