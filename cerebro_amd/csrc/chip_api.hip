@@ -155,6 +155,8 @@ void ctx_destroy(chip_ctx *c)
     }
     if (c->s_scan) (void)hipStreamDestroy(c->s_scan);
     if (c->s_scan2) (void)hipStreamDestroy(c->s_scan2);
+    for (hipStream_t x : c->s_scan_x)
+        if (x) (void)hipStreamDestroy(x);
     if (c->topk_host) (void)hipHostFree(c->topk_host);
     if (c->qvec_dev) (void)hipFree(c->qvec_dev);
     if (c->scores_dev) (void)hipFree(c->scores_dev);
@@ -217,7 +219,16 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
             CHIP_HIP(c, hipStreamCreateWithPriority(&c->s_scan, hipStreamNonBlocking, pr > 0 ? hi : lo));
         }
     }
-    if (env_int("CHIP_SCAN_STREAMS", 2) >= 2) CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_scan2, hipStreamNonBlocking));
+    {
+        // Tick streams.  Short ticks of a plain ctx run scan + merge on ONE stream and rotate over up to four of them: a 10k-row tick
+        // is ~37 us of scan, ~15 us of one-workgroup merge and ~12 us of launch / event gap per stream (rocprofv3 timeline,
+        // profiles/r03_tick_timeline_10k.md), so two streams leave the memory system idle a third of the time.  Sharded / group
+        // contexts (merge + exchange on the ctx stream) use the first two only.
+        const int ns = env_int("CHIP_SCAN_STREAMS", c->nranks > 1 ? 2 : 4);
+        if (ns >= 2) CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_scan2, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++)
+            if (ns >= 3 + i) CHIP_HIP(c, hipStreamCreateWithFlags(&c->s_scan_x[i], hipStreamNonBlocking));
+    }
     for (int i = 0; i < Ctx::kRing; i++) {
         CHIP_HIP(c, hipMalloc(&c->partial_dev[i], (size_t)c->max_grid * CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry)));
         CHIP_HIP(c, hipEventCreateWithFlags(&c->ev_scan[i], hipEventDisableTiming));
@@ -278,7 +289,8 @@ int ctx_create(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device,
 // [nq][K]; res (optional) the decision record of Cerebro.cpp:1056.  Consecutive calls pipeline: scans run back to
 // back on s_scan while the previous merge (and whatever the caller enqueues after it on the ctx stream) proceeds.
 int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, int64_t l,
-                       const chip_dot_params *p, chip_topk_entry *out, chip_tick_result *res, bool tick, hipStream_t *merge_stream)
+                       const chip_dot_params *p, chip_topk_entry *out, chip_tick_result *res, bool tick, hipStream_t *merge_stream,
+                       hipEvent_t *merged_ev)
 {
     const int b = (int)(c->n_enqueued++ % Ctx::kRing);
     // Ticks (queries already resident) over a short prefix alternate between two scan streams so that the ramp-down of
@@ -288,6 +300,15 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
     // uploads its queries on s_scan first stays on s_scan.
     const bool short_scan = (double)local_count(c, k) * c->D * c->elem <= c->scan_overlap_bytes;
     hipStream_t s_scan = (tick && short_scan && !c->prof_on && c->s_scan2 && (c->n_enqueued & 1)) ? c->s_scan2 : c->s_scan;
+    // (same-stream short ticks rotate over all tick streams: see below)
+    const bool same_stream = tick && short_scan && !c->prof_on && c->nranks == 1 && !c->xchg && !c->parent && c->own_query_stream &&
+                             c->s_scan2 && merge_stream && c->tick_same_stream;
+    if (same_stream) {
+        hipStream_t ring[4] = {c->s_scan, c->s_scan2, c->s_scan_x[0], c->s_scan_x[1]};
+        int ns = 2;
+        while (ns < 4 && ring[ns]) ns++;
+        s_scan = ring[c->n_same_stream++ % (uint64_t)ns];
+    }
     ScanArgs a;
     a.seg_table = c->seg_table_dev;
     a.seg_shift = c->seg_shift;
@@ -330,8 +351,6 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
     // records on one stream (no cross-stream event pair), and because consecutive ticks alternate between the two scan streams,
     // merge(i) still overlaps scan(i+1).  At 10k rows the tick is host-enqueue-bound otherwise (round 2: 21-34 us of API calls per
     // tick against a ~20 us kernel).  Anything with an exchange, an external ctx stream or profiling keeps the ctx-stream merge.
-    const bool same_stream = tick && short_scan && !c->prof_on && c->nranks == 1 && !c->xchg && !c->parent && c->own_query_stream &&
-                             c->s_scan2 && merge_stream && c->tick_same_stream;
     hipStream_t s_merge = same_stream ? s_scan : c->s_query;
     if (merge_stream) *merge_stream = s_merge;
     if (!same_stream) {
@@ -352,6 +371,7 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
     rc = launch_merge(c, s_merge, m, nq);
     if (rc != CHIP_OK) return rc;
     CHIP_HIP(c, hipEventRecord(c->ev_merged[b], s_merge));
+    if (merged_ev) *merged_ev = same_stream ? c->ev_merged[b] : nullptr;   // same-stream tick: this IS the tick's completion event
     return CHIP_OK;
 }
 
@@ -469,9 +489,13 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
         rc = query_row_ptrs(c, rows, 3, l, q);
         if (rc != CHIP_OK) return rc;
         hipStream_t s_done = c->s_query;
-        rc = enqueue_scan_merge(c, k, q, 3, CHIP_DEFAULT_TOPK, l, p, nullptr, s.dev, true, &s_done);
+        hipEvent_t merged = nullptr;
+        rc = enqueue_scan_merge(c, k, q, 3, CHIP_DEFAULT_TOPK, l, p, nullptr, s.dev, true, &s_done, &merged);
         if (rc != CHIP_OK) return rc;
-        CHIP_HIP(c, hipEventRecord(s.done, s_done));
+        // a same-stream tick is complete when its merge is: one event record per tick (the list buffer's merge event; the buffer is
+        // not reused before kRing = 64 further enqueues, and at most CHIP_MAX_INFLIGHT - 1 = 63 ticks are uncollected)
+        if (merged) s.wait_ev = merged;
+        else { CHIP_HIP(c, hipEventRecord(s.done, s_done)); s.wait_ev = s.done; }
         s.immediate = false;
         s.in_flight = true;
     }
@@ -482,7 +506,7 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
 int tick_collect_slot(Ctx *c, Slot &s, chip_tick_result *out)
 {
     if (!s.in_flight) return CHIP_ERR_BUSY;
-    if (!s.immediate) CHIP_HIP(c, hipEventSynchronize(s.done));
+    if (!s.immediate) CHIP_HIP(c, hipEventSynchronize(s.wait_ev ? s.wait_ev : s.done));
     *out = *s.host;
     s.in_flight = false;
     if (out->status == CHIP_TICK_FAILED) {   // a shard could not take part: the tick had no effect (:1098 was not reached)
@@ -617,14 +641,16 @@ int ctx_append(Ctx *c, const void *desc, int src_elem, int64_t n, uint32_t flags
         if (rc != CHIP_OK) return rc;
         if (bad & 2u) return CHIP_ERR_NONFINITE;
         if (!(bad & 1u)) break;
-        // not float32-representable: an empty undecided DB takes the data as it is (double rows) -- also when the caller allows
-        // rounding: the flag permits rounding where it is unavoidable (a float DB that already holds rows), it does not ask for it
+        // CHIP_APPEND_ALLOW_ROUNDING is the caller saying "these ARE float32 descriptors, up to the precision they were printed / sent
+        // with" (a state.json checkpoint holds 15-digit decimal text, RawFileIO.cpp:330-459): they are rounded to the float rows they
+        // came from, also in an empty undecided DB.  Without the flag the data decides: an empty undecided DB takes values that are
+        // not float32-representable as they are (double rows); anywhere else they are refused.
+        if (flags & CHIP_APPEND_ALLOW_ROUNDING) break;
         if (attempt == 0 && append_can_switch_to_double(c, first)) {
             rc = append_switch_to_double(c, n);
             if (rc != CHIP_OK) return rc;
             continue;
         }
-        if (flags & CHIP_APPEND_ALLOW_ROUNDING) break;
         return CHIP_ERR_NOT_F32;
     }
     return append_ring_publish(c, desc, src_elem, first, n, (bad & 1u) != 0);
@@ -730,6 +756,7 @@ int merge_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, const void *
     int rc = launch_merge(c, c->s_query, m, 3);
     if (rc != CHIP_OK) return rc;
     CHIP_HIP(c, hipEventRecord(s.done, c->s_query));
+    s.wait_ev = s.done;
     s.immediate = false;
     s.in_flight = true;
     return CHIP_OK;
@@ -838,6 +865,8 @@ int chip_synchronize(chip_ctx *c)
     CHIP_HIP(c, hipStreamSynchronize(c->s_append));
     CHIP_HIP(c, hipStreamSynchronize(c->s_scan));
     if (c->s_scan2) CHIP_HIP(c, hipStreamSynchronize(c->s_scan2));
+    for (hipStream_t x : c->s_scan_x)
+        if (x) CHIP_HIP(c, hipStreamSynchronize(x));
     CHIP_HIP(c, hipStreamSynchronize(c->s_query));
     CHIP_HIP(c, hipStreamSynchronize(c->s_pnp));
     return CHIP_OK;
@@ -906,7 +935,7 @@ static int query_common(chip_ctx *c, int64_t k, const int64_t *query_rows, const
     }
     rc = query_rows ? query_row_ptrs(c, query_rows, nq, n, q) : upload_query_vectors(c, vectors, vec_elem, nq, q);
     if (rc != CHIP_OK) return rc;
-    rc = enqueue_scan_merge(c, k, q, nq, topk, 0, nullptr, c->topk_dev, nullptr, false, nullptr);
+    rc = enqueue_scan_merge(c, k, q, nq, topk, 0, nullptr, c->topk_dev, nullptr, false, nullptr, nullptr);
     if (rc != CHIP_OK) return rc;
     return sync_topk_out(c, nq, topk, scores, idx);
 }
@@ -1025,7 +1054,7 @@ int chip_scan_local(chip_ctx *c, int64_t l, const chip_dot_params *p, int32_t to
     // scan on s_scan, then (behind an event) the local merge on the ctx stream writes this rank's 3 x topk list to
     // dev_out: everything the caller enqueues next on the ctx stream (the all-gather) is ordered after it, while the
     // next tick's scan is free to start as soon as this scan ends.
-    rc = enqueue_scan_merge(c, k, q, 3, topk, l, nullptr, (chip_topk_entry *)dev_out, nullptr, true, nullptr);
+    rc = enqueue_scan_merge(c, k, q, 3, topk, l, nullptr, (chip_topk_entry *)dev_out, nullptr, true, nullptr, nullptr);
     if (rc == CHIP_OK) c->last_l = l;  // :1098
     return rc;
 }

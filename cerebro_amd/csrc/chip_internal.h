@@ -58,6 +58,7 @@ int launch_synth(Ctx *c, hipStream_t s, int64_t first_global, int64_t n, uint64_
 
 struct Slot {
     hipEvent_t done = nullptr;
+    hipEvent_t wait_ev = nullptr;       // what collect waits for: `done`, or the merge event of the tick's list buffer (same-stream ticks)
     chip_tick_result *host = nullptr;   // pinned
     chip_tick_result *dev = nullptr;
     bool in_flight = false;
@@ -119,6 +120,8 @@ struct Ctx {
     static constexpr int kRing = 64;
     hipStream_t s_scan = nullptr;
     hipStream_t s_scan2 = nullptr;   // second scan stream for short scans (CHIP_SCAN_STREAMS=1 disables)
+    hipStream_t s_scan_x[2] = {};    // third / fourth stream of the same-stream short tick (CHIP_SCAN_STREAMS, default 4)
+    uint64_t n_same_stream = 0;      // same-stream ticks so far (round robin over the tick streams)
     chip_topk_entry *partial_dev[kRing] = {};   // [max_grid][CHIP_MAX_NQ][CHIP_MAX_TOPK]
     int32_t partial_lists[kRing] = {};                               // grid of the scan that filled it
     hipEvent_t ev_scan[kRing] = {};             // scan into buffer b finished
@@ -218,7 +221,7 @@ int ctx_read_row(Ctx *c, int64_t g, int64_t total, void *out);          // one r
 int query_row_ptrs(Ctx *c, const int64_t *rows, int nq, int64_t n_global, const void **q);
 int upload_query_vectors(Ctx *c, const void *queries, int src_elem, int nq, const void **q);   // -> qvec_dev (on s_scan)
 int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, int64_t l, const chip_dot_params *p,
-                       chip_topk_entry *out, chip_tick_result *res, bool tick, hipStream_t *merge_stream);
+                       chip_topk_entry *out, chip_tick_result *res, bool tick, hipStream_t *merge_stream, hipEvent_t *merged_ev = nullptr);
 int merge_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, const void *dev_gathered, int32_t n_lists, int32_t topk, Slot &s);
 int merge_enqueue_out(Ctx *c, const void *dev_gathered, int32_t n_lists, int nq, int32_t topk, chip_topk_entry *out);
 int tick_prepare(int64_t rows_global, int64_t last_l, int64_t l, const chip_dot_params *p, int32_t *status, int64_t *k_out);

@@ -334,12 +334,12 @@ int group_append(Ctx *gc, const void *desc, int src_elem, int64_t n, uint32_t fl
         for (uint32_t b : bad) any_bad |= b;
         if (any_bad & 2u) return CHIP_ERR_NONFINITE;
         if (!(any_bad & 1u)) break;
+        if (flags & CHIP_APPEND_ALLOW_ROUNDING) break;   // the caller vouches for float32 descriptors (see ctx_append)
         if (attempt == 0 && append_can_switch_to_double(G->subs[0], first)) {
             rc = run_all(G, [&](int g) { return on_dev(g, [&](Ctx *c) { return append_switch_to_double(c, n); }); });
             if (rc != CHIP_OK) return group_break(G, rc);   // some devices may hold double rows now, others float rows
             continue;
         }
-        if (flags & CHIP_APPEND_ALLOW_ROUNDING) break;
         return CHIP_ERR_NOT_F32;
     }
     const bool lossy = (any_bad & 1u) != 0;

@@ -52,7 +52,18 @@ int64_t Cerebro::loadStateFromDisk(const std::string &path)
     if (sd.stampNSec.empty()) return 0;
     if (sd.D != D_) { error_ = "descriptor size in state.json differs from descriptor_size"; status_ = CHIP_ERR_INVALID_ARG; return -1; }
     int64_t first = -1;
-    status_ = chip_db_append_f64(ctx_, sd.desc.data(), (int64_t)sd.stampNSec.size(), CHIP_APPEND_ALLOW_ROUNDING, &first);
+    // A checkpoint holds Eigen's FullPrecision text: 15 significant digits (RawFileIO.cpp:330-459).  Float32 descriptors (every
+    // Keras model of the reference's server) come back as doubles that are NOT float32-representable but lie within the print
+    // precision of one: rounding them restores the original float rows exactly, so the loaded DB selects the same candidates as
+    // the live run that saved it.  Genuinely float64 descriptors (ReljaNetVLAD, whole_image_desc_compute_server.py:148-149) are
+    // not near any float32: they are appended as they are and an empty DB becomes a double-row DB -- the same storage the live
+    // appends of those descriptors choose (chip_create "decided by the data").  The file decides, value by value.
+    bool float32_text = true;
+    for (double d : sd.desc) {
+        const double r = (double)(float)d;
+        if (!(std::fabs(d - r) <= 1e-14 * std::fabs(d))) { float32_text = false; break; }   // 15 digits: <= 5e-15 relative; NaN fails too
+    }
+    status_ = chip_db_append_f64(ctx_, sd.desc.data(), (int64_t)sd.stampNSec.size(), float32_text ? CHIP_APPEND_ALLOW_ROUNDING : 0u, &first);
     if (status_ != CHIP_OK) { error_ = chip_strerror(status_); return -1; }
     std::lock_guard<std::mutex> lk(m_wholeImageComputedList);
     for (uint64_t ns : sd.stampNSec) {

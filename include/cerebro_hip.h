@@ -131,7 +131,10 @@ int  chip_synchronize(chip_ctx *ctx);
  * The f64->f32 narrowing is done on the device and VERIFIED lossless ((double)(float)x == x); the default
  * NetVLAD server emits float32 values (whole_image_desc_compute_server.py:631,648) so this holds.
  * On CHIP_ERR_NOT_F32 / CHIP_ERR_NONFINITE nothing is appended.                                         */
-#define CHIP_APPEND_ALLOW_ROUNDING 1u   /* round-to-nearest instead of failing; sets info.lossy_rows      */
+#define CHIP_APPEND_ALLOW_ROUNDING 1u   /* the caller vouches that the values ARE float32 descriptors up to the precision they were
+                                           printed / transmitted with (a state.json checkpoint: 15-digit text): round to nearest
+                                           instead of failing -- also in an empty undecided DB, which then stays a float DB; sets
+                                           info.lossy_rows.  Without the flag the data decides (chip_create above).             */
 int chip_db_append_f64(chip_ctx *ctx, const double *desc, int64_t n, uint32_t flags, int64_t *first_index);
 int chip_db_append_f32(chip_ctx *ctx, const float *desc, int64_t n, int64_t *first_index);
 int64_t chip_db_size(const chip_ctx *ctx);           /* global number of appended rows (== l)             */
