@@ -554,6 +554,8 @@ int group_tick_enqueue(Ctx *gc, int64_t l, const chip_dot_params *p, int32_t slo
         s.in_flight = true;
         return CHIP_OK;
     }
+    // the documented limit of sharded ticks, the same on every device: the three query rows must still be in the replicated ring
+    if (G->subs.size() > 1 && n - l > CHIP_RING_ROWS - 3) return CHIP_ERR_RANGE;
     const int64_t rows[3] = {l - 1, l - 2, l - 3};  // v, vm, vmm (Cerebro.cpp:987-989)
     GroupScan j;
     j.k = k; j.l = l; j.nq = 3; j.K = CHIP_DEFAULT_TOPK; j.rows = rows; j.n_global = l; j.p = p; j.slot = &s; j.tick = true;

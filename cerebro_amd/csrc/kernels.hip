@@ -713,6 +713,9 @@ int scan_rows_form(const Ctx *c, int64_t n_rows, int nq, int grid, bool q64)
     if (c->scan_rows > 0) return c->scan_rows > rmax ? rmax : c->scan_rows;
     if (rpw < 1) return 1;
     if (rpw > c->scan_rows_auto_max) return 0;
+    // cache-sized prefix at half occupancy, four tick streams (BASELINE config 2): R = 1 / 2 / 3 measured 25.1 / 26.5 / 27.7 us per
+    // 10k-row tick (profiles/r03_short_scan_ab_2.txt) -- less in flight per wave lets the LDS-DMA of the queries land sooner
+    if ((double)n_rows * c->D * c->elem <= c->scan_plain_bytes) return 1;
     return rpw >= rmax ? rmax : (int)rpw;
 }
 
