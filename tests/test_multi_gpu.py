@@ -338,6 +338,7 @@ def test_group_bulk_append_owner_only(G):
         orc = oracle_lib.LoopOracle(db)
         for l in sched:
             same_tick(chip.loop_tick(l), orc.tick(l))
+        chip.loop_reset()
         with pytest.raises(capi.ChipError) as e:
             chip.loop_tick(N - 4200)                      # its query rows have left the ring: the documented limit, deterministic
         assert e.value.status == capi.CHIP_ERR_RANGE
