@@ -88,6 +88,36 @@ def cpu_baseline(sample_cols: int, budget_s: float):
     return cols_per_s, n, dt
 
 
+def eigen_baseline(sample_cols: int, budget_s: float):
+    """if THIS machine has Eigen (it is absent from the build image), time the literal Eigen statements of
+    Cerebro.cpp:1026-1043 (oracle/eigen_probe.cc, built here with the reference's flags: g++ -O3 -DNDEBUG, no -march).
+    Returns (cols_per_s, n, seconds, eigen_version) or None."""
+    import glob
+    import shutil
+    import subprocess
+    cands = [os.environ.get("EIGEN3_INCLUDE_DIR", "")] + ["/usr/include/eigen3", "/usr/local/include/eigen3", "/opt/eigen3", "/usr/include", "/usr/local/include"]
+    cands += glob.glob("/opt/*/include/eigen3") + glob.glob("/usr/lib/cmake/eigen3/../../../include/eigen3")
+    inc = next((c for c in cands if c and os.path.exists(os.path.join(c, "Eigen", "Dense"))), None)
+    gxx = shutil.which("g++")
+    if inc is None or gxx is None:
+        return None
+    out = ROOT / "oracle" / "_build" / "eigen_probe"
+    out.parent.mkdir(parents=True, exist_ok=True)
+    try:
+        r = subprocess.run([gxx, "-O3", "-DNDEBUG", "-std=c++11", "-I", inc, str(ROOT / "oracle" / "eigen_probe.cc"), "-o", str(out)],
+                           capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            sys.stderr.write("[bench] Eigen found at " + inc + " but the probe did not build:\n" + r.stderr[-800:] + "\n")
+            return None
+        r = subprocess.run([str(out), str(D), str(sample_cols), str(budget_s)], capture_output=True, text=True, timeout=budget_s * 4 + 120)
+        f = r.stdout.split()
+        n, dt = int(f[f.index("ticks") + 1]), float(f[f.index("seconds") + 1])
+        return n * sample_cols / dt, n, dt, f[1]
+    except Exception as e:  # noqa: BLE001 -- a baseline must never take the benchmark down
+        sys.stderr.write(f"[bench] Eigen probe failed: {e!r}\n")
+        return None
+
+
 def fmt_rows(n: int) -> str:
     return f"{n // 10**6}M" if n % 10**6 == 0 else f"{n // 1000}k" if n % 1000 == 0 else str(n)
 
@@ -633,11 +663,19 @@ def main():
         if n_gpus == 1 and world == 1 and not args.no_batch and args.storage == "f32":
             out["batch"] = batch_leg(chip, args.rows)
         if n_gpus == 1 and world == 1 and args.cpu_budget > 0:
+            eig = eigen_baseline(args.cpu_sample, min(args.cpu_budget, 10.0))
             cols_per_s, n, dt = cpu_baseline(args.cpu_sample, args.cpu_budget)
+            if eig is not None:   # the reference's own Eigen statements, on this host: the headline CPU figure when available
+                out["cpu_baseline_eigen"] = {"value": eig[0] / args.rows, "unit": "loop-queries/s", "cores": 1, "kind": "eigen",
+                                             "sample": f"{eig[1]} ticks of the literal Eigen {eig[3]} statements (Cerebro.cpp:1026-1043) over a "
+                                                       f"{args.cpu_sample}-column x {D} MatrixXd ({eig[2]:.1f} s), g++ -O3 -DNDEBUG without -march "
+                                                       f"(the reference's Release flags), scaled to {args.rows} columns"}
+            out["eigen_probe"] = "Eigen found: cpu_baseline_eigen is the reference's own statements" if eig is not None else \
+                "no <Eigen/Dense> on this host (searched EIGEN3_INCLUDE_DIR, /usr/include/eigen3, /usr/local/include/eigen3, /opt/*): cpu_baseline is the port"
             out["cpu_baseline"] = {"value": cols_per_s / args.rows, "unit": "loop-queries/s", "cores": 1, "kind": "port",
                                    "sample": f"{n} ticks of 3 fp64 GEMVs over a {args.cpu_sample}-column x 4096 column-major M "
                                              f"({dt:.1f} s), scaled to {args.rows} columns; sequential-order port (one s += q[e]*col[e] "
-                                             "chain per column, -O2 -ffp-contract=off: does not vectorise) -- Eigen is absent from this image, "
+                                             "chain per column, -O2 -ffp-contract=off: does not vectorise; Eigen itself is probed at run time: see eigen_probe), "
                                              f"its GEMV would use packet accumulators; host has {os.cpu_count()} logical CPUs ({usable_cpus()} usable under the cgroup quota), "
                                              "reference path is single-threaded (Eigen without OpenMP)"}
             ac_cols = max(args.cpu_sample, 200_000)      # 6.5 GB of fp64: large enough to defeat the host caches

@@ -109,6 +109,15 @@ void orc_ref_scan_f64_colmajor_omp(const double *M, int32_t D, int64_t k,
                                    double maxv[3], int64_t argmax[3], int32_t nthreads);
 void orc_tile_columns_omp(double *M, int32_t D, int64_t k, const double *src, int64_t src_cols, int32_t nthreads);
 
+/* Eigen-order emulation of  v.transpose() * M.leftCols(k)  (Cerebro.cpp:1026-1028): Eigen 3.3.x row-major GEMV, one packet
+ * accumulator per output + predux + scalar tail; packet 2 / fma 0 = the reference's x86-64 SSE2 Release build, packet 4 / fma 1 =
+ * an AVX2+FMA build, packet 1 = the sequential chain of orc_dot_seq_f64.  Parity evidence (tests/test_oracle_eigen_order.py):
+ * the selection of this path vs the oracle's fixed-tree order. */
+double orc_dot_eigen_gemv_f64(const double *v, const double *col, int32_t D, int32_t packet, int32_t fma_flag, int32_t aligned_start);
+void orc_ref_scan_f64_eigen_order(const double *M, int32_t D, int64_t k, const double *v, const double *vm, const double *vmm,
+                                  double *u, double *um, double *umm, double maxv[3], int64_t argmax[3],
+                                  int32_t packet, int32_t fma_flag, int32_t nthreads);
+
 
 /* ================================================================== PnP / RANSAC (pnp_ransac.c) */
 typedef struct {

@@ -381,3 +381,66 @@ void orc_tile_columns_omp(double *M, int32_t D, int64_t k, const double *src, in
         for (int32_t j = 0; j < D; j++) d[j] = s[j];
     }
 }
+
+/* ---------------------------------------------------------------- Eigen-order GEMV emulation (parity evidence, not a baseline)
+ * What  u = v.transpose() * M.leftCols(k)  (/root/reference/src/Cerebro.cpp:1026-1028) computes in the reference's build, term
+ * order included.  Eigen is not vendored and not installed here, so this restates its published algorithm; the version followed
+ * is Eigen 3.3.x (ROS Kinetic / Ubuntu 16.04 ship 3.2.92 = 3.3-beta1, the reference's docker image 3.3.4), file
+ * Eigen/src/Core/products/GeneralMatrixVector.h, struct general_matrix_vector_product<Index, LhsScalar, LhsMapper, RowMajor, ...>:
+ *   - a row-vector times a column-major matrix is evaluated as the transposed product M^T v: a ROW-major GEMV whose "rows" are the
+ *     columns of M (each D contiguous doubles) -- GeneralProduct.h / ProductEvaluators.h gemv_dense_selector<OnTheLeft, ...>;
+ *   - rows are taken four at a time (rowsAtOnce = 4; the tail rows one at a time): that blocking shares the loads of v, it does not
+ *     change any row's arithmetic;
+ *   - per row: scalar accumulator tmp = 0 over the first `alignedStart` elements (0 here: VectorXd storage is 16-byte aligned),
+ *     then ONE packet accumulator ptmp = pset1(0) over j = alignedStart .. alignedSize in steps of the packet size with
+ *     ptmp = pmadd(lhs(j), rhs(j), ptmp), then tmp += predux(ptmp), then the scalar tail j = alignedSize .. depth with
+ *     tmp += lhs(j) * rhs(j); finally res[i] += alpha * tmp with alpha = 1 and res zero-initialised (dst.setZero() first);
+ *   - the reference is built with CMAKE_BUILD_TYPE Release and CMAKE_CXX_FLAGS " -Wl,-no-as-needed" (CMakeLists.txt:42-44: no
+ *     -march) on x86-64: SSE2 packets of 2 doubles (Packet2d), pmadd = padd(pmul(a, b), c) (no FMA), and
+ *     predux(Packet2d a) = a[0] + a[1] (arch/SSE/PacketMath.h).  packet = 4 / fma = 1 restate an AVX2+FMA build
+ *     (Packet4d, predux = (a0 + a1) + (a2 + a3), arch/AVX/PacketMath.h) for comparison.
+ * So with packet P the value is  ((s_0 + s_1) [+ (s_2 + s_3)]) + tail,  s_c = sum over j = c, c + P, ... taken in ascending order with
+ * one rounding per addition.  Built with -ffp-contract=off, so `a * b + c` below is two roundings unless fma is asked for. */
+double orc_dot_eigen_gemv_f64(const double *v, const double *col, int32_t D, int32_t packet, int32_t fma_flag, int32_t aligned_start)
+{
+    double tmp = 0.0;
+    int32_t j = 0;
+    if (aligned_start > D) aligned_start = D;
+    for (; j < aligned_start; j++) tmp += col[j] * v[j];
+    const int32_t P = packet == 4 ? 4 : (packet == 2 ? 2 : 1);
+    if (P > 1) {
+        const int32_t aligned_size = aligned_start + ((D - aligned_start) & ~(P - 1));
+        if (aligned_size > aligned_start) {
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            for (; j < aligned_size; j += P)
+                for (int32_t c = 0; c < P; c++) acc[c] = fma_flag ? fma(col[j + c], v[j + c], acc[c]) : col[j + c] * v[j + c] + acc[c];
+            tmp += P == 2 ? acc[0] + acc[1] : (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        }
+    }
+    for (; j < D; j++) tmp += col[j] * v[j];
+    return 0.0 + 1.0 * tmp;   /* res[i] += alpha * tmp */
+}
+
+/* Cerebro.cpp:1026-1043 with the three products in Eigen's order: fp64 column-major M, maxCoeff, last index attaining it. */
+void orc_ref_scan_f64_eigen_order(const double *M, int32_t D, int64_t k, const double *v, const double *vm, const double *vmm,
+                                  double *u, double *um, double *umm, double maxv[3], int64_t argmax[3],
+                                  int32_t packet, int32_t fma_flag, int32_t nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t i = 0; i < k; i++) {
+        u[i] = orc_dot_eigen_gemv_f64(v, M + (size_t)i * D, D, packet, fma_flag, 0);
+        um[i] = orc_dot_eigen_gemv_f64(vm, M + (size_t)i * D, D, packet, fma_flag, 0);
+        umm[i] = orc_dot_eigen_gemv_f64(vmm, M + (size_t)i * D, D, packet, fma_flag, 0);
+    }
+    double a = u[0], b = um[0], c = umm[0];
+    for (int64_t i = 1; i < k; i++) { if (u[i] > a) a = u[i]; if (um[i] > b) b = um[i]; if (umm[i] > c) c = umm[i]; }   /* maxCoeff */
+    int64_t ia = -1, ib = -1, ic = -1;
+    for (int64_t ii = 0; ii < k; ii++) {   /* :1038-1043 */
+        if (u[ii] == a) ia = ii;
+        if (um[ii] == b) ib = ii;
+        if (umm[ii] == c) ic = ii;
+    }
+    maxv[0] = a; maxv[1] = b; maxv[2] = c;
+    argmax[0] = ia; argmax[1] = ib; argmax[2] = ic;
+}

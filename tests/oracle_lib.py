@@ -221,6 +221,27 @@ def ref_scan_f64_colmajor_omp(M: np.ndarray, k: int, v, vm, vmm, nthreads: int, 
     return maxv, arg, (u, um, umm)
 
 
+def ref_scan_f64_eigen_order(M: np.ndarray, k: int, v, vm, vmm, packet: int = 2, fma: bool = False, nthreads: int = 1):
+    """Cerebro.cpp:1026-1043 with Eigen 3.3's row-major GEMV summation order (packet 2, no FMA = the reference's SSE2 build)."""
+    lib = load()
+    lib.orc_ref_scan_f64_eigen_order.restype = None
+    D = M.shape[1]
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    v, vm, vmm = (np.ascontiguousarray(x, dtype=np.float64) for x in (v, vm, vmm))
+    u = np.empty(k); um = np.empty(k); umm = np.empty(k)
+    maxv = np.empty(3); arg = np.empty(3, dtype=np.int64)
+    lib.orc_ref_scan_f64_eigen_order(_p(M), C.c_int32(D), C.c_int64(k), _p(v), _p(vm), _p(vmm), _p(u), _p(um), _p(umm), _p(maxv), _p(arg),
+                                     C.c_int32(packet), C.c_int32(1 if fma else 0), C.c_int32(nthreads))
+    return maxv, arg, (u, um, umm)
+
+
+def dot_eigen_gemv(v, col, packet: int = 2, fma: bool = False, aligned_start: int = 0) -> float:
+    lib = load()
+    lib.orc_dot_eigen_gemv_f64.restype = C.c_double
+    v = np.ascontiguousarray(v, dtype=np.float64); col = np.ascontiguousarray(col, dtype=np.float64)
+    return float(lib.orc_dot_eigen_gemv_f64(_p(v), _p(col), C.c_int32(v.size), C.c_int32(packet), C.c_int32(1 if fma else 0), C.c_int32(aligned_start)))
+
+
 def tile_columns_omp(k: int, src: np.ndarray, nthreads: int) -> np.ndarray:
     """(k, D) float64 array made of repeated copies of `src`, first-touched by the threads that will scan it."""
     M = np.empty((k, src.shape[1]), dtype=np.float64)

@@ -67,3 +67,10 @@ def test_size_legs_do_not_disturb_each_other():
             r = orc.tick(l)
             assert r["status"] == 2
             assert (r["found"] == 0) if e is None else (r["found"] == 1 and (r["idx_curr"], r["idx_prev"]) == e), (rows, l, e, r)
+
+
+def test_eigen_probe_reports_absence_or_a_number():
+    """bench.py probes for a real Eigen at run time; without one it says so instead of assuming."""
+    import bench
+    r = bench.eigen_baseline(64, 0.05)
+    assert r is None or (r[0] > 0 and r[1] >= 1)
