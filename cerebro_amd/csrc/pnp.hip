@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace chip {
@@ -606,6 +607,25 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
 // ------------------------------------------------------------------------------------------------ K5b + K6
 constexpr int EN = 27;
 
+// IEEE-754 double sqrt for an argument in the normal range that needs no pre-scaling (2^-767 <= t < inf, not NaN): the SAME
+// instruction sequence hipcc emits for sqrt(double) -- v_rsq_f64 seed, one coupled Goldschmidt step, two residual corrections --
+// minus its scaling of tiny arguments (v_cmp / v_ldexp in, v_ldexp out) and its zero / inf / NaN pass-through (v_cmp_class, two
+// v_cndmask): three dependent instructions fewer on the critical chain of every double-shift QR step.  Bit-identical to sqrt()
+// on that range (tests/test_pnp_gpu.py compares poses bit for bit with the CPU oracle, which calls libm's correctly rounded sqrt).
+__device__ __forceinline__ double sqrt_normal_range(double t)
+{
+    const double y = __builtin_amdgcn_rsq(t);
+    double g = t * y;
+    double h = y * 0.5;
+    const double r0 = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r0, g);
+    h = __builtin_fma(h, r0, h);
+    const double d0 = __builtin_fma(-g, g, t);
+    g = __builtin_fma(d0, h, g);
+    const double d1 = __builtin_fma(-g, g, t);
+    return __builtin_fma(d1, h, g);
+}
+
 
 struct EigArgs {
     PnpProblem prob[kPnpMaxBatch];
@@ -624,6 +644,7 @@ struct EigArgs {
     int32_t *nsol;          // [H]  number of cheirality-valid real solutions (diagnostics)
     unsigned long long *mask;  // [H][mask_words]
     int32_t debug_stop;     // tuning only (CHIP_PNP_DEBUG_STOP)
+    unsigned long long *stamps;   // tuning only (CHIP_PNP_STAMPS): [H][8] shader-clock totals per wave, see pnp_eig_score<true>
 };
 
 #define HH(i, j) Hs[(i) * EN + (j)]
@@ -642,8 +663,24 @@ struct EigArgs {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        \
     } while (0)
 
+// STAMP = true (CHIP_PNP_STAMPS=1, tuning only): the wave accumulates s_memtime differences per segment of the QR iteration and
+// leaves them in a.stamps[hyp][0..7]: 0 sweep overhead (deflation test, shifts, m search), 1 reflector (|p|+|q|+|r| .. quotients
+// read back), 2 row modification, 3 column modification + forwarding, 4 number of double-shift steps, 5 number of sweeps,
+// 6 Hessenberg reduction + accumulation, 7 whole kernel.  The stamps themselves cost ~10 % (s_memtime + lgkmcnt wait each).
+template <bool STAMP>
 __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
 {
+    unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = 0, t_start = 0;
+    if constexpr (STAMP) { t_start = t_prev = __builtin_readcyclecounter(); }
+#define PNP_STAMP(i)                                                        \
+    do {                                                                    \
+        if constexpr (STAMP) {                                              \
+            const unsigned long long t_ = __builtin_readcyclecounter();     \
+            clk[i] += t_ - t_prev;                                          \
+            t_prev = t_;                                                    \
+        }                                                                   \
+    } while (0)
     __shared__ double Hs[EN * EN], Vs[EN * EN];
     __shared__ double ortm[EN], wr[EN], wi[EN], Tf[27], sxs[kSampleMax * 3], model[16];
     const int lane = threadIdx.x;
@@ -762,6 +799,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     WAVE_SYNC();
 
     if (a.debug_stop == 2) return;
+    PNP_STAMP(6);
     // ================= Francis double-shift QR with accumulation (hqr2) =================
     double norm = 0.0;
     for (int i = 0; i < nn; i++)
@@ -903,71 +941,109 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             // instruction stream serves them with a per-lane base pointer instead of two divergent blocks executed back
             // to back.  The first column of (3) is also what the next step's reflector is built from: it is forwarded
             // through v_readlane instead of an LDS write -> barrier -> read.
+            PNP_STAMP(0);
+            if constexpr (STAMP) clk[5] += 1;
             double *const Abase = (lane < 32) ? Hs : Vs;     // lanes 0..26 work on H, lanes 32..58 on V
             const int arow = (lane < 32) ? lane : lane - 32;
             bool fwd = false;
             double fp = 0.0, fq = 0.0, fr = 0.0;
-            for (int k = m; k <= n - 1; k++) {
-                const bool notlast = (k != n - 1);
+            // One double-shift step.  NOTLAST (k != n-1: the reflector spans three rows) is a compile-time flag: with a run-time one
+            // the third LDS read of each modification sat behind a branch, i.e. behind the first two reads' latency (shader-clock
+            // split, profiles/r03_pnp_pmc.md: row / column modification ~480 / ~520 of ~1500 stamped cycles per step, the arithmetic in
+            // them ~50).  The row modification's inputs H(k..k+2, lane) are final once step k-1 has written (the LDS executes a
+            // wave's accesses in order), so they are read at the TOP of the step and land underneath the reflector's sqrt -> division
+            // chain.  Same operations on the same values: bits unchanged.
+            auto qr_step = [&](int k, auto notlast_tag) {
+                constexpr bool NOTLAST = decltype(notlast_tag)::value;
+                if (k != m) {   // (the rare LDS reads of p, q, r come BEFORE the prefetch: LDS returns in order, so the wait for them
+                                //  then leaves the younger prefetch in flight; the other way round it drained the prefetch as well)
+                    if (fwd) { p = fp; q = fq; r = fr; }
+                    else { p = HH(k, k - 1); q = HH(k + 1, k - 1); r = NOTLAST ? HH(k + 2, k - 1) : 0.0; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bool rowact = lane >= k && lane < nn;
+                const int jr = rowact ? lane : k;                       // idle lanes read a valid element
+                const double h0 = HH(k, jr), h1 = HH(k + 1, jr);
+                double h2 = 0.0;
+                if constexpr (NOTLAST) h2 = HH(k + 2, jr);
+                __builtin_amdgcn_sched_barrier(0);
                 int ex = 0;
                 if (k != m) {
-                    if (fwd) { p = fp; q = fq; r = fr; }
-                    else { p = HH(k, k - 1); q = HH(k + 1, k - 1); r = notlast ? HH(k + 2, k - 1) : 0.0; }
                     fwd = false;
                     x = fabs(p) + fabs(q) + fabs(r);
-                    if (x == 0.0) continue;
+                    if (x == 0.0) return;
                     // overflow protection by an exact power-of-two scale 2^-ex, |p|+|q|+|r| = f * 2^ex (three v_ldexp instead of
                     // the division chain EISPACK has here; the oracle defines it the same way)
                     (void)frexp(x, &ex);
                     p = ldexp(p, -ex); q = ldexp(q, -ex); r = ldexp(r, -ex);
                 }
                 fwd = false;
-                s = sqrt(p * p + q * q + r * r);
+                // p, q, r are scaled so that |p| + |q| + |r| is in [0.5, 1) on both ways in (frexp above / in the m search), hence
+                // p^2 + q^2 + r^2 is in [1/12, 1): sqrt_normal_range is IEEE sqrt there, without the range handling on the chain
+                s = sqrt_normal_range(p * p + q * q + r * r);
                 if (p < 0) s = -s;
-                if (s != 0.0) {
-                    const double hkk1 = (k != m) ? ldexp(-s, ex) : ((l != m) ? -HH(k, k - 1) : 0.0);
-                    const bool wr_sub = (k != m) || (l != m);
-                    p = p + s;
-                    {   // x = p/s, y = q/s, z = r/s, q = q/p, r = r/p as one vector division over lanes 0..4
-                        const double num = (lane == 0) ? p : ((lane & 1) ? q : r);
-                        const double den = (lane < 3) ? s : p;
-                        const double quo = num / den;
-                        x = lane_value_f64(quo, 0); y = lane_value_f64(quo, 1); z = lane_value_f64(quo, 2);
-                        q = lane_value_f64(quo, 3); r = lane_value_f64(quo, 4);
-                    }
-                    WAVE_SYNC();
-                    if (wr_sub && lane == 63) HH(k, k - 1) = hkk1;
-                    if (lane >= k && lane < nn) {  // row modification, column j = lane
-                        const int j = lane;
-                        double pp = HH(k, j) + q * HH(k + 1, j);
-                        if (notlast) { pp = pp + r * HH(k + 2, j); HH(k + 2, j) = HH(k + 2, j) - pp * z; }
-                        HH(k, j) = HH(k, j) - pp * x;
-                        HH(k + 1, j) = HH(k + 1, j) - pp * y;
-                    }
-                    WAVE_SYNC();
-                    const int imax = (n < k + 3) ? n : k + 3;
-                    double c0 = 0.0;
-                    if ((lane < 32) ? (lane <= imax) : (lane - 32 <= high)) {  // H rows 0..imax | V rows 0..26
-                        double *row = Abase + arow * EN + k;
-                        double pp = x * row[0] + y * row[1];
-                        if (notlast) { pp = pp + z * row[2]; row[2] = row[2] - pp * r; }
-                        c0 = row[0] - pp;
-                        row[0] = c0;
-                        row[1] = row[1] - pp * q;
-                    }
-                    // next reflector: H(k+1,k), H(k+2,k), H(k+3,k) as just computed by lanes k+1, k+2, k+3 (<= imax)
-                    if (k + 1 <= n - 1) {
-                        fp = lane_value_f64(c0, k + 1);
-                        fq = lane_value_f64(c0, k + 2);
-                        fr = (k + 1 != n - 1) ? lane_value_f64(c0, k + 3) : 0.0;
-                        fwd = true;
-                    }
-                    WAVE_SYNC();
+                if (s == 0.0) return;
+                const double hkk1 = (k != m) ? ldexp(-s, ex) : ((l != m) ? -HH(k, k - 1) : 0.0);
+                const bool wr_sub = (k != m) || (l != m);
+                p = p + s;
+                {   // x = p/s, y = q/s, z = r/s, q = q/p, r = r/p as one vector division over lanes 0..4
+                    const double num = (lane == 0) ? p : ((lane & 1) ? q : r);
+                    const double den = (lane < 3) ? s : p;
+                    const double quo = num / den;
+                    x = lane_value_f64(quo, 0); y = lane_value_f64(quo, 1); z = lane_value_f64(quo, 2);
+                    q = lane_value_f64(quo, 3); r = lane_value_f64(quo, 4);
                 }
-            }
+                PNP_STAMP(1);
+                WAVE_SYNC();
+                if (wr_sub && lane == 63) HH(k, k - 1) = hkk1;
+                if (rowact) {  // row modification, column j = lane
+                    const int j = lane;
+                    double pp = h0 + q * h1;
+                    if constexpr (NOTLAST) { pp = pp + r * h2; HH(k + 2, j) = h2 - pp * z; }
+                    HH(k, j) = h0 - pp * x;
+                    HH(k + 1, j) = h1 - pp * y;
+                }
+                WAVE_SYNC();
+                PNP_STAMP(2);
+                const int imax = (n < k + 3) ? n : k + 3;
+                double c0 = 0.0;
+                if ((lane < 32) ? (lane <= imax) : (lane - 32 <= high)) {  // H rows 0..imax | V rows 0..26
+                    double *row = Abase + arow * EN + k;
+                    const double a0 = row[0], a1 = row[1];
+                    double a2 = 0.0;
+                    if constexpr (NOTLAST) a2 = row[2];
+                    double pp = x * a0 + y * a1;
+                    if constexpr (NOTLAST) { pp = pp + z * a2; row[2] = a2 - pp * r; }
+                    c0 = a0 - pp;
+                    row[0] = c0;
+                    row[1] = a1 - pp * q;
+                }
+                // next reflector: H(k+1,k), H(k+2,k), H(k+3,k) as just computed by lanes k+1, k+2, k+3 (<= imax)
+                if constexpr (NOTLAST) {
+                    fp = lane_value_f64(c0, k + 1);
+                    fq = lane_value_f64(c0, k + 2);
+                    fr = (k + 1 != n - 1) ? lane_value_f64(c0, k + 3) : 0.0;
+                    fwd = true;
+                }
+                WAVE_SYNC();
+                PNP_STAMP(3);
+                if constexpr (STAMP) clk[4] += 1;
+            };
+            for (int k = m; k <= n - 2; k++) qr_step(k, std::true_type());
+            qr_step(n - 1, std::false_type());
         }
+        PNP_STAMP(0);
     }
     WAVE_SYNC();
+    if constexpr (STAMP) {
+        clk[7] = __builtin_readcyclecounter() - t_start;
+        if (lane < 8) {
+            unsigned long long v = clk[0];
+#pragma unroll
+            for (int i = 1; i < 8; i++) v = (lane == i) ? clk[i] : v;
+            a.stamps[(size_t)hyp * 8 + lane] = v;
+        }
+    }
 
     if (a.debug_stop == 3) return;
     // ================= back-substitution (real eigenvalues only), one lane per eigenvector =================
@@ -1109,6 +1185,8 @@ struct PnpState {
     double *cost = nullptr, *T_out = nullptr;            // device views of the same allocations
     int32_t *nin = nullptr, *valid = nullptr, *nsol = nullptr;
     unsigned long long *mask = nullptr;
+    unsigned long long *stamps = nullptr;                // tuning only (CHIP_PNP_STAMPS)
+    int32_t stamps_n = 0;
 };
 
 int pnp_create(Ctx *c)
@@ -1132,6 +1210,7 @@ static void pnp_free_dev(PnpState *st)
     (void)hipFree(st->sample); (void)hipFree(st->ok);
     (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid);
     (void)hipHostFree(st->h_nsol); (void)hipHostFree(st->h_mask);
+    (void)hipFree(st->stamps);
 }
 
 void pnp_destroy(Ctx *c)
@@ -1221,7 +1300,20 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
     ea.Sg = st->Sg; ea.Tg = st->Tg; ea.sample = st->sample; ea.ok = st->ok; ea.mask_words = words;
     { const char *dv = std::getenv("CHIP_PNP_DEBUG_STOP"); ea.debug_stop = dv ? std::atoi(dv) : 0; }
     ea.T_out = st->T_out; ea.cost = st->cost; ea.nin = st->nin; ea.valid = st->valid; ea.nsol = st->nsol; ea.mask = st->mask;
-    hipLaunchKernelGGL(pnp_eig_score, dim3(P * H), dim3(64), 0, s, ea);
+    static const bool want_stamps = std::getenv("CHIP_PNP_STAMPS") != nullptr;
+    if (want_stamps) {
+        if (st->stamps_n < P * H) {
+            (void)hipFree(st->stamps);
+            st->stamps = nullptr; st->stamps_n = 0;
+            CHIP_HIP(c, hipMalloc(&st->stamps, sizeof(unsigned long long) * 8 * (size_t)P * H));
+            st->stamps_n = P * H;
+        }
+        CHIP_HIP(c, hipMemsetAsync(st->stamps, 0, sizeof(unsigned long long) * 8 * (size_t)P * H, s));
+        ea.stamps = st->stamps;
+        hipLaunchKernelGGL(pnp_eig_score<true>, dim3(P * H), dim3(64), 0, s, ea);
+    } else {
+        hipLaunchKernelGGL(pnp_eig_score<false>, dim3(P * H), dim3(64), 0, s, ea);
+    }
     CHIP_HIP(c, hipGetLastError());
 
     CHIP_HIP(c, hipStreamSynchronize(s));   // every per-hypothesis result is in host memory now
@@ -1265,6 +1357,20 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
 }  // namespace chip
 
 using namespace chip;
+
+// Tuning aid, not part of the ABI: the per-wave shader-clock totals of the most recent pnp_eig_score<true> launch (CHIP_PNP_STAMPS=1).
+extern "C" int chip_debug_pnp_stamps(chip_ctx *c, unsigned long long *out, int32_t n_hyp)
+{
+    if (!c || !out) return CHIP_ERR_INVALID_ARG;
+    if (c->group) c = static_cast<chip_ctx *>(chip::group_root(c));
+    std::lock_guard<std::mutex> lk(c->pnp_mu);
+    PnpState *st = static_cast<PnpState *>(c->pnp_state);
+    if (!st || !st->stamps || n_hyp > st->stamps_n) return CHIP_ERR_INVALID_ARG;
+    CHIP_HIP(c, hipSetDevice(c->device));
+    CHIP_HIP(c, hipStreamSynchronize(c->s_pnp));
+    CHIP_HIP(c, hipMemcpy(out, st->stamps, sizeof(unsigned long long) * 8 * (size_t)n_hyp, hipMemcpyDeviceToHost));
+    return CHIP_OK;
+}
 
 extern "C" int chip_pnp_ransac_batch(chip_ctx *c, int32_t P, const double *const *X, const double *const *uv, const int32_t *N,
                                      const chip_ransac_params *p, const uint64_t *seeds, double *T_colmajor, float *confidence,

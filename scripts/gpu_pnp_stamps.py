@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Shader-clock split of the QR iteration of pnp_eig_score (CHIP_PNP_STAMPS=1 -> pnp_eig_score<true>): per wave, cycles spent in
+the sweep overhead, the reflector (sqrt + division chain), the row modification and the column modification (+ forwarding), with
+the numbers of sweeps and double-shift steps.  Config 3 scene: 512 correspondences, H hypotheses (default 1000)."""
+import ctypes as C
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import numpy as np  # noqa: E402
+
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+os.environ["CHIP_PNP_STAMPS"] = "1"
+from cerebro_amd import capi  # noqa: E402
+from cerebro_amd.synth import make_scene  # noqa: E402
+
+X, uv, T, inl = make_scene(N=512, outlier_frac=0.3, noise_px=0.5, seed=4242)
+with capi.Chip(64) as chip:
+    p = capi.default_ransac_params(); p.n_hypotheses = H; p.seed = 4242
+    for _ in range(3):
+        chip.pnp_ransac(X, uv, p)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        chip.pnp_ransac(X, uv, p)
+    call_us = (time.perf_counter() - t0) / 10 * 1e6
+    fn = chip.lib.chip_debug_pnp_stamps
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    buf = np.zeros((H, 8), dtype=np.uint64)
+    assert fn(chip.h, buf.ctypes.data, H) == 0
+t = buf.astype(np.float64)
+live = t[:, 7] > 0
+t = t[live]
+steps, sweeps = t[:, 4], t[:, 5]
+print(f"H={H}: {live.sum()} waves ran the QR; whole call {call_us:.0f} us WITH stamps (the stamps cost ~10 %)")
+print(f"double-shift steps per matrix: mean {steps.mean():.0f}  p95 {np.percentile(steps, 95):.0f}  max {steps.max():.0f};  sweeps: mean {sweeps.mean():.1f}  max {sweeps.max():.0f}")
+tot = t[:, 0] + t[:, 1] + t[:, 2] + t[:, 3]
+for name, col in (("sweep overhead (deflation test, shifts, m search)", 0), ("reflector: |p|+|q|+|r| .. sqrt .. division .. readlanes", 1),
+                  ("row modification (LDS read, 5 dependent ops, write)", 2), ("column modification + forwarding", 3)):
+    per = t[:, col] / np.where(col == 0, sweeps, steps)
+    print(f"  {name:58s}: {100 * t[:, col].sum() / tot.sum():5.1f} % of the QR cycles, {per.mean():7.1f} cycles per {'sweep' if col == 0 else 'step'}")
+slow = int(np.argmax(t[:, 7]))
+print(f"kernel = slowest wave: {t[slow, 7]:.0f} cycles ({steps[slow]:.0f} steps, {sweeps[slow]:.0f} sweeps): Hessenberg {t[slow, 6]:.0f}, QR {tot[slow]:.0f} "
+      f"= reflector {t[slow, 1]:.0f} + row {t[slow, 2]:.0f} + column {t[slow, 3]:.0f} + sweep overhead {t[slow, 0]:.0f}")
+print(f"mean wave: {t[:, 7].mean():.0f} cycles, Hessenberg {t[:, 6].mean():.0f}, QR {tot.mean():.0f}; cycles per step (all QR cycles / steps): {(tot / steps).mean():.0f}")
