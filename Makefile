@@ -27,7 +27,7 @@ $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/chip_internal.h $(CSRC)/ransac_common.h $(C
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIBDIR)/libcerebro_hip.so: $(HIP_OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -L$(ROCM)/lib -lrccl -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -lpthread -ldl
 
 # ---- ROS-free C++ host side (mirror of the Cerebro / StaticTheiaPoseCompute::PNP surface) + replay harness ----
 HOSTDIR    := cerebro_amd/host

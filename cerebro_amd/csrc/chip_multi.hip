@@ -12,6 +12,7 @@
 #include "chip_internal.h"
 #include "topk_merge.h"
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <atomic>
 #include <condition_variable>
 #include <cmath>
@@ -26,6 +27,48 @@
 namespace chip {
 
 static_assert(sizeof(ncclUniqueId) == CHIP_COMM_ID_BYTES, "CHIP_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
+
+// RCCL is loaded at run time (dlopen), not linked: a machine without librccl can still load libcerebro_hip.so and use everything
+// that needs no collective -- single-GPU contexts, and groups over the device-copy exchange (chip_create_multi falls back to it
+// and says so in chip_get_info().exchange / chip_last_comm_error()).  <rccl/rccl.h> is used for its types only.
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+static const Rccl &rccl()
+{
+    static const Rccl r = [] {
+        Rccl x;
+        const char *names[] = {std::getenv("CHIP_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            if (!n || !*n) continue;
+            x.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (x.handle) break;
+        }
+        if (!x.handle) return x;
+        auto sym = [&](const char *n) { return dlsym(x.handle, n); };
+        x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(sym("ncclGetUniqueId"));
+        x.CommInitAll = reinterpret_cast<decltype(x.CommInitAll)>(sym("ncclCommInitAll"));
+        x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+        x.CommCount = reinterpret_cast<decltype(x.CommCount)>(sym("ncclCommCount"));
+        x.AllGather = reinterpret_cast<decltype(x.AllGather)>(sym("ncclAllGather"));
+        x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(sym("ncclBroadcast"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+        x.ok = x.GetUniqueId && x.CommInitAll && x.CommInitRank && x.CommDestroy && x.CommCount && x.AllGather && x.Broadcast && x.GetErrorString;
+        return x;
+    }();
+    return r;
+}
 
 #define CHIP_NCCL(ctx, expr)                        \
     do {                                            \
@@ -88,7 +131,7 @@ void exchange_destroy(Ctx *c)
     Exchange *x = c->xchg;
     if (!x) return;
     (void)hipSetDevice(c->device);
-    if (x->comm) (void)ncclCommDestroy(x->comm);
+    if (x->comm && rccl().ok) (void)rccl().CommDestroy(x->comm);
     if (x->local_ring) (void)hipFree(x->local_ring);
     if (x->gathered_ring) (void)hipFree(x->gathered_ring);
     if (x->failed_list) (void)hipFree(x->failed_list);
@@ -102,7 +145,7 @@ int exchange_comm_ranks(const Ctx *c)
 {
     if (!c->xchg || !c->xchg->comm) return 0;
     int n = 0;
-    return ncclCommCount(c->xchg->comm, &n) == ncclSuccess ? n : 0;
+    return rccl().ok && rccl().CommCount(c->xchg->comm, &n) == ncclSuccess ? n : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ one process per GPU
@@ -132,7 +175,7 @@ int xchg_tick_enqueue(Ctx *c, int64_t l, int64_t k, const chip_dot_params *p, Sl
         if (rc != CHIP_OK) return rc;
         mine = x->local(b);
     }
-    CHIP_NCCL(c, ncclAllGather(mine, x->gathered(b), sizeof(chip_topk_entry) * 3 * K, ncclChar, x->comm, c->s_query));
+    CHIP_NCCL(c, rccl().AllGather(mine, x->gathered(b), sizeof(chip_topk_entry) * 3 * K, ncclChar, x->comm, c->s_query));
     return merge_enqueue_slot(c, l, p, x->gathered(b), x->world, K, s);               // merge + decision (:1035-1056), every rank
 }
 
@@ -155,7 +198,7 @@ int xchg_fetch_rows(Ctx *c, const int64_t *rows, int nq, int64_t n_local_publish
             if (g >= n_local_published) *fail_local = true;   // garbage goes out, and the failure mark with it
             else src = row_ptr_host(c, local_of(c, g));
         }
-        CHIP_NCCL(c, ncclBroadcast(src, dst, rb, ncclChar, owner, x->comm, c->s_scan));
+        CHIP_NCCL(c, rccl().Broadcast(src, dst, rb, ncclChar, owner, x->comm, c->s_scan));
         q[i] = dst;
     }
     return CHIP_OK;
@@ -172,7 +215,7 @@ int xchg_query(Ctx *c, int64_t k, const void *const *q, int nq, int K, double *s
         if (rc != CHIP_OK) return rc;
         mine = x->local(b);
     }
-    CHIP_NCCL(c, ncclAllGather(mine, x->gathered(b), sizeof(chip_topk_entry) * nq * K, ncclChar, x->comm, c->s_query));
+    CHIP_NCCL(c, rccl().AllGather(mine, x->gathered(b), sizeof(chip_topk_entry) * nq * K, ncclChar, x->comm, c->s_query));
     const int rc = merge_enqueue_out(c, x->gathered(b), x->world, nq, K, c->topk_dev);
     if (rc != CHIP_OK) return rc;
     return sync_topk_out(c, nq, K, scores, idx);
@@ -482,7 +525,7 @@ static int sub_scan(Group *G, int g, const GroupScan &j, int b, std::atomic<int>
     if (rc != CHIP_OK) return fail_hard(rc);
     if (G->transport == CHIP_EXCHANGE_RCCL) {
         // one thread per device, each on its own communicator of the clique: the classic multi-threaded NCCL layout (no group call)
-        const ncclResult_t nr = ncclAllGather(x->local(b), x->gathered(b), sizeof(chip_topk_entry) * list, ncclChar, x->comm, c->s_query);
+        const ncclResult_t nr = rccl().AllGather(x->local(b), x->gathered(b), sizeof(chip_topk_entry) * list, ncclChar, x->comm, c->s_query);
         if (nr != ncclSuccess) { c->last_comm = (int)nr; return fail_hard(CHIP_ERR_COMM); }
         if (g == 0) {
             rc = j.p ? merge_enqueue_slot(c, j.l, j.p, x->gathered(b), x->world, j.K, *j.slot)
@@ -646,7 +689,7 @@ int chip_last_comm_error(const chip_ctx *ctx, const char **text)
     if (ctx->group)
         for (const chip_ctx *s : ctx->group->subs)
             if (s->last_comm) r = s->last_comm;
-    if (text) *text = ncclGetErrorString((ncclResult_t)r);
+    if (text) *text = rccl().ok ? rccl().GetErrorString((ncclResult_t)r) : (r ? "librccl could not be loaded (dlopen): no RCCL exchange available" : "no error");
     return r;
 }
 
@@ -683,7 +726,7 @@ int chip_create_multi(chip_ctx **out, int32_t D, int64_t capacity_hint, const in
     }
     if (rc == CHIP_OK && G->transport == CHIP_EXCHANGE_RCCL) {
         std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
-        const ncclResult_t r = ncclCommInitAll(comms.data(), n_devices, devices);
+        const ncclResult_t r = rccl().ok ? rccl().CommInitAll(comms.data(), n_devices, devices) : ncclSystemError;   // no librccl: copy exchange
         if (r != ncclSuccess) {
             // No communicator (RCCL absent / misconfigured, peer access refused ...): the lists are 384 B per device and tick, so
             // the device-copy exchange is a full substitute -- fall back to it instead of failing the create; the ncclResult_t
@@ -718,7 +761,7 @@ int chip_comm_unique_id(void *id_out)
 {
     if (!id_out) return CHIP_ERR_INVALID_ARG;
     ncclUniqueId id;
-    if (ncclGetUniqueId(&id) != ncclSuccess) return CHIP_ERR_COMM;
+    if (!rccl().ok || rccl().GetUniqueId(&id) != ncclSuccess) return CHIP_ERR_COMM;
     std::memcpy(id_out, &id, sizeof id);
     return CHIP_OK;
 }
@@ -734,9 +777,10 @@ int chip_comm_init_rank(chip_ctx *c, const void *id_in, int32_t n_ranks, int32_t
     ncclUniqueId id;
     std::memcpy(&id, id_in, sizeof id);
     ncclComm_t comm = nullptr;
-    CHIP_NCCL(c, ncclCommInitRank(&comm, n_ranks, id, rank));
+    if (!rccl().ok) { c->last_comm = (int)ncclSystemError; return CHIP_ERR_COMM; }
+    CHIP_NCCL(c, rccl().CommInitRank(&comm, n_ranks, id, rank));
     const int rc = exchange_create(c, n_ranks, true);
-    if (rc != CHIP_OK) { (void)ncclCommDestroy(comm); exchange_destroy(c); return rc; }
+    if (rc != CHIP_OK) { (void)rccl().CommDestroy(comm); exchange_destroy(c); return rc; }
     c->xchg->comm = comm;
     // three small kernels per tick now go through the ctx stream underneath the scans: keep workgroup slots free for them
     c->scan_reserve = env_int("CHIP_SCAN_RESERVE", 4);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CHIP_ABI_VERSION 2
+#define CHIP_ABI_VERSION 3
 
 /* ------------------------------------------------------------------------------------------ status codes */
 enum {
@@ -73,9 +73,11 @@ int chip_last_comm_error(const chip_ctx *ctx, const char **text);
  * CHIP_RING_ROWS rows (64 MiB at D=4096), from which the tick's three query descriptors are read: a sharded
  * tick at l therefore needs chip_db_size() - l <= CHIP_RING_ROWS - 3 (else CHIP_ERR_RANGE) -- always true in
  * live operation, where ticks trail the append head by a few rows.  Every rank must be fed the same append
- * stream.  One process per GPU; the per-shard top-k lists are exchanged by the HOST
- * (RCCL all-gather via torch.distributed, or any other transport) between chip_scan_local and
- * chip_merge_decide.                                                                                   */
+ * stream.  One process per GPU; the per-shard top-k lists are exchanged INSIDE the library once an RCCL
+ * communicator is attached (chip_comm_init_rank below), or by the HOST (any transport) between
+ * chip_scan_local and chip_merge_decide.  Query rows of chip_query_rows / chip_query_scores: with an exchange
+ * attached (or on a chip_create_multi ctx) ANY appended row -- it is fetched from the shard that owns it; on a
+ * sharded ctx without an exchange only rows still in this rank's ring (else CHIP_ERR_RANGE).                */
 #define CHIP_RING_ROWS 4096
 int  chip_create(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device, int32_t shard_rank, int32_t shard_count);
 void chip_destroy(chip_ctx *ctx);
@@ -98,16 +100,24 @@ int  chip_create_ex(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t de
 /* ------------------------------------------------------------------------------------------ multi-GPU inside the library
  * (a) ONE process, G GPUs -- the shape of the reference: the loop-candidate producer is one thread of one process
  *     (src/cerebro_node.cpp:499, src/Cerebro.cpp:903).  chip_create_multi returns ONE ctx backed by G per-device
- *     sub-contexts (rows round-robin, row i on devices[i % G]); every entry point of this header that takes a ctx works on
- *     it unchanged: appends feed all devices, chip_loop_tick* = G local scans -> per-device local top-k -> exchange ->
- *     merge + decision on devices[0], PnP / ICP run on devices[0].  One host worker thread per device enqueues that
- *     device's work, so the host cost of a tick does not grow with G.
+ *     sub-contexts (rows round-robin, row i on devices[i % G]).  The entry points of the reference's path work on it
+ *     unchanged: chip_db_append_* (every device is SENT only the rows it owns plus the newest CHIP_RING_ROWS of the batch: a
+ *     bulk load moves ~1x the batch over PCIe, not Gx; the validation decision is one, from all devices),
+ *     chip_db_read_rows_*, chip_loop_tick* = G local scans -> per-device local top-k -> exchange -> merge + decision on
+ *     devices[0], chip_query_rows / _vectors_* / _scores, chip_synchronize, chip_profile_*, PnP / ICP (on devices[0]).
+ *     NOT on a group ctx (CHIP_ERR_UNSUPPORTED): chip_set_stream / chip_reset_stream, chip_scan_local, chip_merge_decide*,
+ *     chip_comm_init_rank (the group owns its exchange) and chip_query_batch_f32 (the MFMA many-query mode is single-GPU).
+ *     One host worker thread per device enqueues that device's work, so the host cost of a tick does not grow with G.
+ *     Failure containment: a call that fails on SOME devices before anything became visible changes nothing; a shard that
+ *     cannot take part in one tick sends a marked neutral list, the tick fails everywhere alike (CHIP_ERR_SHARD_FAILED) and the
+ *     exchange stays in step; a failure after the devices diverged marks the ctx broken (CHIP_ERR_GROUP_BROKEN).
  *     Exchange: an RCCL communicator over the G devices (ncclCommInitAll; ncclAllGather of 3 x topk (score,index) entries per
  *     rank per tick, enqueued in-stream between the local and the global merge) when the devices are distinct; device
  *     copies (lists written / copied straight into the root's gather buffer behind events) when CHIP_MULTI_EXCHANGE_COPY is
  *     passed or the list names a device twice (RCCL refuses two ranks on one device) -- the latter lets a 1-GPU box run the
- *     G = 2..8 code path.  If RCCL cannot build the communicator the create does not fail: it falls back to the copy exchange
- *     (chip_get_info().exchange tells which one is in use, chip_last_comm_error() why).
+ *     G = 2..8 code path.  RCCL is loaded with dlopen (librccl.so.1, or $CHIP_RCCL_LIBRARY), the library does not link it: if it
+ *     is absent or cannot build the communicator the create does not fail, it falls back to the copy exchange
+ *     (chip_get_info().exchange / .comm_ranks tell which one is in use and over how many ranks, chip_last_comm_error() why).
  * (b) one process PER GPU (torchrun-style launch): create each rank's ctx with chip_create(.., shard_rank, shard_count),
  *     then attach an RCCL communicator: rank 0 calls chip_comm_unique_id, distributes the 128 bytes by any means, every
  *     rank calls chip_comm_init_rank.  From then on chip_loop_tick / _enqueue / _collect and chip_query_* work on the
@@ -165,7 +175,9 @@ int chip_query_vectors_f64(chip_ctx *ctx, int64_t k, const double *queries, int3
                            double *scores, int64_t *idx);
 /* The whole score vector  u = v^T * M.leftCols(k)  of ONE query row (src/Cerebro.cpp:1026; the reference's debug plot consumes
  * all of u, :1047-1052) -- same arithmetic, same bits as the scores chip_query_rows selects from.  u: k doubles (host).
- * A sharded ctx without an exchange fills only the entries of the rows it owns. */
+ * A chip_create_multi ctx fills all of u.  A sharded ctx of the one-process-per-GPU layout fills only the entries of the rows THIS
+ * rank owns (u[i], i % shard_count == shard_rank), with or without an exchange; with an exchange attached the call is collective
+ * (the query row is broadcast from its owner), without one the query row must still be in this rank's ring. */
 int chip_query_scores(chip_ctx *ctx, int64_t k, int64_t query_row, double *u);
 
 /* Many-query batched mode: Q query descriptors (host, Q x D fp32) against rows [0,k) in ONE pass of

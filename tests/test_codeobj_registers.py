@@ -112,3 +112,70 @@ def test_rows_kernel_register_partition(tmp_path):
                 raise AssertionError(f"{name}: compiler-owned instruction touches a reserved register: {text}")
         assert n_loads >= 8 and n_takes >= 8, (name, n_loads, n_takes)
         assert scratch <= 24, (name, scratch)
+
+
+def _kernel_listings(tmp_path, want):
+    out = {}
+    for co in code_objects(tmp_path):
+        dis = subprocess.run([str(LLVM / "llvm-objdump"), "-d", "--mcpu=gfx950", "--no-show-raw-insn", str(co)],
+                             capture_output=True, text=True, check=True).stdout
+        cur = None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                cur = m.group(1) if want(m.group(1)) else None
+                if cur:
+                    out[cur] = []
+                continue
+            if cur and line.strip() and not line.startswith("Disassembly"):
+                out[cur].append(line.split("//")[0].strip())
+    return out
+
+
+@pytest.mark.skipif(not (LLVM / "llvm-objdump").exists(), reason="llvm-objdump not available")
+def test_asm_issued_loads_of_the_one_row_kernel_are_not_touched_before_their_wait(tmp_path):
+    """The one-row scan kernel (db_scan_topk, load paths NT = 6 / 8, and db_scan_scores) also issues its row loads from inline asm
+    with "=v" outputs and consumes them behind counted waits; there the compiler OWNS the target registers and believes them defined
+    at the load statement: a copy, spill or reuse scheduled between load and wait would read a register still in
+    flight.  This walks the built code: every vector-memory load is queued with its destination registers (loads return in order,
+    `s_waitcnt vmcnt(n)` retires all but the newest n), and any instruction that reads or writes a register of a load still
+    pending fails the test.  Straight-line walk, restarted at unconditional branches."""
+    if not SO.exists():
+        pytest.skip("libcerebro_hip.so not built")
+
+    def want(name):
+        if "db_scan_scores" in name:
+            return True
+        m = re.search(r"db_scan_topkI[fd]Li\d+ELi\d+ELb[01]ELi(\d+)ELi\d+EE", name)
+        return bool(m) and m.group(1) in ("6", "8")
+
+    kernels = _kernel_listings(tmp_path, want)
+    assert len(kernels) >= 8, sorted(kernels)
+    n_checked = 0
+    for name, ins in kernels.items():
+        pending = []          # oldest first: set of VGPRs each outstanding VMEM operation will write (empty for stores)
+        for text in ins:
+            parts = text.split(None, 1)
+            if not parts:
+                continue
+            op = parts[0]
+            ops = [o.strip().split()[0] for o in parts[1].split(",")] if len(parts) > 1 else []
+            if op == "s_waitcnt":
+                m = re.search(r"vmcnt\((\d+)\)", text)
+                if m:
+                    n = int(m.group(1))
+                    while len(pending) > n:
+                        pending.pop(0)
+                continue
+            if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                pending = []
+                continue
+            touched = {r for o in ops for r in regs_of(o)}
+            busy = set().union(*pending) if pending else set()
+            assert not (touched & busy), f"{name}: `{text}` touches {sorted(touched & busy)} while their load is in flight"
+            if op.startswith(("global_load", "buffer_load", "scratch_load", "flat_load")) and "lds" not in op:
+                pending.append(set(regs_of(ops[0])))
+                n_checked += 1
+            elif op.startswith(("global_store", "buffer_store", "scratch_store", "flat_store", "global_atomic")) or "load_lds" in op:
+                pending.append(set())
+    assert n_checked >= 100
