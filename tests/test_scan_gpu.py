@@ -237,6 +237,15 @@ def test_10k_full_oracle_parity():
             u = chip.query_scores(l - 50, l - 1 - j)
             assert np.array_equal(bits(u), bits(oracle_lib.scores(db, l - 50, qrows[j], nthreads=os.cpu_count() or 1)))
             assert int(np.flatnonzero(u == u.max())[-1]) == r.argmax[j]      # maxCoeff + LAST index attaining it (:1035-1043)
+        # ... and against the summation order of the reference's own build (Eigen 3.3 row-major GEMV, SSE2 packets, no FMA --
+        # oracle/dot_scan.c orc_ref_scan_f64_eigen_order): the GPU's score vector deviates by rounding only, the selection is the same
+        db64 = db.astype(np.float64)
+        emaxv, earg, (eu, eum, eumm) = oracle_lib.ref_scan_f64_eigen_order(db64, l - 50, qrows[0], qrows[1], qrows[2], 2, False,
+                                                                           nthreads=os.cpu_count() or 1)
+        assert list(earg) == list(r.argmax)
+        u0 = chip.query_scores(l - 50, l - 1)
+        assert np.max(np.abs(u0 - eu)) <= 1e-15 * np.sqrt(D)
+        assert abs(emaxv[0] - r.maxv[0]) <= 1e-15 * np.sqrt(D) and (emaxv[0] > capi.default_dot_params().thresh) == bool(r.found)
 
 
 def test_score_vector_export_2500():
