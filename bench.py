@@ -345,11 +345,11 @@ def size_leg(chip, rows, plan, params, inflight, n_ticks=240, warm=20):
     gaps = np.diff(np.array(stamps))
     return {"db_rows": rows, "value": n / dt, "unit": "loop-queries/s", "ms_per_step": 1e3 * step_s,
             "ms_per_step_median": 1e3 * float(np.median(gaps)) if gaps.size else None, "steps": n,
-            "roofline": {"bound": "hbm" if not cache_resident else "hbm (NOT an HBM figure: the 164 MB prefix is Infinity-Cache resident, 256 MiB)",
+            "roofline": {"bound": "hbm" if not cache_resident else "hbm (the 164 MB prefix is Infinity-Cache sized, 256 MiB; a pure reader of such a buffer peaks at 7.3 TB/s on this part, profiles/r03_tick_timeline_10k.md)",
                          "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS,
                          "priced_from": "ms_per_step of the timed loop (launches of consecutive ticks overlap on two scan streams)",
                          "kernel_overlap": True,
-                         "traffic": None, "kernel": "db_scan_topk_rows (row-batched form: <= 8 rows per wave)" if rows <= 8 * 4096 else "db_scan_topk",
+                         "traffic": None, "kernel": "db_scan_topk_rows (row-batched form, R = 1, temporal loads: prefixes <= 768 MiB)" if alg <= 768 * 2**20 else "db_scan_topk",
                          "isolated_kernel_ms": iso_s * 1e3, "isolated_kernel_note": "one launch alone on one stream between two hipEvents "
                          "(profiled pass, no overlap): >= ms_per_step by the ramp-up / ramp-down that overlapping launches hide",
                          "launches": cnt, "algorithmic_bytes_per_launch": alg, "cache_resident": cache_resident}}
@@ -415,7 +415,7 @@ def main():
     n_ticks = args.warmup + args.steps
     # the 10k / 100k legs (N = 1) tick over shorter prefixes of the same DB: their planted query rows are DB rows of the
     # longer scans, so the longer plans keep their revisited rows out of those windows
-    leg_rows = [r for r in (10_000, 100_000) if r + 4000 < args.rows] if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 \
+    leg_rows = [r for r in (10_000, 29_000, 100_000) if r + 4000 < args.rows]   # 29k = the reference's own capacity (Cerebro.cpp:946) if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 \
         and not args.no_sizes and not args.force_sharded else []
     windows = [(r, r + LAG + 3 * 260 + 3) for r in leg_rows]
     ls, plants, expect = plan_ticks(args.rows, n_ticks, avoid=windows)

@@ -161,6 +161,7 @@ void ctx_destroy(chip_ctx *c)
     if (c->qvec_dev) (void)hipFree(c->qvec_dev);
     if (c->scores_dev) (void)hipFree(c->scores_dev);
     if (c->stamps_dev) (void)hipFree(c->stamps_dev);
+    if (c->tickets_dev) (void)hipFree(c->tickets_dev);
     for (Slot &s : c->slots) {
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.host) (void)hipHostFree(s.host);
@@ -203,9 +204,9 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);
     c->scan_rows = env_int("CHIP_SCAN_ROWS", 0);
     c->tick_same_stream = env_int("CHIP_TICK_SAME_STREAM", 1) != 0;
-    c->scan_rows_auto_max = env_int("CHIP_SCAN_ROWS_AUTO_MAX", 8);
     c->scan_short_bpc = env_int("CHIP_SCAN_SHORT_BPC", 1);
-    c->scan_plain_bytes = (double)env_int("CHIP_SCAN_PLAIN_MIB", 192) * 1024 * 1024;
+    c->scan_plain_bytes = (double)env_int("CHIP_SCAN_PLAIN_MIB", 768) * 1024 * 1024;
+    c->scan_half_bytes = (double)env_int("CHIP_SCAN_HALF_MIB", 192) * 1024 * 1024;
     c->scan_overlap_bytes = (double)env_int("CHIP_SCAN_OVERLAP_GIB", 8) * 1024 * 1024 * 1024;
     // a sharded ctx gets three small kernels per tick through its ctx stream underneath the scans: keep slots free for them
     c->scan_reserve = env_int("CHIP_SCAN_RESERVE", c->nranks > 1 ? 4 : 0);
@@ -234,6 +235,9 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
         CHIP_HIP(c, hipEventCreateWithFlags(&c->ev_scan[i], hipEventDisableTiming));
         CHIP_HIP(c, hipEventCreateWithFlags(&c->ev_merged[i], hipEventDisableTiming));
     }
+    CHIP_HIP(c, hipMalloc(&c->tickets_dev, Ctx::kRing * sizeof(int32_t)));
+    CHIP_HIP(c, hipMemset(c->tickets_dev, 0, Ctx::kRing * sizeof(int32_t)));
+    c->tick_fused = env_int("CHIP_TICK_FUSED", 1) != 0;
     CHIP_HIP(c, hipHostMalloc(&c->topk_host, (size_t)CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry), hipHostMallocDefault));
     CHIP_HIP(c, hipHostGetDevicePointer((void **)&c->topk_dev, c->topk_host, 0));
     for (Slot &s : c->slots) {
@@ -325,6 +329,17 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
     a.rows_form = scan_rows_form(c, a.n_rows, nq, grid, a.q64 != 0);
     a.plain_loads = (double)a.n_rows * c->D * c->elem <= c->scan_plain_bytes ? 1 : 0;
     a.stamps = c->stamps_dev;
+    // fused tick: one launch (kernels.hip fused_tick_finish) -- same-stream short ticks through the row-batched kernel, decision wanted,
+    // no list output
+    const bool fused = same_stream && a.rows_form > 0 && c->tick_fused && res != nullptr && out == nullptr && nq == 3 && p != nullptr;
+    if (fused) {
+        a.K = 1;
+        a.fused_result = res;
+        a.fused_ticket = c->tickets_dev + b;
+        a.tick_l = l;
+        a.locality = p->locality;
+        a.thresh = p->thresh;
+    }
 
     // The merge that last read this buffer ran kRing ticks ago; only when it is not already complete (a stalled ctx
     // stream) does the scan stream need a barrier packet -- in steady state this costs nothing.
@@ -359,6 +374,11 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
         CHIP_HIP(c, hipStreamWaitEvent(c->s_query, c->ev_scan[b], 0));
     }
 
+    if (fused) {   // the scan's last workgroup has written the decision record: the scan's end IS the tick's end
+        CHIP_HIP(c, hipEventRecord(c->ev_merged[b], s_scan));
+        if (merged_ev) *merged_ev = c->ev_merged[b];
+        return CHIP_OK;
+    }
     MergeArgs m;
     m.in = c->partial_dev[b];
     m.n_lists = grid;

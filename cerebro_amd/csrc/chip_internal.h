@@ -29,6 +29,13 @@ struct ScanArgs {
     int32_t rows_form = 0;          // > 0: row-batched kernel with this many rows per wave in flight (scan_rows_form)
     int32_t plain_loads = 0;        // row-batched kernel: temporal loads (the prefix fits the Infinity Cache and is re-read every tick)
     unsigned long long *stamps = nullptr;   // tuning only (CHIP_SCAN_STAMPS): 4 wall-clock stamps per wave of the row-batched kernel
+    // fused tick (row-batched kernel, plain ctx): the LAST workgroup to finish reduces the per-workgroup best entries and writes the
+    // decision record itself -- a tick is then ONE launch.  fused_result == nullptr: lists only, K2 follows as a launch of its own.
+    chip_tick_result *fused_result = nullptr;
+    int32_t *fused_ticket = nullptr;        // arrival counter of this launch's list buffer (0 at launch, reset by the last workgroup)
+    int64_t tick_l = 0;
+    int32_t locality = 0;
+    double thresh = 0.0;
 };
 
 struct MergeArgs {
@@ -126,6 +133,8 @@ struct Ctx {
     int32_t partial_lists[kRing] = {};                               // grid of the scan that filled it
     hipEvent_t ev_scan[kRing] = {};             // scan into buffer b finished
     hipEvent_t ev_merged[kRing] = {};           // merge out of buffer b finished
+    int32_t *tickets_dev = nullptr;             // [kRing] arrival counters of the fused tick (one per list buffer)
+    bool tick_fused = true;                     // CHIP_TICK_FUSED=0 disables
     uint64_t n_enqueued = 0;
     int32_t max_grid = 0;
     chip_topk_entry *topk_dev = nullptr;      // [CHIP_MAX_NQ][CHIP_MAX_TOPK]
@@ -153,10 +162,10 @@ struct Ctx {
     int32_t scan_reserve = 0;
     int32_t scan_variant = 0;
     bool tick_same_stream = true;  // short ticks of a plain ctx: merge on the scan's stream (CHIP_TICK_SAME_STREAM=0 disables)
-    int32_t scan_rows = 0;        // CHIP_SCAN_ROWS: 0 = auto, 1..3 = row-batched kernel with that R for every scan, -1 = never
-    double scan_plain_bytes = 192.0 * 1024 * 1024;   // prefixes up to this size are read with temporal loads (CHIP_SCAN_PLAIN_MIB)
+    int32_t scan_rows = 0;        // CHIP_SCAN_ROWS: 0 = auto (prefixes up to scan_plain_bytes), 1..3 = row-batched kernel with that R for every scan, -1 = never
+    double scan_plain_bytes = 768.0 * 1024 * 1024;   // prefixes up to this size: rows form, R = 1, temporal loads (CHIP_SCAN_PLAIN_MIB)
+    double scan_half_bytes = 192.0 * 1024 * 1024;    // prefixes up to this size: launches take half of every CU's workgroup slots (CHIP_SCAN_HALF_MIB)
     int32_t scan_short_bpc = 1;       // workgroups per CU of a launch over a cache-sized prefix (CHIP_SCAN_SHORT_BPC; 0 = as any other)
-    int32_t scan_rows_auto_max = 8;   // auto: row-batched kernel while a wave owns at most this many rows (CHIP_SCAN_ROWS_AUTO_MAX)
     double scan_overlap_bytes = 8.0 * 1024 * 1024 * 1024;   // launches up to this size alternate between the two scan streams (CHIP_SCAN_OVERLAP_GIB)
 
     // --- profiling ---

@@ -367,8 +367,22 @@ __device__ __forceinline__ void wave_topk_offer_lds(double s, int64_t gi, int K,
 }
 
 // Block merge over the LDS lists: wpb sorted lists of K per query -> one sorted list of K per query in a.partial[blockIdx.x].
+// device-coherent 16-byte entry store / load (agent-scope relaxed atomics: write-through `sc1` stores and loads, no cache-wide fence)
+__device__ __forceinline__ void store_entry_agent(chip_topk_entry *p, double s, int64_t i)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&p->score), (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(&p->idx), (unsigned long long)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ chip_topk_entry load_entry_agent(const chip_topk_entry *p)
+{
+    chip_topk_entry e;
+    e.score = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(&p->score), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    e.idx = (int64_t)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(&p->idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return e;
+}
+
 template <int NQ>
-__device__ __forceinline__ void block_merge_lists(const ScanArgs &a, const chip_topk_entry *lists, int K, int lane, int wave, int wpb)
+__device__ __forceinline__ void block_merge_lists(const ScanArgs &a, const chip_topk_entry *lists, int K, int lane, int wave, int wpb, bool coherent = false)
 {
     __syncthreads();
     for (int q = wave; q < NQ; q += wpb) {
@@ -400,7 +414,10 @@ __device__ __forceinline__ void block_merge_lists(const ScanArgs &a, const chip_
 #pragma unroll
             for (int h = 0; h < 4; h++)
                 if (ci[h] == bi && cs[h] == bs) { cs[h] = -INFINITY; ci[h] = -1; }
-            if (lane == 0) { chip_topk_entry t; t.score = bs; t.idx = bi; outp[j] = t; }
+            if (lane == 0) {
+                if (coherent) store_entry_agent(outp + j, bs, bi);
+                else { chip_topk_entry t; t.score = bs; t.idx = bi; outp[j] = t; }
+            }
         }
     }
 }
@@ -447,6 +464,80 @@ __device__ __forceinline__ void rows_take(double (&d)[2], double)
 {
     asm volatile("s_waitcnt vmcnt(%1)\n\tv_mov_b64 %0, v[%2:%3]" : "=&v"(d[0]) : "n"(CNT), "n"(REG + 2 * H), "n"(REG + 2 * H + 1) : "memory");
     d[1] = 0.0;
+}
+
+// Fused tick: the decision of Cerebro.cpp:1035-1056 needs the BEST entry per query only (chip_tick_result carries argmax / maxv, no
+// lists), and the best of the whole prefix is the best of the per-workgroup bests under the same total order (score desc, index
+// desc).  So a tick runs the scan with K = 1 and the last workgroup to arrive (device-scope ticket) reduces the <= 512 per-workgroup
+// entries -- one per thread, wave butterfly, eight waves through LDS -- applies the accept rule and stores the 64-byte record straight
+// into the pinned host slot: no K2 launch, no launch gap, no second kernel's ramp (a 10k-row tick spent ~15 us of its stream's time in
+// the one-workgroup merge and ~6 us in front of it, profiles/r03_tick_timeline_10k.md).  Hand-off: write-through stores + completion
+// wait + device-scope ticket on the writers' side, L2-bypassing loads on the last workgroup's side (no cache-wide fences).
+template <int NQ>
+__device__ __forceinline__ void fused_tick_finish(const ScanArgs &a, char *smem, int K, int tid, int lane, int wave, int wpb)
+{
+    int *last = reinterpret_cast<int *>(smem);                                  // LDS is free again: the lists have been consumed
+    chip_topk_entry *wbest = reinterpret_cast<chip_topk_entry *>(smem + 64);    // [wpb][NQ]
+    // This workgroup's entries went out as write-through (agent-scope) stores; once they have completed (vmcnt(0)) they are visible
+    // device-wide, and the ticket may be taken.  No __threadfence(): an agent-scope release fence writes back this XCD's L2 -- with
+    // 256-512 workgroups doing it the tick took 120 us instead of 25 (measured; it is also why round 2's fused merge lost).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) *last = atomicAdd(a.fused_ticket, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!*last) return;
+    double bs[NQ];
+    int64_t bi[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        bs[q] = -INFINITY; bi[q] = -1;
+        if (tid < (int)gridDim.x) {
+            const chip_topk_entry e = load_entry_agent(a.partial + ((int64_t)tid * NQ + q) * K);   // bypasses this XCD's L2
+            bs[q] = e.score; bi[q] = e.idx;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double os = __shfl_xor(bs[q], m, 64);
+            const int64_t oi = __shfl_xor(bi[q], m, 64);
+            if (key_gt(os, oi, bs[q], bi[q])) { bs[q] = os; bi[q] = oi; }
+        }
+        if (lane == 0) { chip_topk_entry e; e.score = bs[q]; e.idx = bi[q]; wbest[wave * NQ + q] = e; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        chip_tick_result res;
+        res.status = CHIP_TICK_SCANNED;
+        res.found = 0;
+        res.idx_curr = -1;
+        res.idx_prev = -1;
+        res.score = 0.0;
+        for (int q = 0; q < 3; q++) {
+            double s = -INFINITY;
+            int64_t i = -1;
+            if (q < NQ)
+                for (int w = 0; w < wpb; w++) {
+                    const chip_topk_entry e = wbest[w * NQ + q];
+                    if (key_gt(e.score, e.idx, s, i)) { s = e.score; i = e.idx; }
+                }
+            res.argmax[q] = i;
+            res.maxv[q] = s;
+        }
+        if (NQ >= 3 && res.argmax[0] >= 0 && res.argmax[1] >= 0 && res.argmax[2] >= 0) {
+            // Cerebro.cpp:1056  abs(u_argmax-um_argmax) < LOCALITY && abs(u_argmax-umm_argmax) < LOCALITY && u_max > THRESH
+            int64_t d1 = res.argmax[0] - res.argmax[1];
+            int64_t d2 = res.argmax[0] - res.argmax[2];
+            if (d1 < 0) d1 = -d1;
+            if (d2 < 0) d2 = -d2;
+            if (d1 < a.locality && d2 < a.locality && res.maxv[0] > a.thresh) {
+                res.found = 1;
+                res.idx_curr = a.tick_l - 1;  // Cerebro.cpp:1080
+                res.idx_prev = res.argmax[0];
+                res.score = res.maxv[0];
+            }
+        }
+        *a.fused_result = res;
+        *a.fused_ticket = 0;               // ready for the launch that reuses this list buffer (ordered behind this one by its event)
+    }
 }
 
 template <typename T, int NQ, int R, bool NTL>
@@ -596,7 +687,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
 #undef CHIP_ROWS_FMA_HALF
 #undef CHIP_ROWS_ISSUE_SLOT
     if (stamp && lane == 0) stamp[2] = wall_clock64();
-    block_merge_lists<NQ>(a, lists, K, lane, wave, wpb);
+    block_merge_lists<NQ>(a, lists, K, lane, wave, wpb, a.fused_result != nullptr);
+    if (a.fused_result != nullptr) fused_tick_finish<NQ>(a, smem, K, tid, lane, wave, wpb);
     if (stamp && lane == 0) stamp[3] = wall_clock64();
 }
 
@@ -699,8 +791,7 @@ bool scan_q64(const Ctx *c, int nq, bool long_scan)
 }
 
 // Row-batched form of K1 (db_scan_topk_rows): R rows per wave in flight.  Returns R (1..3), or 0 for the one-row kernel.
-// Default policy: short scans, where a wave owns only a handful of rows and the one-row kernel is a chain of dependent
-// 4 KiB batches; CHIP_SCAN_ROWS forces R for every scan (1..3) or disables the form (-1).
+// CHIP_SCAN_ROWS forces R for every scan (1..3) or disables the form (-1).
 int scan_rows_form(const Ctx *c, int64_t n_rows, int nq, int grid, bool q64)
 {
     if (q64 || c->scan_rows < 0 || c->scan_variant == 1 || (int64_t)c->D * c->elem % 4096 != 0) return 0;
@@ -711,12 +802,15 @@ int scan_rows_form(const Ctx *c, int64_t n_rows, int nq, int grid, bool q64)
     const int64_t rpw = (n_rows + waves - 1) / waves;
     const int rmax = nq >= 4 ? 1 : 3;
     if (c->scan_rows > 0) return c->scan_rows > rmax ? rmax : c->scan_rows;
-    if (rpw < 1) return 1;
-    if (rpw > c->scan_rows_auto_max) return 0;
-    // cache-sized prefix at half occupancy, four tick streams (BASELINE config 2): R = 1 / 2 / 3 measured 25.1 / 26.5 / 27.7 us per
-    // 10k-row tick (profiles/r03_short_scan_ab_2.txt) -- less in flight per wave lets the LDS-DMA of the queries land sooner
-    if ((double)n_rows * c->D * c->elem <= c->scan_plain_bytes) return 1;
-    return rpw >= rmax ? rmax : (int)rpw;
+    (void)rpw;
+    // Default policy, from A/B runs on one box (us per tick, 4096-D; profiles/r03_short_scan_ab_2.txt, r03_mid_scan_ab.txt):
+    //   10k rows (164 MB): rows form R = 1 / 2 / 3 at half occupancy 25.1 / 26.5 / 27.7, one-row kernel 30.0;
+    //   29k rows (475 MB, the reference's own capacity, Cerebro.cpp:946): rows form R = 1 with temporal loads 66.4, one-row kernel
+    //   71.7, rows form with non-temporal loads R = 1 / 2 / 3 75.6 / 75.1 / 83.8;   60k rows (983 MB): 142.1 vs 141.3;
+    //   100k / 1M rows: one-row kernel 232 / 2355 vs 245 / 2353.
+    // => prefixes up to scan_plain_bytes (768 MiB: a good part of them survives in the 256 MiB Infinity Cache from tick to tick) take
+    //    the rows form with R = 1 and temporal loads; longer ones the one-row kernel with non-temporal loads.
+    return (double)n_rows * c->D * c->elem <= c->scan_plain_bytes ? 1 : 0;
 }
 
 int scan_grid_for(const Ctx *c, int64_t n_rows, int nq, bool q64)
@@ -738,7 +832,7 @@ int scan_grid_for(const Ctx *c, int64_t n_rows, int nq, bool q64)
     // the wave starts, query staging, the workgroups' tails).  A launch that takes only HALF of every CU's workgroup slots lets the
     // launches of consecutive ticks (alternating scan streams) be resident TOGETHER, so one tick streams while its neighbours ramp
     // up / finish; 8 waves x 12 KiB in flight per CU already saturate the memory system.
-    if (bpc > 1 && c->scan_short_bpc > 0 && c->scan_short_bpc < bpc && (double)n_rows * c->D * c->elem <= c->scan_plain_bytes)
+    if (bpc > 1 && c->scan_short_bpc > 0 && c->scan_short_bpc < bpc && (double)n_rows * c->D * c->elem <= c->scan_half_bytes)
         cap = (int64_t)c->n_cus * c->scan_short_bpc - c->scan_reserve;
     if (cap > c->max_grid) cap = c->max_grid;
     if (want > cap) want = cap;

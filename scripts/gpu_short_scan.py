@@ -20,7 +20,7 @@ import numpy as np  # noqa: E402
 import bench  # noqa: E402
 from cerebro_amd import capi  # noqa: E402
 
-KNOBS = ("CHIP_SCAN_ROWS", "CHIP_TICK_SAME_STREAM", "CHIP_SCAN_PLAIN_MIB", "CHIP_SCAN_VARIANT", "CHIP_SCAN_STREAMS", "CHIP_SCAN_ROWS_AUTO_MAX", "CHIP_SCAN_SHORT_BPC", "CHIP_SCAN_STREAMS3")
+KNOBS = ("CHIP_TICK_FUSED", "CHIP_SCAN_ROWS", "CHIP_TICK_SAME_STREAM", "CHIP_SCAN_PLAIN_MIB", "CHIP_SCAN_VARIANT", "CHIP_SCAN_STREAMS", "CHIP_SCAN_HALF_MIB", "CHIP_SCAN_SHORT_BPC", "CHIP_SCAN_STREAMS3")
 
 
 def run_config(rows, env, n_ticks, inflight):
