@@ -415,7 +415,8 @@ def main():
     n_ticks = args.warmup + args.steps
     # the 10k / 100k legs (N = 1) tick over shorter prefixes of the same DB: their planted query rows are DB rows of the
     # longer scans, so the longer plans keep their revisited rows out of those windows
-    leg_rows = [r for r in (10_000, 29_000, 100_000) if r + 4000 < args.rows]   # 29k = the reference's own capacity (Cerebro.cpp:946) if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 \
+    # (29k rows = the reference's own capacity, Cerebro.cpp:946)
+    leg_rows = [r for r in (10_000, 29_000, 100_000) if r + 4000 < args.rows] if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 \
         and not args.no_sizes and not args.force_sharded else []
     windows = [(r, r + LAG + 3 * 260 + 3) for r in leg_rows]
     ls, plants, expect = plan_ticks(args.rows, n_ticks, avoid=windows)
