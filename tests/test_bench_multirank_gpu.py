@@ -79,9 +79,14 @@ def test_bench_force_sharded_uses_in_library_rccl():
 
 def test_bench_sizes_key_and_f64_storage():
     j = _run_single(["--rows", "200000"])
-    assert set(j["sizes"]) == {"10k", "100k", "200k"}
+    assert set(j["sizes"]) == {"10k", "29k", "100k", "200k"}
     for k, leg in j["sizes"].items():
         assert leg["value"] > 0 and leg["roofline"]["achieved"] > 0 and leg["roofline"]["algorithmic_bytes_per_launch"] == 4.0 * 4096 * leg["db_rows"]
+        if k != "200k":     # the size legs are priced from their step time and say so
+            r = leg["roofline"]
+            assert r["kernel_overlap"] is True and abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (leg["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+            assert r["isolated_kernel_ms"] > 0
+    assert j["config"]["rccl_ranks"] == 0 and j["config"]["exchange_fallback"] is False
     assert j["sizes"]["10k"]["roofline"]["cache_resident"] and not j["sizes"]["100k"]["roofline"]["cache_resident"]
     assert j["roofline"]["traffic"] is None and j["ms_per_step_median"] > 0
     j64 = _run_single(["--rows", "60000", "--storage", "f64", "--no-sizes"])
