@@ -128,6 +128,33 @@ __device__ __forceinline__ double dpp_max_step(double v)
     const double o = __longlong_as_double(((long long)hi2 << 32) | (unsigned int)lo2);
     return o > v ? o : v;
 }
+// wave-wide max of a 32-bit unsigned value: six v_max_u32 with DPP source modifiers -- ONE instruction per step, issued from inline asm
+// (hipcc expands the update_dpp builtin + max into v_mov / s_nop / v_mov_dpp / v_max, three dependent instructions per step).  A lane
+// whose DPP source does not exist is not written (bound_ctrl off) and keeps its own value; the result is read from lane 63.
+__device__ __forceinline__ unsigned wave_umax(unsigned v)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+                 : "+v"(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// wave-wide max of a NON-NEGATIVE, non-NaN double: such doubles order like their bit patterns, so the max is found on the high
+// words first and on the low words of the lanes that attain it second -- 12 one-instruction DPP steps instead of 6 x (two DPP moves,
+// a 64-bit compare, two selects).  Same value as the 64-bit ladder below (kept for reference / A-B).
+__device__ __forceinline__ double wave_max_nonneg_2x32(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned hi = (unsigned)(b >> 32), lo = (unsigned)b;
+    const unsigned mhi = wave_umax(hi);
+    const unsigned mlo = wave_umax(hi == mhi ? lo : 0u);
+    return __longlong_as_double((long long)(((unsigned long long)mhi << 32) | mlo));
+}
+
 __device__ __forceinline__ double wave_max_nonneg(double v)
 {
     v = dpp_max_step<0x111, 0xf>(v);  // row_shr:1
@@ -174,13 +201,14 @@ struct SolveArgs {
     double *Tg;         // [H][27]   translation factor (t = Tfac * vec(R))
     int32_t *sample;    // [H][kSampleMax]
     int32_t *ok;        // [H] 1 = S valid, 0 = singular D
+    unsigned long long *stamps;   // tuning only (CHIP_PNP_STAMPS): [H][8] s_memtime at the phase boundaries of pnp_build_solve
 };
 
 constexpr int kSolveThreads = 448;   // waves 0..5 hold the Macaulay block (3 row groups x 128 columns), wave 6 factorises panels
 constexpr int kPanel = 4;   // pivot columns factorised per panel of the blocked LU
 // dynamic LDS of pnp_build_solve (must match the carve-up at the top of the kernel)
 constexpr size_t kSolveLds = sizeof(double) * (kSampleMax * 8 + 9 + 9 + 27 + 27 + 81 + 90 + 100 + 36 + 60 + 4 + 27 * 27 +
-                                               2 * 96 * kPanel * 2 + kPanel * 128 + 2 * kPanel * kPanel + 27 * kNC) +
+                                               2 * 96 * kPanel * 2 + 2 * kPanel * 128 + 2 * kPanel * kPanel + 27 * kNC) +
                              sizeof(int) * (16 + 4 + 2 * kPanel) + 64;
 
 __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
@@ -203,7 +231,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     double *Xb = sm;            sm += 27 * 27;                    // X[66+t][c]
     double *panel = sm;         sm += 2 * 96 * kPanel;            // [parity][physical row][c]: pivot columns of panels p, p+1
     double *Lp = sm;            sm += 2 * 96 * kPanel;            // [parity][physical row][c]: multipliers of a panel
-    double *prow_raw = sm;      sm += kPanel * 128;               // the panel's pivot rows as they were before the panel, [c][column]
+    double *prow_raw = sm;      sm += 2 * kPanel * 128;           // [parity][c][column]: a panel's pivot rows as they were before the panel
     double *Lsub = sm;          sm += 2 * kPanel * kPanel;        // [parity][c][c' < c]: multipliers among a panel's pivot rows
     double *Urows = sm;         sm += 27 * kNC;                   // pivot rows of steps 66..92 = rows of U needed by the back-substitution
     int *smp = reinterpret_cast<int *>(sm);                       // [16]
@@ -220,6 +248,8 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     const int n = a.S;
     const PnpTables &tb = *a.tab;
 
+#define SOLVE_STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(size_t)slot * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+    SOLVE_STAMP(0);
     // ---- sampler: partial Fisher-Yates over a virtual identity permutation (theia::RandomSampler restated) ----
     if (wave == 0) {
         const int sv = ransac_sample_wave(pr.seed, hyp, pr.N, n, lane);
@@ -284,6 +314,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     }
     __syncthreads();
     if (tid < 27) a.Tg[slot * 27 + tid] = Tf[tid];
+    SOLVE_STAMP(1);   // sampler, bearings, H, W, T done
     // ---- M9 = sum (L+T)^T (I - z z^T) (L+T) ----
     if (tid < 81) {
         const int j = tid / 9, k = tid % 9;
@@ -332,6 +363,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
         fc[tid] = (double)tb.fmul[k][mth] * c4[tb.fsrc[k][mth]];
     }
     __syncthreads();
+    SOLVE_STAMP(2);   // cost matrix -> cubics done
     // ---- Macaulay [D | C] (93 x 120) lives in REGISTERS of waves 0..5: thread (tx = column, ty = row group) holds rows
     //      ty, ty+3, ..., ty+90 of its column in er[0..30] (static slot indices); wave 6 never touches it. ----
     const int tx = tid & 127, ty = tid >> 7;          // ty == 3 <=> the factor wave
@@ -360,8 +392,10 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
         for (int sl = 0; sl < 31; sl++) er[sl] = 0.0;
     }
     if (tid == 0) flag[0] = 0;
+    if (tid < 2 * kPanel) prow_s[tid] = -1;   // "not decided yet" (polled by the matrix waves, see the LU loop)
     __syncthreads();
 
+    SOLVE_STAMP(3);   // Macaulay block filled
     // ---- Blocked right-looking LU with partial (row) pivoting, no physical swaps, with LOOKAHEAD: the panel of kPanel pivot
     //      columns is factorised by a wave of its own (wave 6, two physical rows per lane, registers / DPP / readlane only)
     //      while waves 0..5 apply the previous panel to the trailing matrix.  Per panel p:
@@ -406,7 +440,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
                 const double v0 = al0 ? fabs(A0(c)) : -1.0, v1 = al1 ? fabs(A1(c)) : -1.0;
                 double vm = v0 > 0.0 ? v0 : 0.0;                       // NaN never wins, as in the reference scan
                 if (v1 > vm) vm = v1;
-                const double best = wave_max_nonneg(vm);
+                const double best = wave_max_nonneg_2x32(vm);
                 const bool w0 = al0 && v0 == best, w1 = al1 && v1 == best;
                 const unsigned long long t0 = __ballot(w0), t1 = __ballot(w1);
                 int olane, plog;
@@ -427,6 +461,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
                 if (!(best > 0.0) || plog == 0x7fffffff) { sing = true; }
                 else {
                     pr_c[c] = olane + (ohalf ? 64 : 0);
+                    if (lane == 0) reinterpret_cast<volatile int *>(prow_s)[par * kPanel + c] = pr_c[c];   // the owners publish that row at once
                     double urow[kPanel];
 #pragma unroll
                     for (int c2 = 0; c2 < kPanel; c2++) {
@@ -441,9 +476,10 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
 #pragma unroll
                     for (int c2 = 0; c2 < kPanel; c2++)
                         if (c2 > c) {
-                            const double n0 = A0(c2) - m0 * urow[c2], n1 = A1(c2) - m1 * urow[c2];
-                            A0(c2) = (m0 != 0.0) ? n0 : A0(c2);      // the reference skips l == 0
-                            A1(c2) = (m1 != 0.0) ? n1 : A1(c2);
+                            // the reference skips l == 0; e - 0 * u == e for the finite u of a block that is not rejected anyway
+                            // (same argument as in P4), so no compare / select on the chain to the next pivot search
+                            A0(c2) = A0(c2) - m0 * urow[c2];
+                            A1(c2) = A1(c2) - m1 * urow[c2];
                         }
                     // the reference swaps logical rows kk and plog
                     lp0 = is0 ? kk : (lp0 == kk ? plog : lp0);
@@ -478,35 +514,67 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
 
     if (is_factor) { load_panel(0); factor_panel(0, kPanel, 0); }
     __syncthreads();
+    // tuning only (CHIP_PNP_STAMPS): per-phase shader-clock totals of the LU, wave 0 (a matrix wave) and wave 6 (the factor wave)
+    unsigned long long lu_t = 0, lu_acc[4] = {0, 0, 0, 0};
+    const bool lu_stamp = a.stamps != nullptr && lane == 0 && (wave == 0 || wave == 6);
+#define LU_STAMP(i) do { if (lu_stamp) { const unsigned long long t_ = __builtin_readcyclecounter(); lu_acc[i] += t_ - lu_t; lu_t = t_; } } while (0)
+    if (lu_stamp) lu_t = __builtin_readcyclecounter();
+    // P3 as a function: the owners of panel q's pivot rows publish them (as they are NOW: after the owner's P4 of panel q-1) into
+    // prow_raw[q & 1].  The pivot row indices are POLLED from LDS: the factor wave stores each one the moment it is decided, while the
+    // matrix waves -- done with their trailing update ~2 k cycles before the factor wave (shader-clock split) -- would otherwise idle
+    // at the barrier; so the publication of panel q runs underneath the factorisation of panel q instead of between two barriers
+    // on the critical path (it was 1.5-2.1 k of ~10 k cycles per panel, plus a barrier).
+    auto publish_pivot_rows = [&](int q) {
+        const int kq = q * kPanel, parq = q & 1;
+        const int bwq = (kNR - kq) < kPanel ? (kNR - kq) : kPanel;
+#pragma unroll
+        for (int c = 0; c < kPanel; c++) {
+            if (c < bwq) {
+                int prow = -1;
+                for (int spin = 0; spin < (1 << 22); spin++) {       // bounded: a wedged factor wave must not hang the GPU
+                    prow = reinterpret_cast<volatile int *>(prow_s)[parq * kPanel + c];
+                    if (prow >= 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (prow < 0) { flag[0] = 1; prow = 0; }
+                if (prow % 3 == ty) {
+                    const int ps = __builtin_amdgcn_readfirstlane(prow / 3);
+                    // er[ps] with a wave-uniform ps: a scalar switch (one jump, one register move) -- a run-time index would
+                    // send er[] to scratch, and the 30-deep select chain used before cost ~500 cycles per pivot row
+                    double u;
+                    switch (ps) {
+#define ER_CASE(n) case n: u = er[n]; break;
+                        ER_CASE(0) ER_CASE(1) ER_CASE(2) ER_CASE(3) ER_CASE(4) ER_CASE(5) ER_CASE(6) ER_CASE(7) ER_CASE(8) ER_CASE(9)
+                        ER_CASE(10) ER_CASE(11) ER_CASE(12) ER_CASE(13) ER_CASE(14) ER_CASE(15) ER_CASE(16) ER_CASE(17) ER_CASE(18)
+                        ER_CASE(19) ER_CASE(20) ER_CASE(21) ER_CASE(22) ER_CASE(23) ER_CASE(24) ER_CASE(25) ER_CASE(26) ER_CASE(27)
+                        ER_CASE(28) ER_CASE(29)
+#undef ER_CASE
+                        default: u = er[30]; break;
+                    }
+                    prow_raw[(parq * kPanel + c) * 128 + tx] = u;
+                    live &= ~(1u << ps);
+                }
+            }
+        }
+    };
+    if (!is_factor) publish_pivot_rows(0);
+    __syncthreads();
     for (int p = 0; p < kPanels; p++) {
         const int k = p * kPanel, par = p & 1;
         const int bw = (kNR - k) < kPanel ? (kNR - k) : kPanel;
         if (flag[0]) { singular = true; break; }
-        // -- P3: owners of the pivot rows publish them (dynamic slot -> static select chain; wave-uniform branches)
-        if (!is_factor) {
-#pragma unroll
-            for (int c = 0; c < kPanel; c++) {
-                if (c < bw) {
-                    const int prow = prow_s[par * kPanel + c];
-                    if (prow % 3 == ty) {
-                        const int ps = prow / 3;
-                        double u = er[0];
-#pragma unroll
-                        for (int sl = 1; sl < 31; sl++) u = (ps == sl) ? er[sl] : u;
-                        prow_raw[c * 128 + tx] = u;
-                        live &= ~(1u << ps);
-                    }
-                }
-            }
-        }
-        __syncthreads();
+        // panel p's pivot row indices were consumed before the barrier above: mark the slots "undecided" for panel p + 2 (the factor
+        // wave fills prow_s[par ^ 1] in this iteration and prow_s[par] in the next one, behind the barrier that ends this one)
+        if (is_factor && lane < kPanel) prow_s[par * kPanel + lane] = -1;
+        LU_STAMP(0);
+        LU_STAMP(1);
         if (!is_factor) {
             // -- P4
             const double *Lss = Lsub + par * kPanel * kPanel;
             double u[kPanel];
 #pragma unroll
             for (int c = 0; c < kPanel; c++) {
-                double v = prow_raw[c * 128 + tx];
+                double v = prow_raw[(par * kPanel + c) * 128 + tx];
 #pragma unroll
                 for (int c2 = 0; c2 < kPanel; c2++)
                     if (c2 < c) {
@@ -517,6 +585,16 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
                 u[c] = v;
                 if (ty == 0 && tx < kNC && c < bw && k + c >= 66) Urows[(k + c - 66) * kNC + tx] = v;
             }
+            // The reference's elimination step is  if (l != 0) e -= l * u  on the columns right of the pivot.  The per-element form
+            // of that (a compare and a 64-bit select per row and pivot: 3 of 5 VALU instructions) made P4 the LU's bottleneck -- 620
+            // fp64 VALU instructions per wave and panel, 3.5 waves per SIMD = ~9 k cycles against the ~4-7 k of the factor wave's
+            // chain (shader-clock split, profiles/r03_pnp_pmc.md: LU = 82 % of pnp_build_solve).  Equivalent form: the column
+            // predicate is per THREAD, so it is folded into the pivot-row value once (uz = 0 left of the pivot: e - l*0 == e), and
+            // l == 0 needs no test either (e - 0*u == e for finite u; a non-finite u only occurs in a block that is singular /
+            // overflowed, whose hypothesis is rejected in both implementations).  2 instructions per row and pivot.
+            double uz[kPanel];
+#pragma unroll
+            for (int c = 0; c < kPanel; c++) uz[c] = (c < bw && tx > k + c) ? u[c] : 0.0;
             const double *Lpp = Lp + par * 96 * kPanel;
 #pragma unroll
             for (int sl = 0; sl < 31; sl++) {
@@ -524,11 +602,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
                     const double *lq = Lpp + (ty + 3 * sl) * kPanel;
                     double e = er[sl];
 #pragma unroll
-                    for (int c = 0; c < kPanel; c++) {
-                        const double l = lq[c];
-                        const double nv = e - l * u[c];
-                        e = (c < bw && l != 0.0 && tx > k + c) ? nv : e;
-                    }
+                    for (int c = 0; c < kPanel; c++) e = e - lq[c] * uz[c];
                     er[sl] = e;
                 }
             }
@@ -538,6 +612,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
 #pragma unroll
                 for (int sl = 0; sl < 31; sl++) dst[(ty + 3 * sl) * kPanel] = er[sl];
             }
+            if (p + 1 < kPanels) publish_pivot_rows(p + 1);   // underneath the factor wave's work on that very panel
         } else if (p + 1 < kPanels) {
             // -- F: panel p+1 (dumped before panel p was applied) -> apply panel p -> factorise
             const int kn = k + kPanel;
@@ -549,7 +624,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
                 double un[kPanel];
 #pragma unroll
                 for (int c = 0; c < kPanel; c++) {
-                    double v = prow_raw[c * 128 + kn + c2];
+                    double v = prow_raw[(par * kPanel + c) * 128 + kn + c2];
 #pragma unroll
                     for (int c3 = 0; c3 < kPanel; c3++)
                         if (c3 < c) {
@@ -562,9 +637,9 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
                 double e1 = has1 ? pp[(lane + 64) * kPanel + c2] : 0.0;
 #pragma unroll
                 for (int c = 0; c < kPanel; c++) {
-                    const double n0 = e0 - L0(c) * un[c], n1 = e1 - L1(c) * un[c];
-                    e0 = (c < bw && L0(c) != 0.0) ? n0 : e0;
-                    e1 = (c < bw && L1(c) != 0.0) ? n1 : e1;
+                    const double uc = c < bw ? un[c] : 0.0;
+                    e0 = e0 - L0(c) * uc;
+                    e1 = e1 - L1(c) * uc;
                 }
                 B0(c2) = e0; B1(c2) = e1;
             }
@@ -572,12 +647,20 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
             for (int c2 = 0; c2 < kPanel; c2++) { A0(c2) = B0(c2); A1(c2) = B1(c2); }
             factor_panel(kn, bwn, par ^ 1);
         }
+        LU_STAMP(2);          // P4 (matrix waves) / F (factor wave)
         __syncthreads();
+        LU_STAMP(3);          // wait at the barrier behind P4 / F
     }
+    if (lu_stamp) {
+        unsigned long long *o = a.stamps + (size_t)slot * 16 + (wave == 0 ? 8 : 12);
+        o[0] = lu_acc[0]; o[1] = lu_acc[1]; o[2] = lu_acc[2]; o[3] = lu_acc[3];
+    }
+#undef LU_STAMP
     if (singular) {
         if (tid == 0) a.ok[slot] = 0;
         return;
     }
+    SOLVE_STAMP(4);   // LU done
     // ---- back-substitution: only the last 27 unknowns (boundary monomials) are referenced by B; Urows[i-66] = row i of U ----
     if (tid < 27) {
         const int c = tid;
@@ -589,6 +672,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
         }
     }
     __syncthreads();
+    SOLVE_STAMP(5);   // back-substitution done
     // ---- S = A - B X ----
     for (int e = tid; e < 729; e += kSolveThreads) {
         const int r = e / 27, j = e % 27;
@@ -602,6 +686,8 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
         a.Sg[(size_t)slot * 729 + e] = s;
     }
     if (tid == 0) a.ok[slot] = 1;
+    SOLVE_STAMP(6);
+#undef SOLVE_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------ K5b + K6
@@ -1185,7 +1271,7 @@ struct PnpState {
     double *cost = nullptr, *T_out = nullptr;            // device views of the same allocations
     int32_t *nin = nullptr, *valid = nullptr, *nsol = nullptr;
     unsigned long long *mask = nullptr;
-    unsigned long long *stamps = nullptr;                // tuning only (CHIP_PNP_STAMPS)
+    unsigned long long *stamps = nullptr;                // tuning only (CHIP_PNP_STAMPS): [H][8] of pnp_eig_score, then [H][8] of pnp_build_solve
     int32_t stamps_n = 0;
 };
 
@@ -1293,6 +1379,17 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
     sa.H = H; sa.S = S; sa.tab = st->tab_dev;
     sa.Sg = st->Sg; sa.Tg = st->Tg; sa.sample = st->sample; sa.ok = st->ok;
     const size_t lds = kSolveLds;
+    static const bool want_stamps = std::getenv("CHIP_PNP_STAMPS") != nullptr;
+    if (want_stamps) {
+        if (st->stamps_n < P * H) {
+            (void)hipFree(st->stamps);
+            st->stamps = nullptr; st->stamps_n = 0;
+            CHIP_HIP(c, hipMalloc(&st->stamps, sizeof(unsigned long long) * 24 * (size_t)P * H));
+            st->stamps_n = P * H;
+        }
+        CHIP_HIP(c, hipMemsetAsync(st->stamps, 0, sizeof(unsigned long long) * 24 * (size_t)st->stamps_n, s));
+        sa.stamps = st->stamps + 8 * (size_t)st->stamps_n;
+    }
     hipLaunchKernelGGL(pnp_build_solve, dim3(P * H), dim3(kSolveThreads), lds, s, sa);
     CHIP_HIP(c, hipGetLastError());
 
@@ -1300,15 +1397,7 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
     ea.Sg = st->Sg; ea.Tg = st->Tg; ea.sample = st->sample; ea.ok = st->ok; ea.mask_words = words;
     { const char *dv = std::getenv("CHIP_PNP_DEBUG_STOP"); ea.debug_stop = dv ? std::atoi(dv) : 0; }
     ea.T_out = st->T_out; ea.cost = st->cost; ea.nin = st->nin; ea.valid = st->valid; ea.nsol = st->nsol; ea.mask = st->mask;
-    static const bool want_stamps = std::getenv("CHIP_PNP_STAMPS") != nullptr;
     if (want_stamps) {
-        if (st->stamps_n < P * H) {
-            (void)hipFree(st->stamps);
-            st->stamps = nullptr; st->stamps_n = 0;
-            CHIP_HIP(c, hipMalloc(&st->stamps, sizeof(unsigned long long) * 8 * (size_t)P * H));
-            st->stamps_n = P * H;
-        }
-        CHIP_HIP(c, hipMemsetAsync(st->stamps, 0, sizeof(unsigned long long) * 8 * (size_t)P * H, s));
         ea.stamps = st->stamps;
         hipLaunchKernelGGL(pnp_eig_score<true>, dim3(P * H), dim3(64), 0, s, ea);
     } else {
@@ -1369,6 +1458,19 @@ extern "C" int chip_debug_pnp_stamps(chip_ctx *c, unsigned long long *out, int32
     CHIP_HIP(c, hipSetDevice(c->device));
     CHIP_HIP(c, hipStreamSynchronize(c->s_pnp));
     CHIP_HIP(c, hipMemcpy(out, st->stamps, sizeof(unsigned long long) * 8 * (size_t)n_hyp, hipMemcpyDeviceToHost));
+    return CHIP_OK;
+}
+
+extern "C" int chip_debug_pnp_solve_stamps(chip_ctx *c, unsigned long long *out, int32_t n_hyp)
+{
+    if (!c || !out) return CHIP_ERR_INVALID_ARG;
+    if (c->group) c = static_cast<chip_ctx *>(chip::group_root(c));
+    std::lock_guard<std::mutex> lk(c->pnp_mu);
+    PnpState *st = static_cast<PnpState *>(c->pnp_state);
+    if (!st || !st->stamps || n_hyp > st->stamps_n) return CHIP_ERR_INVALID_ARG;
+    CHIP_HIP(c, hipSetDevice(c->device));
+    CHIP_HIP(c, hipStreamSynchronize(c->s_pnp));
+    CHIP_HIP(c, hipMemcpy(out, st->stamps + 8 * (size_t)st->stamps_n, sizeof(unsigned long long) * 16 * (size_t)n_hyp, hipMemcpyDeviceToHost));
     return CHIP_OK;
 }
 

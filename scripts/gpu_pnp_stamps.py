@@ -46,3 +46,27 @@ slow = int(np.argmax(t[:, 7]))
 print(f"kernel = slowest wave: {t[slow, 7]:.0f} cycles ({steps[slow]:.0f} steps, {sweeps[slow]:.0f} sweeps): Hessenberg {t[slow, 6]:.0f}, QR {tot[slow]:.0f} "
       f"= reflector {t[slow, 1]:.0f} + row {t[slow, 2]:.0f} + column {t[slow, 3]:.0f} + sweep overhead {t[slow, 0]:.0f}")
 print(f"mean wave: {t[:, 7].mean():.0f} cycles, Hessenberg {t[:, 6].mean():.0f}, QR {tot.mean():.0f}; cycles per step (all QR cycles / steps): {(tot / steps).mean():.0f}")
+
+# ---- pnp_build_solve: s_memtime at the phase boundaries (thread 0 of every workgroup)
+with capi.Chip(64) as chip:
+    p = capi.default_ransac_params(); p.n_hypotheses = H; p.seed = 4242
+    for _ in range(3):
+        chip.pnp_ransac(X, uv, p)
+    fn = chip.lib.chip_debug_pnp_solve_stamps
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    buf = np.zeros((H, 16), dtype=np.uint64)
+    assert fn(chip.h, buf.ctypes.data, H) == 0
+t = buf.astype(np.float64)
+t = t[t[:, 6] > 0]
+names = ["sampler, bearings, H, W, T", "cost matrix M9 -> G -> quartic -> cubics", "Macaulay fill (registers)", "blocked LU (24 panels)",
+         "back-substitution (27 unknowns x 27 RHS)", "S = A - B X, stores"]
+tot = t[:, 6] - t[:, 0]
+print(f"pnp_build_solve, {len(t)} workgroups: {tot.mean():.0f} cycles per workgroup (max {tot.max():.0f})")
+for i, nme in enumerate(names):
+    d = t[:, i + 1] - t[:, i]
+    print(f"  {nme:44s}: {d.mean():9.0f} cycles ({100 * d.mean() / tot.mean():5.1f} %)")
+
+print("  LU per phase, cycles per workgroup (sum over the 24 panels):")
+print(f"    matrix wave 0: P3 (publish pivot rows) {t[:, 8].mean():8.0f}  barrier {t[:, 9].mean():8.0f}  P4 (trailing update) {t[:, 10].mean():8.0f}  barrier {t[:, 11].mean():8.0f}")
+print(f"    factor wave 6: (idle in P3)            {t[:, 12].mean():8.0f}  barrier {t[:, 13].mean():8.0f}  F  (update + factor)   {t[:, 14].mean():8.0f}  barrier {t[:, 15].mean():8.0f}")
