@@ -196,6 +196,7 @@ constexpr int kPnpMaxBatch = 8;
 struct SolveArgs {
     PnpProblem prob[kPnpMaxBatch];
     int32_t H, S;
+    int32_t slot0, pad2_;   // first slot of this launch (a batch may be issued as several launch pairs)
     const PnpTables *tab;
     double *Sg;         // [H][729]  action matrices
     double *Tg;         // [H][27]   translation factor (t = Tfac * vec(R))
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int slot = blockIdx.x;
+    const int slot = blockIdx.x + a.slot0;
     const int pi = slot / a.H;
     const int hyp = slot - pi * a.H;                               // hypothesis index within its problem (keys the RNG)
     const PnpProblem pr = a.prob[pi];
@@ -716,6 +717,7 @@ __device__ __forceinline__ double sqrt_normal_range(double t)
 struct EigArgs {
     PnpProblem prob[kPnpMaxBatch];
     int32_t H, S;
+    int32_t slot0, pad2_;
     double thresh;
     int32_t use_mle;
     const double *Sg;       // [H][729]
@@ -770,7 +772,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     __shared__ double Hs[EN * EN], Vs[EN * EN];
     __shared__ double ortm[EN], wr[EN], wi[EN], Tf[27], sxs[kSampleMax * 3], model[16];
     const int lane = threadIdx.x;
-    const int hyp = blockIdx.x;                                    // slot: hypothesis (hyp % H) of problem (hyp / H)
+    const int hyp = blockIdx.x + a.slot0;                          // slot: hypothesis (hyp % H) of problem (hyp / H)
     const PnpProblem pr = a.prob[hyp / a.H];
     const int low = 0, high = EN - 1, nn = EN;
     const double eps = DBL_EPSILON;
@@ -1271,7 +1273,9 @@ struct PnpState {
     double *cost = nullptr, *T_out = nullptr;            // device views of the same allocations
     int32_t *nin = nullptr, *valid = nullptr, *nsol = nullptr;
     unsigned long long *mask = nullptr;
-    unsigned long long *stamps = nullptr;                // tuning only (CHIP_PNP_STAMPS): [H][8] of pnp_eig_score, then [H][8] of pnp_build_solve
+    unsigned long long *stamps = nullptr;                // tuning only (CHIP_PNP_STAMPS): [H][8] of pnp_eig_score, then [H][16] of pnp_build_solve
+    hipStream_t s2 = nullptr;                            // second launch-pair stream of a split batch (CHIP_PNP_GROUPS)
+    hipEvent_t ev_in = nullptr, ev_g2 = nullptr;
     int32_t stamps_n = 0;
 };
 
@@ -1297,6 +1301,9 @@ static void pnp_free_dev(PnpState *st)
     (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid);
     (void)hipHostFree(st->h_nsol); (void)hipHostFree(st->h_mask);
     (void)hipFree(st->stamps);
+    if (st->s2) (void)hipStreamDestroy(st->s2);
+    if (st->ev_in) (void)hipEventDestroy(st->ev_in);
+    if (st->ev_g2) (void)hipEventDestroy(st->ev_g2);
 }
 
 void pnp_destroy(Ctx *c)
@@ -1390,21 +1397,35 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
         CHIP_HIP(c, hipMemsetAsync(st->stamps, 0, sizeof(unsigned long long) * 24 * (size_t)st->stamps_n, s));
         sa.stamps = st->stamps + 8 * (size_t)st->stamps_n;
     }
-    hipLaunchKernelGGL(pnp_build_solve, dim3(P * H), dim3(kSolveThreads), lds, s, sa);
-    CHIP_HIP(c, hipGetLastError());
-
     ea.H = H; ea.S = S; ea.thresh = p->error_thresh; ea.use_mle = p->use_mle;
     ea.Sg = st->Sg; ea.Tg = st->Tg; ea.sample = st->sample; ea.ok = st->ok; ea.mask_words = words;
     { const char *dv = std::getenv("CHIP_PNP_DEBUG_STOP"); ea.debug_stop = dv ? std::atoi(dv) : 0; }
     ea.T_out = st->T_out; ea.cost = st->cost; ea.nin = st->nin; ea.valid = st->valid; ea.nsol = st->nsol; ea.mask = st->mask;
-    if (want_stamps) {
-        ea.stamps = st->stamps;
-        hipLaunchKernelGGL(pnp_eig_score<true>, dim3(P * H), dim3(64), 0, s, ea);
-    } else {
-        hipLaunchKernelGGL(pnp_eig_score<false>, dim3(P * H), dim3(64), 0, s, ea);
+    if (want_stamps) ea.stamps = st->stamps;
+    // A batch of several problems may go out as `groups` launch pairs on as many streams (CHIP_PNP_GROUPS, tuning): both kernels are
+    // latency chains that leave issue slots free, so build(group g+1) can run underneath eig(group g).
+    static const int want_groups = [] { const char *e = std::getenv("CHIP_PNP_GROUPS"); return e ? std::atoi(e) : 1; }();
+    int groups = want_groups < 1 ? 1 : (want_groups > 2 ? 2 : want_groups);
+    if (groups > P) groups = P;
+    if (groups > 1 && !st->s2) {
+        CHIP_HIP(c, hipStreamCreateWithFlags(&st->s2, hipStreamNonBlocking));
+        CHIP_HIP(c, hipEventCreateWithFlags(&st->ev_in, hipEventDisableTiming));
+        CHIP_HIP(c, hipEventCreateWithFlags(&st->ev_g2, hipEventDisableTiming));
     }
-    CHIP_HIP(c, hipGetLastError());
-
+    if (groups > 1) CHIP_HIP(c, hipEventRecord(st->ev_in, s));   // inputs (and the stamp memset) are on the device
+    for (int g = 0; g < groups; g++) {
+        const int p0 = (int)((long long)P * g / groups), p1 = (int)((long long)P * (g + 1) / groups);
+        hipStream_t sg = g == 0 ? s : st->s2;
+        if (g > 0) CHIP_HIP(c, hipStreamWaitEvent(sg, st->ev_in, 0));
+        sa.slot0 = ea.slot0 = p0 * H;
+        const int nslots = (p1 - p0) * H;
+        hipLaunchKernelGGL(pnp_build_solve, dim3(nslots), dim3(kSolveThreads), lds, sg, sa);
+        CHIP_HIP(c, hipGetLastError());
+        if (want_stamps) hipLaunchKernelGGL(pnp_eig_score<true>, dim3(nslots), dim3(64), 0, sg, ea);
+        else hipLaunchKernelGGL(pnp_eig_score<false>, dim3(nslots), dim3(64), 0, sg, ea);
+        CHIP_HIP(c, hipGetLastError());
+        if (g > 0) { CHIP_HIP(c, hipEventRecord(st->ev_g2, sg)); CHIP_HIP(c, hipStreamWaitEvent(s, st->ev_g2, 0)); }
+    }
     CHIP_HIP(c, hipStreamSynchronize(s));   // every per-hypothesis result is in host memory now
 
     // K7: theia::Ransac::Estimate's sequential rule replayed over the per-hypothesis results
