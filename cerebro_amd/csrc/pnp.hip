@@ -196,7 +196,8 @@ constexpr int kPnpMaxBatch = 8;
 struct SolveArgs {
     PnpProblem prob[kPnpMaxBatch];
     int32_t H, S;
-    int32_t slot0, pad2_;   // first slot of this launch (a batch may be issued as several launch pairs)
+    int32_t slot0;          // first slot of this launch (a batch may be issued as several launch pairs)
+    int32_t factor_prio;    // > 0: the LU's factor wave runs at raised issue priority (s_setprio)
     const PnpTables *tab;
     double *Sg;         // [H][729]  action matrices
     double *Tg;         // [H][27]   translation factor (t = Tfac * vec(R))
@@ -212,7 +213,8 @@ constexpr size_t kSolveLds = sizeof(double) * (kSampleMax * 8 + 9 + 9 + 27 + 27 
                                                2 * 96 * kPanel * 2 + 2 * kPanel * 128 + 2 * kPanel * kPanel + 27 * kNC) +
                              sizeof(int) * (16 + 4 + 2 * kPanel) + 64;
 
-__global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
+// two workgroups per CU (7 waves each, 4 SIMDs): at most 128 VGPRs -- asked for explicitly, the budget is not left to chance
+__global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void pnp_build_solve(SolveArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *sm = reinterpret_cast<double *>(smem);
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     const int n = a.S;
     const PnpTables &tb = *a.tab;
 
-#define SOLVE_STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(size_t)slot * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define SOLVE_STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(size_t)slot * 24 + (i)] = __builtin_readcyclecounter(); } while (0)
     SOLVE_STAMP(0);
     // ---- sampler: partial Fisher-Yates over a virtual identity permutation (theia::RandomSampler restated) ----
     if (wave == 0) {
@@ -426,54 +428,94 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     int lp0 = lane, lp1 = lane + 64;   // logical position of physical rows lane, lane + 64
     const bool has1 = lane + 64 < kNR;
 
+    // tuning only (CHIP_PNP_STAMPS): sub-phase shader-clock totals of the factor wave
+    // (compiled in with -DCHIP_PNP_FSTAMPS only: eight 64-bit accumulators push the kernel past 128 VGPRs = one workgroup per CU,
+    // and every stamp costs ~60 cycles on the chain it measures)
+#ifdef CHIP_PNP_FSTAMPS
+    unsigned long long f_t = 0, f_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool f_stamp = a.stamps != nullptr && wave == 6;
+#define F_STAMP(i) do { if (f_stamp) { const unsigned long long t_ = __builtin_readcyclecounter(); f_acc[i] += t_ - f_t; f_t = t_; } } while (0)
+#else
+#define F_STAMP(i) do { } while (0)
+#endif
     // factorise the panel held in a0/a1 (columns k .. k+bw-1), publish into parity set `par`
     auto factor_panel = [&](int k, int bw, int par) {
+        F_STAMP(0);   // whatever preceded (the update of the panel by the previous one)
         int pr_c[kPanel];
         bool sing = false;
 #pragma unroll
         for (int c = 0; c < kPanel; c++) { L0(c) = 0.0; L1(c) = 0.0; }
-#pragma unroll
-        for (int c = 0; c < kPanel; c++) {
+        // one pivot column.  The column index is a compile-time constant (generic lambda over integral_constant), so that every
+        // A0(c) / LS(c, c2) / urow[c2] below is a fixed register whatever the unroller decides.
+        auto factor_column = [&](auto c_tag) {
+            constexpr int c = decltype(c_tag)::value;
             pr_c[c] = 0;
             if (c < bw && !sing) {
                 const int kk = k + c;
                 const bool al0 = lp0 >= kk, al1 = has1 && lp1 >= kk;   // pivots sit at logical positions < kk
                 const double v0 = al0 ? fabs(A0(c)) : -1.0, v1 = al1 ? fabs(A1(c)) : -1.0;
                 double vm = v0 > 0.0 ? v0 : 0.0;                       // NaN never wins, as in the reference scan
-                if (v1 > vm) vm = v1;
-                const double best = wave_max_nonneg_2x32(vm);
-                const bool w0 = al0 && v0 == best, w1 = al1 && v1 == best;
-                const unsigned long long t0 = __ballot(w0), t1 = __ballot(w1);
+                const bool up = v1 > vm;                               // the lane's larger candidate is its row lane + 64
+                if (up) vm = v1;
+                // Non-negative doubles order like their bit patterns: the HIGH words decide unless two candidates agree in sign,
+                // exponent and 20 mantissa bits.  Usual case: one lane attains the max high word (and its two rows differ) -> that
+                // row is the pivot; no second reduction over the low words, no 64-bit compares.  Everything else (ties on the high
+                // word, exact ties, an all-zero / denormal column) takes the full path below.  Same pivot either way.
+                const unsigned long long vb = (unsigned long long)__double_as_longlong(vm);
+                const unsigned vhi = (unsigned)(vb >> 32);
+                const unsigned mhi = wave_umax(vhi);
+                const unsigned long long cand = __builtin_amdgcn_ballot_w64(vhi == mhi);
+                const unsigned long long upm = __builtin_amdgcn_ballot_w64(up), eqm = __builtin_amdgcn_ballot_w64(al0 && al1 && v0 == v1);
+                F_STAMP(1);   // candidates + wave max
                 int olane, plog;
                 bool ohalf;
-                if (__popcll(t0) + __popcll(t1) == 1) {               // the usual case: one row attains the max
-                    ohalf = t0 == 0ull;
-                    olane = __builtin_ctzll(ohalf ? t1 : t0);
+                double best;
+                const int cl = __builtin_ctzll(cand);                  // cand != 0: the lane holding mhi is in it
+                if (__popcll(cand) == 1 && mhi != 0u && !((eqm >> cl) & 1ull)) {
+                    olane = cl;
+                    ohalf = (upm >> cl) & 1ull;
                     plog = __builtin_amdgcn_readlane(ohalf ? lp1 : lp0, olane);
-                } else {                                               // exact ties: smallest logical index among them
-                    plog = w0 ? lp0 : 0x7fffffff;
-                    if (w1 && lp1 < plog) plog = lp1;
+                    best = 1.0;                                        // only its sign is looked at below
+                } else {
+                    const unsigned mlo = wave_umax(vhi == mhi ? (unsigned)vb : 0u);
+                    best = __longlong_as_double((long long)(((unsigned long long)mhi << 32) | mlo));
+                    const bool w0 = al0 && v0 == best, w1 = al1 && v1 == best;
+                    const unsigned long long t0 = __builtin_amdgcn_ballot_w64(w0), t1 = __builtin_amdgcn_ballot_w64(w1);
+                    if (__popcll(t0) + __popcll(t1) == 1) {           // one row attains the max
+                        ohalf = t0 == 0ull;
+                        olane = __builtin_ctzll(ohalf ? t1 : t0);
+                        plog = __builtin_amdgcn_readlane(ohalf ? lp1 : lp0, olane);
+                    } else {                                           // exact ties: smallest logical index among them
+                        plog = w0 ? lp0 : 0x7fffffff;
+                        if (w1 && lp1 < plog) plog = lp1;
 #pragma unroll
-                    for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(plog, m, 64); plog = o < plog ? o : plog; }
-                    const unsigned long long o0 = __ballot(al0 && lp0 == plog), o1 = __ballot(al1 && lp1 == plog);
-                    ohalf = o0 == 0ull;
-                    olane = __builtin_ctzll(ohalf ? (o1 ? o1 : 1ull) : o0);
+                        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(plog, m, 64); plog = o < plog ? o : plog; }
+                        const unsigned long long o0 = __builtin_amdgcn_ballot_w64(al0 && lp0 == plog), o1 = __builtin_amdgcn_ballot_w64(al1 && lp1 == plog);
+                        ohalf = o0 == 0ull;
+                        olane = __builtin_ctzll(ohalf ? (o1 ? o1 : 1ull) : o0);
+                    }
                 }
+                F_STAMP(2);   // who attains it: compares, ballots, logical position
                 if (!(best > 0.0) || plog == 0x7fffffff) { sing = true; }
                 else {
                     pr_c[c] = olane + (ohalf ? 64 : 0);
-                    if (lane == 0) reinterpret_cast<volatile int *>(prow_s)[par * kPanel + c] = pr_c[c];   // the owners publish that row at once
+                    // the owners publish that row at once.  A relaxed workgroup-scope atomic, NOT a volatile store: the volatile form
+                    // compiled to flat_store_dword + s_waitcnt vmcnt(0) (address-space inference skips volatile accesses), a
+                    // several-hundred-cycle stall on the critical chain of every column; this is one ds_write_b32, no wait
+                    if (lane == 0) __hip_atomic_store(&prow_s[par * kPanel + c], pr_c[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     double urow[kPanel];
 #pragma unroll
                     for (int c2 = 0; c2 < kPanel; c2++) {
                         urow[c2] = lane_value_f64(ohalf ? A1(c2) : A0(c2), olane);
                         if (c2 < c) LS(c, c2) = lane_value_f64(ohalf ? L1(c2) : L0(c2), olane);
                     }
+                    F_STAMP(3);   // pivot row entries / earlier multipliers by readlane
                     const double piv = urow[c];
                     const bool is0 = !ohalf && lane == olane, is1 = ohalf && lane == olane;
                     const double m0 = (al0 && !is0) ? A0(c) / piv : 0.0;
                     const double m1 = (al1 && !is1) ? A1(c) / piv : 0.0;
                     L0(c) = m0; L1(c) = m1;
+                    F_STAMP(4);   // the two IEEE divisions
 #pragma unroll
                     for (int c2 = 0; c2 < kPanel; c2++)
                         if (c2 > c) {
@@ -485,9 +527,15 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
                     // the reference swaps logical rows kk and plog
                     lp0 = is0 ? kk : (lp0 == kk ? plog : lp0);
                     lp1 = is1 ? kk : (lp1 == kk ? plog : lp1);
+                    F_STAMP(5);   // panel update + logical positions
                 }
             }
-        }
+        };
+        static_assert(kPanel == 4, "factor_panel names its four columns");
+        factor_column(std::integral_constant<int, 0>{});
+        factor_column(std::integral_constant<int, 1>{});
+        factor_column(std::integral_constant<int, 2>{});
+        factor_column(std::integral_constant<int, 3>{});
         double *Lpp = Lp + par * 96 * kPanel;
 #pragma unroll
         for (int c = 0; c < kPanel; c++) {
@@ -503,6 +551,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
                 for (int c2 = 0; c2 < kPanel; c2++) Lsub[par * kPanel * kPanel + c * kPanel + c2] = (c2 < c && c < bw) ? LS(c, c2) : 0.0;
             }
         }
+        F_STAMP(6);   // publication of multipliers / pivot rows / sub-multipliers
     };
     auto load_panel = [&](int par) {
         const double *pp = panel + par * 96 * kPanel;
@@ -513,6 +562,10 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
         }
     };
 
+    // The factor wave's chain is the LU's critical path and it shares its SIMD with matrix waves streaming fp64 FMAs: at equal
+    // priority it gets one issue slot in ~4 (shader-clock split: ~20 cycles per dependent instruction).  Raised priority lets the
+    // arbiter pick it whenever it is ready; the matrix waves fill the slots its latencies leave.  CHIP_PNP_PRIO (tuning knob).
+    if (is_factor && a.factor_prio > 0) __builtin_amdgcn_s_setprio(3);
     if (is_factor) { load_panel(0); factor_panel(0, kPanel, 0); }
     __syncthreads();
     // tuning only (CHIP_PNP_STAMPS): per-phase shader-clock totals of the LU, wave 0 (a matrix wave) and wave 6 (the factor wave)
@@ -520,6 +573,9 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
     const bool lu_stamp = a.stamps != nullptr && lane == 0 && (wave == 0 || wave == 6);
 #define LU_STAMP(i) do { if (lu_stamp) { const unsigned long long t_ = __builtin_readcyclecounter(); lu_acc[i] += t_ - lu_t; lu_t = t_; } } while (0)
     if (lu_stamp) lu_t = __builtin_readcyclecounter();
+#ifdef CHIP_PNP_FSTAMPS
+    if (f_stamp) f_t = __builtin_readcyclecounter();
+#endif
     // P3 as a function: the owners of panel q's pivot rows publish them (as they are NOW: after the owner's P4 of panel q-1) into
     // prow_raw[q & 1].  The pivot row indices are POLLED from LDS: the factor wave stores each one the moment it is decided, while the
     // matrix waves -- done with their trailing update ~2 k cycles before the factor wave (shader-clock split) -- would otherwise idle
@@ -533,7 +589,7 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
             if (c < bwq) {
                 int prow = -1;
                 for (int spin = 0; spin < (1 << 22); spin++) {       // bounded: a wedged factor wave must not hang the GPU
-                    prow = reinterpret_cast<volatile int *>(prow_s)[parq * kPanel + c];
+                    prow = __hip_atomic_load(&prow_s[parq * kPanel + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_read_b32
                     if (prow >= 0) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -572,18 +628,15 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
         if (!is_factor) {
             // -- P4
             const double *Lss = Lsub + par * kPanel * kPanel;
-            double u[kPanel];
+            double u[kPanel], uz[kPanel];
 #pragma unroll
             for (int c = 0; c < kPanel; c++) {
                 double v = prow_raw[(par * kPanel + c) * 128 + tx];
 #pragma unroll
                 for (int c2 = 0; c2 < kPanel; c2++)
-                    if (c2 < c) {
-                        const double l = Lss[c * kPanel + c2];
-                        const double nv = v - l * u[c2];
-                        v = (l != 0.0 && tx > k + c2) ? nv : v;
-                    }
+                    if (c2 < c) v = v - Lss[c * kPanel + c2] * uz[c2];   // select-free, as the row updates below (uz, see there)
                 u[c] = v;
+                uz[c] = (c < bw && tx > k + c) ? v : 0.0;
                 if (ty == 0 && tx < kNC && c < bw && k + c >= 66) Urows[(k + c - 66) * kNC + tx] = v;
             }
             // The reference's elimination step is  if (l != 0) e -= l * u  on the columns right of the pivot.  The per-element form
@@ -593,13 +646,15 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
             // predicate is per THREAD, so it is folded into the pivot-row value once (uz = 0 left of the pivot: e - l*0 == e), and
             // l == 0 needs no test either (e - 0*u == e for finite u; a non-finite u only occurs in a block that is singular /
             // overflowed, whose hypothesis is rejected in both implementations).  2 instructions per row and pivot.
-            double uz[kPanel];
-#pragma unroll
-            for (int c = 0; c < kPanel; c++) uz[c] = (c < bw && tx > k + c) ? u[c] : 0.0;
+            // (the pivot rows' own triangular solve above uses the same uz: Lsub is 0 where the reference's l == 0 / c >= bw)
             const double *Lpp = Lp + par * 96 * kPanel;
+            // `live` is wave-uniform (ty and the pivot rows are), but it is updated under a per-lane-looking condition and hipcc kept
+            // it in a VGPR: every row paid v_and + v_cmp + s_and_saveexec + exec restore (62 VALU per wave and panel next to the 128
+            // of the ~16 live rows' arithmetic).  From an SGPR the test is s_bitcmp1 + s_cbranch.
+            const unsigned live_s = __builtin_amdgcn_readfirstlane(live);
 #pragma unroll
             for (int sl = 0; sl < 31; sl++) {
-                if (live >> sl & 1u) {   // wave-uniform: rows already used as pivots are skipped by a scalar branch
+                if (live_s >> sl & 1u) {   // wave-uniform: rows already used as pivots are skipped by a scalar branch
                     const double *lq = Lpp + (ty + 3 * sl) * kPanel;
                     double e = er[sl];
 #pragma unroll
@@ -653,10 +708,19 @@ __global__ __launch_bounds__(kSolveThreads) void pnp_build_solve(SolveArgs a)
         LU_STAMP(3);          // wait at the barrier behind P4 / F
     }
     if (lu_stamp) {
-        unsigned long long *o = a.stamps + (size_t)slot * 16 + (wave == 0 ? 8 : 12);
+        unsigned long long *o = a.stamps + (size_t)slot * 24 + (wave == 0 ? 8 : 12);
         o[0] = lu_acc[0]; o[1] = lu_acc[1]; o[2] = lu_acc[2]; o[3] = lu_acc[3];
     }
+#ifdef CHIP_PNP_FSTAMPS
+    if (f_stamp && lane == 0) { unsigned long long *o = a.stamps + (size_t)slot * 24 + 16; for (int i = 0; i < 7; i++) o[i] = f_acc[i]; }
+#endif
+    if (a.stamps != nullptr && lane == 0) {   // which SIMD every wave of the workgroup sits on: HW_ID[5:4] (and the CU: [11:8], SE [14:13])
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (15 << 11));   // hwreg(HW_ID, 0, 16)
+        atomicOr(a.stamps + (size_t)slot * 24 + 23, (unsigned long long)((hw >> 4) & 3u) << (4 * wave) | (unsigned long long)((hw >> 8) & 0xfu) << 32);
+    }
+#undef F_STAMP
 #undef LU_STAMP
+    __builtin_amdgcn_s_setprio(0);
     if (singular) {
         if (tid == 0) a.ok[slot] = 0;
         return;
@@ -1391,10 +1455,10 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
         if (st->stamps_n < P * H) {
             (void)hipFree(st->stamps);
             st->stamps = nullptr; st->stamps_n = 0;
-            CHIP_HIP(c, hipMalloc(&st->stamps, sizeof(unsigned long long) * 24 * (size_t)P * H));
+            CHIP_HIP(c, hipMalloc(&st->stamps, sizeof(unsigned long long) * 32 * (size_t)P * H));
             st->stamps_n = P * H;
         }
-        CHIP_HIP(c, hipMemsetAsync(st->stamps, 0, sizeof(unsigned long long) * 24 * (size_t)st->stamps_n, s));
+        CHIP_HIP(c, hipMemsetAsync(st->stamps, 0, sizeof(unsigned long long) * 32 * (size_t)st->stamps_n, s));
         sa.stamps = st->stamps + 8 * (size_t)st->stamps_n;
     }
     ea.H = H; ea.S = S; ea.thresh = p->error_thresh; ea.use_mle = p->use_mle;
@@ -1405,6 +1469,8 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
     // A batch of several problems may go out as `groups` launch pairs on as many streams (CHIP_PNP_GROUPS, tuning): both kernels are
     // latency chains that leave issue slots free, so build(group g+1) can run underneath eig(group g).
     static const int want_groups = [] { const char *e = std::getenv("CHIP_PNP_GROUPS"); return e ? std::atoi(e) : 1; }();
+    static const int want_prio = [] { const char *e = std::getenv("CHIP_PNP_PRIO"); return e ? std::atoi(e) : 1; }();
+    sa.factor_prio = want_prio;
     int groups = want_groups < 1 ? 1 : (want_groups > 2 ? 2 : want_groups);
     if (groups > P) groups = P;
     if (groups > 1 && !st->s2) {
@@ -1491,7 +1557,7 @@ extern "C" int chip_debug_pnp_solve_stamps(chip_ctx *c, unsigned long long *out,
     if (!st || !st->stamps || n_hyp > st->stamps_n) return CHIP_ERR_INVALID_ARG;
     CHIP_HIP(c, hipSetDevice(c->device));
     CHIP_HIP(c, hipStreamSynchronize(c->s_pnp));
-    CHIP_HIP(c, hipMemcpy(out, st->stamps + 8 * (size_t)st->stamps_n, sizeof(unsigned long long) * 16 * (size_t)n_hyp, hipMemcpyDeviceToHost));
+    CHIP_HIP(c, hipMemcpy(out, st->stamps + 8 * (size_t)st->stamps_n, sizeof(unsigned long long) * 24 * (size_t)n_hyp, hipMemcpyDeviceToHost));
     return CHIP_OK;
 }
 

@@ -55,7 +55,7 @@ with capi.Chip(64) as chip:
     fn = chip.lib.chip_debug_pnp_solve_stamps
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
-    buf = np.zeros((H, 16), dtype=np.uint64)
+    buf = np.zeros((H, 24), dtype=np.uint64)
     assert fn(chip.h, buf.ctypes.data, H) == 0
 t = buf.astype(np.float64)
 t = t[t[:, 6] > 0]
@@ -70,3 +70,14 @@ for i, nme in enumerate(names):
 print("  LU per phase, cycles per workgroup (sum over the 24 panels):")
 print(f"    matrix wave 0: P3 (publish pivot rows) {t[:, 8].mean():8.0f}  barrier {t[:, 9].mean():8.0f}  P4 (trailing update) {t[:, 10].mean():8.0f}  barrier {t[:, 11].mean():8.0f}")
 print(f"    factor wave 6: (idle in P3)            {t[:, 12].mean():8.0f}  barrier {t[:, 13].mean():8.0f}  F  (update + factor)   {t[:, 14].mean():8.0f}  barrier {t[:, 15].mean():8.0f}")
+
+fn_ = ["update of the panel by the previous one (+ waits)", "candidates + wave max", "compare / ballots / logical position", "pivot-row + multiplier readlanes",
+       "two IEEE divisions", "panel update + logical positions", "publication (LDS writes)", "-"]
+print("  factor wave, cycles per workgroup (24 panels, 93 columns):")
+for i in range(7):
+    print(f"    {fn_[i]:52s}: {t[:, 16 + i].mean():9.0f}  ({t[:, 16 + i].mean() / (24 if i in (0, 6) else 93):7.0f} per {'panel' if i in (0, 6) else 'column'})")
+
+hw = buf[buf[:, 6] > 0][:, 23]
+from collections import Counter
+cnt = Counter(tuple(int(h >> (4 * w)) & 3 for w in range(7)) for h in hw)
+print("  SIMD of waves 0..6 (HW_ID), most common placements:", cnt.most_common(4))
