@@ -214,6 +214,9 @@ constexpr size_t kSolveLds = sizeof(double) * (kSampleMax * 8 + 9 + 9 + 27 + 27 
                              sizeof(int) * (16 + 4 + 2 * kPanel) + 64;
 
 // two workgroups per CU (7 waves each, 4 SIMDs): at most 128 VGPRs -- asked for explicitly, the budget is not left to chance
+// STAMP = true (CHIP_PNP_STAMPS=1, tuning only): shader-clock stamps at the phase boundaries; compiled out of the product kernel
+// (they were run-time-guarded before: four guarded blocks per panel in every wave of the LU loop).
+template <bool STAMP>
 __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void pnp_build_solve(SolveArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     const int n = a.S;
     const PnpTables &tb = *a.tab;
 
-#define SOLVE_STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(size_t)slot * 24 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define SOLVE_STAMP(i) do { if (STAMP && tid == 0) a.stamps[(size_t)slot * 24 + (i)] = __builtin_readcyclecounter(); } while (0)
     SOLVE_STAMP(0);
     // ---- sampler: partial Fisher-Yates over a virtual identity permutation (theia::RandomSampler restated) ----
     if (wave == 0) {
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     // and every stamp costs ~60 cycles on the chain it measures)
 #ifdef CHIP_PNP_FSTAMPS
     unsigned long long f_t = 0, f_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool f_stamp = a.stamps != nullptr && wave == 6;
+    const bool f_stamp = STAMP && wave == 6;
 #define F_STAMP(i) do { if (f_stamp) { const unsigned long long t_ = __builtin_readcyclecounter(); f_acc[i] += t_ - f_t; f_t = t_; } } while (0)
 #else
 #define F_STAMP(i) do { } while (0)
@@ -453,32 +456,32 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
             if (c < bw && !sing) {
                 const int kk = k + c;
                 const bool al0 = lp0 >= kk, al1 = has1 && lp1 >= kk;   // pivots sit at logical positions < kk
-                const double v0 = al0 ? fabs(A0(c)) : -1.0, v1 = al1 ? fabs(A1(c)) : -1.0;
-                double vm = v0 > 0.0 ? v0 : 0.0;                       // NaN never wins, as in the reference scan
-                const bool up = v1 > vm;                               // the lane's larger candidate is its row lane + 64
-                if (up) vm = v1;
-                // Non-negative doubles order like their bit patterns: the HIGH words decide unless two candidates agree in sign,
-                // exponent and 20 mantissa bits.  Usual case: one lane attains the max high word (and its two rows differ) -> that
-                // row is the pivot; no second reduction over the low words, no 64-bit compares.  Everything else (ties on the high
-                // word, exact ties, an all-zero / denormal column) takes the full path below.  Same pivot either way.
-                const unsigned long long vb = (unsigned long long)__double_as_longlong(vm);
-                const unsigned vhi = (unsigned)(vb >> 32);
-                const unsigned mhi = wave_umax(vhi);
-                const unsigned long long cand = __builtin_amdgcn_ballot_w64(vhi == mhi);
-                const unsigned long long upm = __builtin_amdgcn_ballot_w64(up), eqm = __builtin_amdgcn_ballot_w64(al0 && al1 && v0 == v1);
+                // Finite non-negative doubles order like their bit patterns, so the HIGH words (sign cleared) decide unless two
+                // candidates agree in exponent and 20 mantissa bits.  Usual case: one lane attains the max high word and its two rows
+                // differ there -> that row is the pivot, found with 32-bit integer work and ONE DPP reduction.  Everything else -- ties on
+                // a high word, exact ties, an all-zero / denormal column, a NaN or Inf (high word >= 0x7ff00000) -- takes the full path
+                // (64-bit compares, second reduction over the low words, smallest-logical-index rule).  Same pivot either way.
+                const unsigned h0 = al0 ? ((unsigned)((unsigned long long)__double_as_longlong(A0(c)) >> 32) & 0x7fffffffu) : 0u;
+                const unsigned h1 = al1 ? ((unsigned)((unsigned long long)__double_as_longlong(A1(c)) >> 32) & 0x7fffffffu) : 0u;
+                const unsigned vhi_i = h0 > h1 ? h0 : h1;
+                const unsigned mhi_i = wave_umax(vhi_i);
+                const unsigned long long cand = __builtin_amdgcn_ballot_w64(vhi_i == mhi_i);
+                const unsigned long long upm = __builtin_amdgcn_ballot_w64(h1 > h0), eqm = __builtin_amdgcn_ballot_w64(h1 == h0);
                 F_STAMP(1);   // candidates + wave max
                 int olane, plog;
                 bool ohalf;
                 double best;
-                const int cl = __builtin_ctzll(cand);                  // cand != 0: the lane holding mhi is in it
-                if (__popcll(cand) == 1 && mhi != 0u && !((eqm >> cl) & 1ull)) {
+                const int cl = __builtin_ctzll(cand);                  // cand != 0: the lane holding the max is in it
+                if (__popcll(cand) == 1 && mhi_i != 0u && mhi_i < 0x7ff00000u && !((eqm >> cl) & 1ull)) {
                     olane = cl;
                     ohalf = (upm >> cl) & 1ull;
                     plog = __builtin_amdgcn_readlane(ohalf ? lp1 : lp0, olane);
                     best = 1.0;                                        // only its sign is looked at below
                 } else {
-                    const unsigned mlo = wave_umax(vhi == mhi ? (unsigned)vb : 0u);
-                    best = __longlong_as_double((long long)(((unsigned long long)mhi << 32) | mlo));
+                    const double v0 = al0 ? fabs(A0(c)) : -1.0, v1 = al1 ? fabs(A1(c)) : -1.0;
+                    double vm = v0 > 0.0 ? v0 : 0.0;                   // NaN never wins, as in the reference scan
+                    if (v1 > vm) vm = v1;
+                    best = wave_max_nonneg_2x32(vm);
                     const bool w0 = al0 && v0 == best, w1 = al1 && v1 == best;
                     const unsigned long long t0 = __builtin_amdgcn_ballot_w64(w0), t1 = __builtin_amdgcn_ballot_w64(w1);
                     if (__popcll(t0) + __popcll(t1) == 1) {           // one row attains the max
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     __syncthreads();
     // tuning only (CHIP_PNP_STAMPS): per-phase shader-clock totals of the LU, wave 0 (a matrix wave) and wave 6 (the factor wave)
     unsigned long long lu_t = 0, lu_acc[4] = {0, 0, 0, 0};
-    const bool lu_stamp = a.stamps != nullptr && lane == 0 && (wave == 0 || wave == 6);
+    const bool lu_stamp = STAMP && lane == 0 && (wave == 0 || wave == 6);
 #define LU_STAMP(i) do { if (lu_stamp) { const unsigned long long t_ = __builtin_readcyclecounter(); lu_acc[i] += t_ - lu_t; lu_t = t_; } } while (0)
     if (lu_stamp) lu_t = __builtin_readcyclecounter();
 #ifdef CHIP_PNP_FSTAMPS
@@ -683,10 +686,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                     double v = prow_raw[(par * kPanel + c) * 128 + kn + c2];
 #pragma unroll
                     for (int c3 = 0; c3 < kPanel; c3++)
-                        if (c3 < c) {
-                            const double nv = v - LS(c, c3) * un[c3];
-                            v = (c < bw && LS(c, c3) != 0.0) ? nv : v;
-                        }
+                        if (c3 < c) v = v - LS(c, c3) * un[c3];   // no l != 0 test (v - 0*u == v); un[c >= bw] is not used (uc below)
                     un[c] = v;
                 }
                 double e0 = pp[lane * kPanel + c2];
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
 #ifdef CHIP_PNP_FSTAMPS
     if (f_stamp && lane == 0) { unsigned long long *o = a.stamps + (size_t)slot * 24 + 16; for (int i = 0; i < 7; i++) o[i] = f_acc[i]; }
 #endif
-    if (a.stamps != nullptr && lane == 0) {   // which SIMD every wave of the workgroup sits on: HW_ID[5:4] (and the CU: [11:8], SE [14:13])
+    if (STAMP && lane == 0) {   // which SIMD every wave of the workgroup sits on: HW_ID[5:4] (and the CU: [11:8], SE [14:13])
         const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (15 << 11));   // hwreg(HW_ID, 0, 16)
         atomicOr(a.stamps + (size_t)slot * 24 + 23, (unsigned long long)((hw >> 4) & 3u) << (4 * wave) | (unsigned long long)((hw >> 8) & 0xfu) << 32);
     }
@@ -1353,7 +1353,8 @@ int pnp_create(Ctx *c)
     build_tables(t);
     CHIP_HIP(c, hipMalloc(&st->tab_dev, sizeof(PnpTables)));
     CHIP_HIP(c, hipMemcpy(st->tab_dev, &t, sizeof t, hipMemcpyHostToDevice));
-    CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(pnp_build_solve), hipFuncAttributeMaxDynamicSharedMemorySize, 102 * 1024));
+    CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(pnp_build_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 102 * 1024));
+    CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(pnp_build_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 102 * 1024));
     return CHIP_OK;
 }
 
@@ -1485,7 +1486,8 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
         if (g > 0) CHIP_HIP(c, hipStreamWaitEvent(sg, st->ev_in, 0));
         sa.slot0 = ea.slot0 = p0 * H;
         const int nslots = (p1 - p0) * H;
-        hipLaunchKernelGGL(pnp_build_solve, dim3(nslots), dim3(kSolveThreads), lds, sg, sa);
+        if (want_stamps) hipLaunchKernelGGL(pnp_build_solve<true>, dim3(nslots), dim3(kSolveThreads), lds, sg, sa);
+        else hipLaunchKernelGGL(pnp_build_solve<false>, dim3(nslots), dim3(kSolveThreads), lds, sg, sa);
         CHIP_HIP(c, hipGetLastError());
         if (want_stamps) hipLaunchKernelGGL(pnp_eig_score<true>, dim3(nslots), dim3(64), 0, sg, ea);
         else hipLaunchKernelGGL(pnp_eig_score<false>, dim3(nslots), dim3(64), 0, sg, ea);

@@ -199,4 +199,4 @@ def test_pnp_build_solve_fits_two_workgroups_per_cu(tmp_path):
             assert get(r"\.vgpr_count") <= 128, (name, get(r"\.vgpr_count"))
             assert get(r"\.vgpr_spill_count") == 0 and get(r"\.private_segment_fixed_size") == 0, name
             seen += 1
-    assert seen == 1
+    assert seen == 2          # the product kernel and its stamped (tuning) twin
