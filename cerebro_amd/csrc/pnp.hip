@@ -727,13 +727,24 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     }
     SOLVE_STAMP(4);   // LU done
     // ---- back-substitution: only the last 27 unknowns (boundary monomials) are referenced by B; Urows[i-66] = row i of U ----
-    if (tid < 27) {
-        const int c = tid;
-        for (int i = kNR - 1; i >= kNR - 27; i--) {
-            const double *Ui = Urows + (i - 66) * kNC;
+    // One thread per right-hand side; the 27 x 26 / 2 terms of a column are one serial chain (the reference's order).  Fully unrolled
+    // with the solved unknowns in REGISTERS: the rolled form read U and X from LDS term by term, ~70 cycles of exposed LDS latency
+    // per term (25 k cycles per workgroup, 11 % of the kernel); here the U reads (wave-uniform broadcasts) carry no dependence on
+    // the chain and are issued ahead of it, and a term costs its multiply and its dependent subtract.
+    if (wave == 0) {
+        const int c = lane < 27 ? lane : 0;   // lanes >= 27 repeat column 0 (no divergence, no store)
+        double xs[27];
+#pragma unroll
+        for (int r = 26; r >= 0; r--) {       // row i = 66 + r of U
+            const double *Ui = Urows + r * kNC;
             double s = Ui[93 + c];
-            for (int j = i + 1; j < kNR; j++) s = s - Ui[j] * Xb[(j - 66) * 27 + c];
-            Xb[(i - 66) * 27 + c] = s / Ui[i];
+#pragma unroll
+            for (int q = r + 1; q < 27; q++) s = s - Ui[66 + q] * xs[q];
+            xs[r] = s / Ui[66 + r];
+        }
+        if (lane < 27) {
+#pragma unroll
+            for (int r = 0; r < 27; r++) Xb[r * 27 + c] = xs[r];
         }
     }
     __syncthreads();
