@@ -73,8 +73,9 @@ print(f"    factor wave 6: (idle in P3)            {t[:, 12].mean():8.0f}  barri
 
 fn_ = ["update of the panel by the previous one (+ waits)", "candidates + wave max", "compare / ballots / logical position", "pivot-row + multiplier readlanes",
        "two IEEE divisions", "panel update + logical positions", "publication (LDS writes)", "-"]
-print("  factor wave, cycles per workgroup (24 panels, 93 columns):")
-for i in range(7):
+if t[:, 16:23].sum() > 0:      # only in a -DCHIP_PNP_FSTAMPS build
+  print("  factor wave, cycles per workgroup (24 panels, 93 columns):")
+  for i in range(7):
     print(f"    {fn_[i]:52s}: {t[:, 16 + i].mean():9.0f}  ({t[:, 16 + i].mean() / (24 if i in (0, 6) else 93):7.0f} per {'panel' if i in (0, 6) else 'column'})")
 
 hw = buf[buf[:, 6] > 0][:, 23]
