@@ -789,6 +789,91 @@ __device__ __forceinline__ double sqrt_normal_range(double t)
 }
 
 
+
+// ---- serial sums / updates of the Hessenberg reduction (orthes / ortran), one wave, operands in LDS -------------------------------
+// A lone wave issues one instruction per ~8 cycles and pays ~100 cycles for every LDS read it waits for (profiles/r03_chain_latency.txt),
+// so these loops (2800 terms per matrix, each a multiply and a dependent add) are written to (1) read the reflector u from LDS as
+// wave-uniform broadcasts -- one DS read instead of two v_readlane per term --, and (2) keep the NEXT four terms' reads in flight
+// underneath the current four terms' arithmetic (LDS returns in order: counted lgkmcnt waits).  Term order is the reference's.
+//   dot_desc:  f = sum_{i = hi, hi-1, .., lo} a[i] * b[i * SB]     (f starts at +0.0, one rounding per multiply and per add)
+template <int SB>
+__device__ __forceinline__ double dot_desc(const double *a, const double *b, int hi, int lo)
+{
+    double f = 0.0;
+    int i = hi;
+    if (i - 3 >= lo) {
+        double a0 = a[i], a1 = a[i - 1], a2 = a[i - 2], a3 = a[i - 3];
+        double b0 = b[i * SB], b1 = b[(i - 1) * SB], b2 = b[(i - 2) * SB], b3 = b[(i - 3) * SB];
+        i -= 4;
+        while (i - 3 >= lo) {
+            const double na0 = a[i], na1 = a[i - 1], na2 = a[i - 2], na3 = a[i - 3];
+            const double nb0 = b[i * SB], nb1 = b[(i - 1) * SB], nb2 = b[(i - 2) * SB], nb3 = b[(i - 3) * SB];
+            f = f + a0 * b0; f = f + a1 * b1; f = f + a2 * b2; f = f + a3 * b3;
+            a0 = na0; a1 = na1; a2 = na2; a3 = na3; b0 = nb0; b1 = nb1; b2 = nb2; b3 = nb3;
+            i -= 4;
+        }
+        f = f + a0 * b0; f = f + a1 * b1; f = f + a2 * b2; f = f + a3 * b3;
+    }
+    const int rem = i - lo + 1;   // 0..3 terms left: all reads first, then the chain
+    double ra0 = 0.0, ra1 = 0.0, ra2 = 0.0, rb0 = 0.0, rb1 = 0.0, rb2 = 0.0;
+    if (rem > 0) { ra0 = a[i]; rb0 = b[i * SB]; }
+    if (rem > 1) { ra1 = a[i - 1]; rb1 = b[(i - 1) * SB]; }
+    if (rem > 2) { ra2 = a[i - 2]; rb2 = b[(i - 2) * SB]; }
+    if (rem > 0) f = f + ra0 * rb0;
+    if (rem > 1) f = f + ra1 * rb1;
+    if (rem > 2) f = f + ra2 * rb2;
+    return f;
+}
+//   dot_asc:  g = sum_{i = lo, lo+1, .., hi} a[i] * b[i * SB]
+template <int SB>
+__device__ __forceinline__ double dot_asc(const double *a, const double *b, int lo, int hi)
+{
+    double f = 0.0;
+    int i = lo;
+    if (i + 3 <= hi) {
+        double a0 = a[i], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3];
+        double b0 = b[i * SB], b1 = b[(i + 1) * SB], b2 = b[(i + 2) * SB], b3 = b[(i + 3) * SB];
+        i += 4;
+        while (i + 3 <= hi) {
+            const double na0 = a[i], na1 = a[i + 1], na2 = a[i + 2], na3 = a[i + 3];
+            const double nb0 = b[i * SB], nb1 = b[(i + 1) * SB], nb2 = b[(i + 2) * SB], nb3 = b[(i + 3) * SB];
+            f = f + a0 * b0; f = f + a1 * b1; f = f + a2 * b2; f = f + a3 * b3;
+            a0 = na0; a1 = na1; a2 = na2; a3 = na3; b0 = nb0; b1 = nb1; b2 = nb2; b3 = nb3;
+            i += 4;
+        }
+        f = f + a0 * b0; f = f + a1 * b1; f = f + a2 * b2; f = f + a3 * b3;
+    }
+    const int rem = hi - i + 1;
+    double ra0 = 0.0, ra1 = 0.0, ra2 = 0.0, rb0 = 0.0, rb1 = 0.0, rb2 = 0.0;
+    if (rem > 0) { ra0 = a[i]; rb0 = b[i * SB]; }
+    if (rem > 1) { ra1 = a[i + 1]; rb1 = b[(i + 1) * SB]; }
+    if (rem > 2) { ra2 = a[i + 2]; rb2 = b[(i + 2) * SB]; }
+    if (rem > 0) f = f + ra0 * rb0;
+    if (rem > 1) f = f + ra1 * rb1;
+    if (rem > 2) f = f + ra2 * rb2;
+    return f;
+}
+//   axpy_rows:  b[i * SB] = b[i * SB] + c * a[i],  i = lo .. hi  (independent per i; c = -f gives the reference's  b - f * a:
+//   x - y == x + (-y) and (-f) * a == -(f * a) exactly in IEEE arithmetic)
+template <int SB>
+__device__ __forceinline__ void axpy_rows(const double *a, double *b, double c, int lo, int hi)
+{
+    int i = lo;
+    for (; i + 3 <= hi; i += 4) {
+        const double a0 = a[i], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3];
+        const double b0 = b[i * SB], b1 = b[(i + 1) * SB], b2 = b[(i + 2) * SB], b3 = b[(i + 3) * SB];
+        b[i * SB] = b0 + c * a0; b[(i + 1) * SB] = b1 + c * a1; b[(i + 2) * SB] = b2 + c * a2; b[(i + 3) * SB] = b3 + c * a3;
+    }
+    const int rem = hi - i + 1;
+    double ra0 = 0.0, ra1 = 0.0, ra2 = 0.0, rb0 = 0.0, rb1 = 0.0, rb2 = 0.0;
+    if (rem > 0) { ra0 = a[i]; rb0 = b[i * SB]; }
+    if (rem > 1) { ra1 = a[i + 1]; rb1 = b[(i + 1) * SB]; }
+    if (rem > 2) { ra2 = a[i + 2]; rb2 = b[(i + 2) * SB]; }
+    if (rem > 0) b[i * SB] = rb0 + c * ra0;
+    if (rem > 1) b[(i + 1) * SB] = rb1 + c * ra1;
+    if (rem > 2) b[(i + 2) * SB] = rb2 + c * ra2;
+}
+
 struct EigArgs {
     PnpProblem prob[kPnpMaxBatch];
     int32_t H, S;
@@ -846,6 +931,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     } while (0)
     __shared__ double Hs[EN * EN], Vs[EN * EN];
     __shared__ double ortm[EN], wr[EN], wi[EN], Tf[27], sxs[kSampleMax * 3], model[16];
+    __shared__ __attribute__((aligned(16))) double us[EN + 5];   // the current Householder vector (orthes / ortran)
     const int lane = threadIdx.x;
     const int hyp = blockIdx.x + a.slot0;                          // slot: hypothesis (hyp % H) of problem (hyp / H)
     const PnpProblem pr = a.prob[hyp / a.H];
@@ -866,68 +952,68 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
 
     if (a.debug_stop == 1) return;
     // ================= Householder reduction to Hessenberg form (orthes) =================
-    // The reflector vector u (EISPACK's ort[]) stays in a register, lane i holding u_i: wave-uniform reads of it are
-    // v_readlane pairs instead of LDS broadcasts, the two serial sums (scale, h) run off registers, and the matrix loops fetch
-    // H four elements at a time so one LDS round trip is exposed per four terms.  Term order is that of the reference loops.
+    // The reflector u (EISPACK's ort[]) lives in LDS (us[], zero outside m..high): the serial sums read it as wave-uniform
+    // broadcasts, four terms ahead of the arithmetic (dot_desc / dot_asc / axpy_rows above).  Term order is the reference's.
     for (int m = low + 1; m <= high - 1; m++) {
-        const double colv = (lane <= high) ? HH(lane, m - 1) : 0.0;
+        // scale = sum_{i = m..high} |H(i, m-1)|, ascending: every lane runs the same chain on broadcast reads of the column
         double scale = 0.0;
-        for (int i = m; i <= high; i++) scale = scale + fabs(lane_value_f64(colv, i));
+        {
+            const double *col = &HH(0, m - 1);
+            int i = m;
+            for (; i + 3 <= high; i += 4) {
+                const double c0 = col[i * EN], c1 = col[(i + 1) * EN], c2 = col[(i + 2) * EN], c3 = col[(i + 3) * EN];
+                scale = scale + fabs(c0); scale = scale + fabs(c1); scale = scale + fabs(c2); scale = scale + fabs(c3);
+            }
+            const int rem = high - i + 1;
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+            if (rem > 0) c0 = col[i * EN];
+            if (rem > 1) c1 = col[(i + 1) * EN];
+            if (rem > 2) c2 = col[(i + 2) * EN];
+            if (rem > 0) scale = scale + fabs(c0);
+            if (rem > 1) scale = scale + fabs(c1);
+            if (rem > 2) scale = scale + fabs(c2);
+        }
         if (scale != 0.0) {
+            const bool mine = lane >= m && lane <= high;
+            const double colv = mine ? HH(lane, m - 1) : 0.0;
             double ov = colv / scale;                       // u_i = H(i, m-1) / scale on lanes m..high
-            double h = 0.0;
-            for (int i = high; i >= m; i--) { const double o = lane_value_f64(ov, i); h = h + o * o; }
-            double g = sqrt(h);
-            const double om = lane_value_f64(ov, m);
-            if (om > 0) g = -g;
-            h = h - om * g;
-            if (lane == m) ov = om - g;
-            if (lane >= m && lane < nn) {  // H = (I - u u^T/h) H, column j = lane
-                const int j = lane;
-                double f = 0.0;
+            if (lane < EN + 5) us[lane] = mine ? ov : 0.0;
+            WAVE_SYNC();
+            double h = 0.0;                                  // h = sum_{i = high..m} u_i^2, descending
+            {
                 int i = high;
                 for (; i - 3 >= m; i -= 4) {
-                    const double h0 = HH(i, j), h1 = HH(i - 1, j), h2 = HH(i - 2, j), h3 = HH(i - 3, j);
-                    f = f + lane_value_f64(ov, i) * h0;
-                    f = f + lane_value_f64(ov, i - 1) * h1;
-                    f = f + lane_value_f64(ov, i - 2) * h2;
-                    f = f + lane_value_f64(ov, i - 3) * h3;
+                    const double o0 = us[i], o1 = us[i - 1], o2 = us[i - 2], o3 = us[i - 3];
+                    h = h + o0 * o0; h = h + o1 * o1; h = h + o2 * o2; h = h + o3 * o3;
                 }
-                for (; i >= m; i--) f = f + lane_value_f64(ov, i) * HH(i, j);
+                const int rem = i - m + 1;
+                double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+                if (rem > 0) o0 = us[i];
+                if (rem > 1) o1 = us[i - 1];
+                if (rem > 2) o2 = us[i - 2];
+                if (rem > 0) h = h + o0 * o0;
+                if (rem > 1) h = h + o1 * o1;
+                if (rem > 2) h = h + o2 * o2;
+            }
+            double g = sqrt(h);
+            const double om = us[m];
+            if (om > 0) g = -g;
+            h = h - om * g;
+            WAVE_SYNC();
+            if (lane == m) us[m] = om - g;
+            WAVE_SYNC();
+            if (lane >= m && lane < nn) {  // H = (I - u u^T/h) H, column j = lane
+                double *colj = &HH(0, lane);
+                double f = dot_desc<EN>(us, colj, high, m);
                 f = f / h;
-                i = m;
-                for (; i + 3 <= high; i += 4) {
-                    const double h0 = HH(i, j), h1 = HH(i + 1, j), h2 = HH(i + 2, j), h3 = HH(i + 3, j);
-                    HH(i, j) = h0 - f * lane_value_f64(ov, i);
-                    HH(i + 1, j) = h1 - f * lane_value_f64(ov, i + 1);
-                    HH(i + 2, j) = h2 - f * lane_value_f64(ov, i + 2);
-                    HH(i + 3, j) = h3 - f * lane_value_f64(ov, i + 3);
-                }
-                for (; i <= high; i++) HH(i, j) = HH(i, j) - f * lane_value_f64(ov, i);
+                axpy_rows<EN>(us, colj, -f, m, high);
             }
             WAVE_SYNC();
             if (lane <= high) {  // H = H (I - u u^T/h), row i = lane
-                const int i = lane;
-                double f = 0.0;
-                int j = high;
-                for (; j - 3 >= m; j -= 4) {
-                    const double h0 = HH(i, j), h1 = HH(i, j - 1), h2 = HH(i, j - 2), h3 = HH(i, j - 3);
-                    f = f + lane_value_f64(ov, j) * h0;
-                    f = f + lane_value_f64(ov, j - 1) * h1;
-                    f = f + lane_value_f64(ov, j - 2) * h2;
-                    f = f + lane_value_f64(ov, j - 3) * h3;
-                }
-                for (; j >= m; j--) f = f + lane_value_f64(ov, j) * HH(i, j);
+                double *rowi = &HH(lane, 0);
+                double f = dot_desc<1>(us, rowi, high, m);
                 f = f / h;
-                j = m;
-                for (; j + 3 <= high; j += 4) {
-                    const double h0 = HH(i, j), h1 = HH(i, j + 1), h2 = HH(i, j + 2), h3 = HH(i, j + 3);
-                    HH(i, j) = h0 - f * lane_value_f64(ov, j);
-                    HH(i, j + 1) = h1 - f * lane_value_f64(ov, j + 1);
-                    HH(i, j + 2) = h2 - f * lane_value_f64(ov, j + 2);
-                    HH(i, j + 3) = h3 - f * lane_value_f64(ov, j + 3);
-                }
-                for (; j <= high; j++) HH(i, j) = HH(i, j) - f * lane_value_f64(ov, j);
+                axpy_rows<1>(us, rowi, -f, m, high);
             }
             WAVE_SYNC();
             if (lane == 0) {
@@ -944,13 +1030,15 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     for (int m = high - 1; m >= low + 1; m--) {
         const double hmm = HH(m, m - 1);
         if (hmm != 0.0) {
+            const double om = ortm[m];
+            // u = (ort[m], H(m+1, m-1), .., H(high, m-1)) staged contiguously for the broadcast reads
+            if (lane >= m && lane <= high) us[lane] = (lane == m) ? om : HH(lane, m - 1);
+            WAVE_SYNC();
             if (lane >= m && lane <= high) {
-                const int j = lane;
-                const double om = ortm[m];
-                double g = 0.0;
-                for (int i = m; i <= high; i++) g = g + (i == m ? om : HH(i, m - 1)) * VV(i, j);
+                double *colj = &VV(0, lane);
+                double g = dot_asc<EN>(us, colj, m, high);
                 g = (g / om) / hmm;
-                for (int i = m; i <= high; i++) VV(i, j) = VV(i, j) + g * (i == m ? om : HH(i, m - 1));
+                axpy_rows<EN>(us, colj, g, m, high);
             }
             WAVE_SYNC();
         }
