@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                 if (ss == 0.0) ss = norm;
                 small = fabs(HH(lane, lane - 1)) < eps * ss;
             }
-            const unsigned long long bm = __ballot(small);
+            const unsigned long long bm = __builtin_amdgcn_ballot_w64(small);
             l = bm ? 63 - __builtin_clzll(bm) : low;
         }
         if (l == n) {  // one root
@@ -1179,9 +1179,9 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                     else pass = fabs(HH(mm, mm - 1)) * (fabs(qm) + fabs(rm)) <
                                 eps * (fabs(pm) * (fabs(HH(mm - 1, mm - 1)) + fabs(zz) + fabs(HH(mm + 1, mm + 1))));
                 }
-                const unsigned long long bm = __ballot(pass);
+                const unsigned long long bm = __builtin_amdgcn_ballot_w64(pass);
                 m = 63 - __builtin_clzll(bm);   // lane l always passes and l <= n-2 in this branch
-                p = __shfl(pm, m, 64); q = __shfl(qm, m, 64); r = __shfl(rm, m, 64);
+                p = lane_value_f64(pm, m); q = lane_value_f64(qm, m); r = lane_value_f64(rm, m);   // m is wave-uniform: v_readlane, not ds_bpermute
             }
             WAVE_SYNC();
             if (lane >= m + 2 && lane <= n) { HH(lane, lane - 2) = 0.0; if (lane > m + 2) HH(lane, lane - 3) = 0.0; }
@@ -1258,7 +1258,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                 PNP_STAMP(2);
                 const int imax = (n < k + 3) ? n : k + 3;
                 double c0 = 0.0;
-                if ((lane < 32) ? (lane <= imax) : (lane - 32 <= high)) {  // H rows 0..imax | V rows 0..26
+                if (arow <= ((lane < 32) ? imax : high)) {  // H rows 0..imax | V rows 0..26 (one compare: the two-sided form compiled to divergent control flow)
                     double *row = Abase + arow * EN + k;
                     const double a0 = row[0], a1 = row[1];
                     double a2 = 0.0;
