@@ -853,6 +853,32 @@ __device__ __forceinline__ double dot_asc(const double *a, const double *b, int 
     if (rem > 2) f = f + ra2 * rb2;
     return f;
 }
+//   abs_sum_asc:  acc + |b[lo * SB]| + |b[(lo+1) * SB]| + .. + |b[hi * SB]|, ascending, next four reads in flight under the current four adds
+template <int SB>
+__device__ __forceinline__ double abs_sum_asc(const double *b, int lo, int hi, double acc)
+{
+    int i = lo;
+    if (i + 3 <= hi) {
+        double b0 = b[i * SB], b1 = b[(i + 1) * SB], b2 = b[(i + 2) * SB], b3 = b[(i + 3) * SB];
+        i += 4;
+        while (i + 3 <= hi) {
+            const double n0 = b[i * SB], n1 = b[(i + 1) * SB], n2 = b[(i + 2) * SB], n3 = b[(i + 3) * SB];
+            acc = acc + fabs(b0); acc = acc + fabs(b1); acc = acc + fabs(b2); acc = acc + fabs(b3);
+            b0 = n0; b1 = n1; b2 = n2; b3 = n3;
+            i += 4;
+        }
+        acc = acc + fabs(b0); acc = acc + fabs(b1); acc = acc + fabs(b2); acc = acc + fabs(b3);
+    }
+    const int rem = hi - i + 1;
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    if (rem > 0) c0 = b[i * SB];
+    if (rem > 1) c1 = b[(i + 1) * SB];
+    if (rem > 2) c2 = b[(i + 2) * SB];
+    if (rem > 0) acc = acc + fabs(c0);
+    if (rem > 1) acc = acc + fabs(c1);
+    if (rem > 2) acc = acc + fabs(c2);
+    return acc;
+}
 //   axpy_rows:  b[i * SB] = b[i * SB] + c * a[i],  i = lo .. hi  (independent per i; c = -f gives the reference's  b - f * a:
 //   x - y == x + (-y) and (-f) * a == -(f * a) exactly in IEEE arithmetic)
 template <int SB>
@@ -956,23 +982,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     // broadcasts, four terms ahead of the arithmetic (dot_desc / dot_asc / axpy_rows above).  Term order is the reference's.
     for (int m = low + 1; m <= high - 1; m++) {
         // scale = sum_{i = m..high} |H(i, m-1)|, ascending: every lane runs the same chain on broadcast reads of the column
-        double scale = 0.0;
-        {
-            const double *col = &HH(0, m - 1);
-            int i = m;
-            for (; i + 3 <= high; i += 4) {
-                const double c0 = col[i * EN], c1 = col[(i + 1) * EN], c2 = col[(i + 2) * EN], c3 = col[(i + 3) * EN];
-                scale = scale + fabs(c0); scale = scale + fabs(c1); scale = scale + fabs(c2); scale = scale + fabs(c3);
-            }
-            const int rem = high - i + 1;
-            double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-            if (rem > 0) c0 = col[i * EN];
-            if (rem > 1) c1 = col[(i + 1) * EN];
-            if (rem > 2) c2 = col[(i + 2) * EN];
-            if (rem > 0) scale = scale + fabs(c0);
-            if (rem > 1) scale = scale + fabs(c1);
-            if (rem > 2) scale = scale + fabs(c2);
-        }
+        const double scale = abs_sum_asc<EN>(&HH(0, m - 1), m, high, 0.0);
         if (scale != 0.0) {
             const bool mine = lane >= m && lane <= high;
             const double colv = mine ? HH(lane, m - 1) : 0.0;
@@ -1052,9 +1062,8 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     if (a.debug_stop == 2) return;
     PNP_STAMP(6);
     // ================= Francis double-shift QR with accumulation (hqr2) =================
-    double norm = 0.0;
-    for (int i = 0; i < nn; i++)
-        for (int j = (i - 1 > 0 ? i - 1 : 0); j < nn; j++) norm = norm + fabs(HH(i, j));
+    double norm = 0.0;   // sum over the Hessenberg part, row by row (one serial chain; broadcast reads four terms ahead)
+    for (int i = 0; i < nn; i++) norm = abs_sum_asc<1>(&HH(i, 0), (i - 1 > 0 ? i - 1 : 0), nn - 1, norm);
     int n = nn - 1;
     double exshift = 0.0, p = 0, q = 0, r = 0, s = 0, z = 0, w, x, y;
     int iter = 0;
@@ -1233,7 +1242,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                 // p^2 + q^2 + r^2 is in [1/12, 1): sqrt_normal_range is IEEE sqrt there, without the range handling on the chain
                 s = sqrt_normal_range(p * p + q * q + r * r);
                 if (p < 0) s = -s;
-                if (s == 0.0) return;
+                if (k == m && s == 0.0) return;   // k != m: |p|+|q|+|r| is in [0.5, 1) after the scaling above, s cannot be 0
                 const double hkk1 = (k != m) ? ldexp(-s, ex) : ((l != m) ? -HH(k, k - 1) : 0.0);
                 const bool wr_sub = (k != m) || (l != m);
                 p = p + s;
@@ -1569,7 +1578,7 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
     // A batch of several problems may go out as `groups` launch pairs on as many streams (CHIP_PNP_GROUPS, tuning): both kernels are
     // latency chains that leave issue slots free, so build(group g+1) can run underneath eig(group g).
     static const int want_groups = [] { const char *e = std::getenv("CHIP_PNP_GROUPS"); return e ? std::atoi(e) : 1; }();
-    static const int want_prio = [] { const char *e = std::getenv("CHIP_PNP_PRIO"); return e ? std::atoi(e) : 1; }();
+    static const int want_prio = [] { const char *e = std::getenv("CHIP_PNP_PRIO"); return e ? std::atoi(e) : 0; }();   // measured: no effect (profiles/r03_pnp_pmc.md)
     sa.factor_prio = want_prio;
     int groups = want_groups < 1 ? 1 : (want_groups > 2 ? 2 : want_groups);
     if (groups > P) groups = P;
