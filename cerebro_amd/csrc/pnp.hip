@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
         }
     }
     if (a.debug_stop == 4) return;
-    const unsigned long long vb = __ballot(my_valid);
+    const unsigned long long vb = __builtin_amdgcn_ballot_w64(my_valid != 0);
     const int nsol = __popcll(vb);
     if (lane == 0) a.nsol[hyp] = failed ? -2 : nsol;
     if (nsol == 1 && my_valid) {  // DlsPnpWithRansac.h:62  accept iff exactly one solution; b_T_a column-major
@@ -1401,22 +1401,37 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     if (lane < 16) a.T_out[hyp * 16 + lane] = model[lane];
     double acc = 0.0;
     int cnt = 0;
+    // One wave walks the N correspondences 64 at a time.  The loads of block b+1 are issued before the arithmetic of block b (two IEEE
+    // divisions per point): as a plain loop every block waited a full global-memory latency for its five loads.
+    unsigned long long my_word = 0ull;
+    double nX0 = 0.0, nX1 = 0.0, nX2 = 0.0, nu = 0.0, nv = 0.0;
+    if (lane < pr.N) { nX0 = pr.X[3 * lane]; nX1 = pr.X[3 * lane + 1]; nX2 = pr.X[3 * lane + 2]; nu = pr.uv[2 * lane]; nv = pr.uv[2 * lane + 1]; }
     for (int base = 0; base < pr.N; base += 64) {
         const int i = base + lane;
+        const double X0 = nX0, X1 = nX1, X2 = nX2, pu = nu, pv = nv;
+        const int in_ = i + 64;
+        if (in_ < pr.N) { nX0 = pr.X[3 * in_]; nX1 = pr.X[3 * in_ + 1]; nX2 = pr.X[3 * in_ + 2]; nu = pr.uv[2 * in_]; nv = pr.uv[2 * in_ + 1]; }
         bool in = false;
         if (i < pr.N) {
-            const double X0 = pr.X[3 * i], X1 = pr.X[3 * i + 1], X2 = pr.X[3 * i + 2];
             const double xx = ((T[0] * X0 + T[4] * X1) + T[8] * X2) + T[12];
             const double yy = ((T[1] * X0 + T[5] * X1) + T[9] * X2) + T[13];
             const double zz = ((T[2] * X0 + T[6] * X1) + T[10] * X2) + T[14];
             const double xn = xx / zz, yn = yy / zz;
-            const double rr = fabs(xn - pr.uv[2 * i]) + fabs(yn - pr.uv[2 * i + 1]);
+            const double rr = fabs(xn - pu) + fabs(yn - pv);
             in = rr < a.thresh;
             acc = acc + (in ? rr : a.thresh);
         }
-        const unsigned long long bw = __ballot(in);
+        const unsigned long long bw = __builtin_amdgcn_ballot_w64(in);
         cnt += __popcll(bw);
-        if (lane == 0) a.mask[(size_t)hyp * a.mask_words + (base >> 6)] = bw;
+        // The mask lives in pinned HOST memory.  Stores count in vmcnt like loads, so a store per block made the next block's
+        // `s_waitcnt vmcnt` wait for a PCIe write round trip (~4 us x 8 blocks at N = 512: the whole scoring phase).  Lane w keeps
+        // word w; 64 words go out in one store instruction.
+        const int word = base >> 6;
+        if (lane == (word & 63)) my_word = bw;
+        if ((word & 63) == 63 || base + 64 >= pr.N) {
+            const int w0 = word & ~63;
+            if (w0 + lane <= word) a.mask[(size_t)hyp * a.mask_words + w0 + lane] = my_word;
+        }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) acc = acc + __shfl_xor(acc, m, 64);

@@ -61,7 +61,8 @@ def test_golden_fixture_through_c_abi():
 
 
 @pytest.mark.parametrize("N,outl,noise,seed", [(20, 0.0, 0.0, 1), (64, 0.1, 0.3, 2), (100, 0.3, 0.5, 3), (512, 0.3, 0.5, 4242),
-                                                (777, 0.5, 1.0, 5), (3000, 0.2, 0.5, 6)])
+                                                (777, 0.5, 1.0, 5), (3000, 0.2, 0.5, 6),
+                                                (4500, 0.2, 0.5, 7)])   # > 4096 points: more than one 64-word group of the inlier mask
 def test_random_scenes_both_modes(N, outl, noise, seed):
     X, uv, T, inl = M.make_scene(N=N, outlier_frac=outl, noise_px=noise, seed=seed)
     with capi.Chip(256) as chip:
