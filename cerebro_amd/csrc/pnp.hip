@@ -25,6 +25,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
 #include <type_traits>
 #include <vector>
 
@@ -1548,6 +1550,16 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
                    const chip_ransac_params *p, const uint64_t *seeds, double *T_colmajor, float *confidence,
                    uint8_t *const *inlier_mask, chip_ransac_summary *summary)
 {
+    // tuning only (CHIP_PNP_HOST_TIMING=1): host-side phases of a call, averaged, printed at process exit
+    struct HostTiming {
+        double acc[5] = {0, 0, 0, 0, 0}; long n = 0; bool on = std::getenv("CHIP_PNP_HOST_TIMING") != nullptr;
+        ~HostTiming() { if (on && n) std::fprintf(stderr, "pnp host timing over %ld calls (us): prepare+H2D enqueue %.1f, launches %.1f, wait %.1f, select+copy out %.1f, total %.1f\n",
+                                                   n, acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n); }
+    };
+    static HostTiming ht;
+    const auto ht_now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double ht0 = ht.on ? ht_now() : 0.0;
+    double ht1 = 0.0, ht2 = 0.0, ht3 = 0.0;
     const int32_t S = p->sample_size;
     const int H = ransac_initial_iterations(p);
     int Ntot = 0, words = 0;
@@ -1571,6 +1583,7 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
         ea.prob[i] = pr;
     }
     CHIP_HIP(c, hipMemcpyAsync(st->X, st->h_in, sizeof(double) * 5 * (size_t)Ntot, hipMemcpyHostToDevice, s));
+    if (ht.on) ht1 = ht_now();
     sa.H = H; sa.S = S; sa.tab = st->tab_dev;
     sa.Sg = st->Sg; sa.Tg = st->Tg; sa.sample = st->sample; sa.ok = st->ok;
     const size_t lds = kSolveLds;
@@ -1617,7 +1630,9 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
         CHIP_HIP(c, hipGetLastError());
         if (g > 0) { CHIP_HIP(c, hipEventRecord(st->ev_g2, sg)); CHIP_HIP(c, hipStreamWaitEvent(s, st->ev_g2, 0)); }
     }
+    if (ht.on) ht2 = ht_now();
     CHIP_HIP(c, hipStreamSynchronize(s));   // every per-hypothesis result is in host memory now
+    if (ht.on) ht3 = ht_now();
 
     // K7: theia::Ransac::Estimate's sequential rule replayed over the per-hypothesis results
     int32_t best_h[kPnpMaxBatch], num_it[kPnpMaxBatch], n_models[kPnpMaxBatch];
@@ -1652,6 +1667,7 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
             summary[i].best_cost = best_h[i] >= 0 ? best_cost[i] : INFINITY;
         }
     }
+    if (ht.on) { const double t4 = ht_now(); ht.acc[0] += ht1 - ht0; ht.acc[1] += ht2 - ht1; ht.acc[2] += ht3 - ht2; ht.acc[3] += t4 - ht3; ht.acc[4] += t4 - ht0; ht.n++; }
     return CHIP_OK;
 }
 
