@@ -68,18 +68,29 @@ def plan_ticks(rows_scanned: int, n_ticks: int, avoid=()):
     return ls, sorted(plants), expect
 
 
-def cpu_baseline(sample_cols: int, budget_s: float):
-    """Reference-faithful CPU path (oracle port): fp64 column-major M, 3 separate GEMVs + maxCoeff + last-index
-    argmax (Cerebro.cpp:1023-1043), one thread.  Returns ticks/s extrapolated to the 1M-row tick."""
+def cpu_baseline(sample_cols: int, budget_s: float, kind: str = "eigen"):
+    """Reference CPU path, one thread (the reference's dot_product_th is one thread; Eigen's GEMV is not parallel without OpenMP,
+    which the reference does not enable): fp64 column-major M, 3 SEPARATE GEMVs + maxCoeff + last-index argmax
+    (Cerebro.cpp:1023-1043).  kind "eigen": the Eigen-order port (oracle/dot_scan.c orc_ref_scan_f64_eigen_gemv3 -- Eigen 3.3's
+    row-major GEMV for the reference's SSE2 Release build: four rows at a time, one Packet2d accumulator each, no FMA), the closest
+    restatement of what the reference runs; kind "chain": the sequential-order port (one s += q[e]*col[e] chain per column).
+    Returns columns/s, passes, seconds."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib  # checker/baseline only -- never on the product path
     M = oracle_lib.synth_rows(SEED, range(sample_cols + 3), D).astype(np.float64)
     v, vm, vmm = M[sample_cols + 2].copy(), M[sample_cols + 1].copy(), M[sample_cols].copy()
-    oracle_lib.ref_scan_f64_colmajor(M, 1000, v, vm, vmm)  # touch
+    scratch = (np.empty(sample_cols), np.empty(sample_cols), np.empty(sample_cols))
+    if kind == "eigen":
+        def scan(k):
+            return oracle_lib.ref_scan_f64_eigen_gemv3(M, k, v, vm, vmm, 1, scratch)
+    else:
+        def scan(k):
+            return oracle_lib.ref_scan_f64_colmajor(M, k, v, vm, vmm)
+    scan(1000)  # touch
     n = 0
     t0 = time.perf_counter()
     while True:
-        oracle_lib.ref_scan_f64_colmajor(M, sample_cols, v, vm, vmm)
+        scan(sample_cols)
         n += 1
         dt = time.perf_counter() - t0
         if dt > budget_s:
@@ -136,7 +147,7 @@ def usable_cpus() -> int:
 
 
 def cpu_baseline_all_cores(sample_cols: int, budget_s: float):
-    """the same three GEMVs + maxCoeff + argmax with OpenMP over columns on every host core (what the
+    """the same three Eigen-order GEMVs + maxCoeff + argmax with OpenMP over columns on every host core (what the
     reference would get from Eigen's OpenMP GEMV, which it does not enable).  Reported next to `cpu_baseline`, never as it."""
     import oracle_lib  # baseline only
     nthreads = usable_cpus()
@@ -144,11 +155,11 @@ def cpu_baseline_all_cores(sample_cols: int, budget_s: float):
     M = oracle_lib.tile_columns_omp(sample_cols, src, nthreads)           # first touch by the scanning threads
     v, vm, vmm = src[5].copy(), src[6].copy(), src[7].copy()
     scratch = (np.empty(sample_cols), np.empty(sample_cols), np.empty(sample_cols))
-    oracle_lib.ref_scan_f64_colmajor_omp(M, sample_cols, v, vm, vmm, nthreads, scratch)
+    oracle_lib.ref_scan_f64_eigen_gemv3(M, sample_cols, v, vm, vmm, nthreads, scratch)
     n = 0
     t0 = time.perf_counter()
     while True:
-        oracle_lib.ref_scan_f64_colmajor_omp(M, sample_cols, v, vm, vmm, nthreads, scratch)
+        oracle_lib.ref_scan_f64_eigen_gemv3(M, sample_cols, v, vm, vmm, nthreads, scratch)
         n += 1
         dt = time.perf_counter() - t0
         if dt > budget_s:
@@ -278,6 +289,28 @@ class c_stdout_to_stderr:
         return False
 
 
+def call_with_deadline(fn, timeout_s):
+    """Run fn() on a helper (daemon) thread and wait at most timeout_s for it.  Returns (finished, value, exception).  A helper
+    that has not finished keeps whatever it is blocked on (an RCCL bootstrap, a collective that never completes): the caller moves
+    on without it and must leave the process through os._exit."""
+    box = {}
+
+    def body():
+        try:
+            box["value"] = fn()
+        except BaseException as e:   # noqa: BLE001 -- handed to the caller
+            box["exc"] = e
+
+    th = threading.Thread(target=body, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    return (not th.is_alive()), box.get("value"), box.get("exc")
+
+
+def info_exchange(chip) -> int:
+    return int(chip.info()["exchange"])
+
+
 def run_ticks(chip, tick_ls, params, inflight, stamps=None):
     """Pipelined tick loop: up to `inflight` ticks enqueued ahead, results collected in order.  stamps (optional list) gets
     the host time of every collect -- the per-step cadence of the steady state."""
@@ -313,17 +346,37 @@ def check_results(results, exp):
             assert r.found == 0, r.as_dict()
 
 
+SIZES_TRAFFIC = None
+
+
+def sizes_traffic(rows: int):
+    """HBM-side bytes per launch of the size legs' launch shapes, from the committed PMC passes (profiles/scan_traffic_sizes.json:
+    rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, scripts/gpu_scan_sizes_pmc.sh); None when that shape was not measured."""
+    global SIZES_TRAFFIC
+    if SIZES_TRAFFIC is None:
+        try:
+            SIZES_TRAFFIC = json.loads((ROOT / "profiles" / "scan_traffic_sizes.json").read_text())
+        except Exception:
+            SIZES_TRAFFIC = {}
+    e = SIZES_TRAFFIC.get("sizes", {}).get(str(rows)) if D == 4096 else None
+    return (e or {}).get("hbm_bytes_per_launch")
+
+
 def size_leg(chip, rows, plan, params, inflight, n_ticks=240, warm=20):
     """The same tick loop over a SHORTER prefix of the resident DB (BASELINE configs 2 and 3: 10k and 100k keyframes).
-    `plan` = (ls, expect) of plan_ticks(rows, ...)."""
+    `plan` = (ls, expect) of plan_ticks(rows, ...).  Three figures per size, each named for what it is:
+      * ms_per_step / frac_step : the pipelined loop (up to `inflight` ticks enqueued ahead; launches of consecutive ticks overlap
+        on the tick streams) -- the sustained rate;
+      * isolated_kernel_ms / frac_kernel (= roofline.achieved / .frac): ONE launch alone between two hipEvents on its stream --
+        the per-kernel figure rocprofv3 reports for a synchronous tick (profiles/scan_traffic_sizes.json holds that trace);
+      * sync_tick_us: host-to-host latency of one synchronous chip_loop_tick -- what a 10 Hz producer sees."""
     ls, expect = plan
     ls, expect = ls[:warm + n_ticks], expect[:warm + n_ticks]
     chip.loop_reset()
     run_ticks(chip, ls[:warm], params, inflight)
     chip.synchronize()
-    stamps = []
     t0 = time.perf_counter()
-    res = run_ticks(chip, ls[warm:], params, inflight, stamps)
+    res = run_ticks(chip, ls[warm:], params, inflight)
     chip.synchronize()
     dt = time.perf_counter() - t0
     check_results(res, expect[warm:])
@@ -335,24 +388,36 @@ def size_leg(chip, rows, plan, params, inflight, n_ticks=240, warm=20):
     ms, cnt, _, _ = chip.profile_scan()
     chip.profile_enable(False)
     iso_s = ms / 1e3 / max(1, cnt)          # one launch ALONE on one stream, bracketed by hipEvents (profiled pass)
-    step_s = dt / n                          # what a tick costs in the timed loop
+    step_s = dt / n                          # what a tick costs in the pipelined loop
+    # synchronous ticks: enqueue + wait, one at a time (the live system's mode: dot_product_th ticks at 10 Hz, Cerebro.cpp:1100)
+    chip.loop_reset()
+    lat = []
+    for i, l in enumerate(ls[warm:warm + 60]):
+        t1 = time.perf_counter()
+        r = chip.loop_tick(l, params)
+        lat.append(time.perf_counter() - t1)
+        assert r.status == 2
+    lat = np.array(lat[10:])
     alg = 4.0 * D * rows
     cache_resident = alg <= 256 * 2**20
-    # Short scans alternate between two scan streams in the timed loop (chip_api.hip enqueue_scan_merge), so consecutive launches
-    # overlap there: the rate the hardware sustains is algorithmic bytes / STEP time.  The profiled pass keeps every launch on one
-    # stream so that a per-launch duration exists at all; it includes the ramp-up / ramp-down the overlap hides and is reported
-    # next to it, never as `achieved`.
-    gaps = np.diff(np.array(stamps))
-    return {"db_rows": rows, "value": n / dt, "unit": "loop-queries/s", "ms_per_step": 1e3 * step_s,
-            "ms_per_step_median": 1e3 * float(np.median(gaps)) if gaps.size else None, "steps": n,
-            "roofline": {"bound": "hbm" if not cache_resident else "hbm (the 164 MB prefix is Infinity-Cache sized, 256 MiB; a pure reader of such a buffer peaks at 7.3 TB/s on this part, profiles/r03_tick_timeline_10k.md)",
-                         "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS,
-                         "priced_from": "ms_per_step of the timed loop (launches of consecutive ticks overlap on two scan streams)",
-                         "kernel_overlap": True,
-                         "traffic": None, "kernel": "db_scan_topk_rows (row-batched form, R = 1, temporal loads: prefixes <= 768 MiB)" if alg <= 768 * 2**20 else "db_scan_topk",
-                         "isolated_kernel_ms": iso_s * 1e3, "isolated_kernel_note": "one launch alone on one stream between two hipEvents "
-                         "(profiled pass, no overlap): >= ms_per_step by the ramp-up / ramp-down that overlapping launches hide",
-                         "launches": cnt, "algorithmic_bytes_per_launch": alg, "cache_resident": cache_resident}}
+    rows_form = alg <= 768 * 2**20
+    return {"db_rows": rows, "value": n / dt, "unit": "loop-queries/s", "ms_per_step": 1e3 * step_s, "steps": n,
+            "sync_tick_us": 1e6 * float(lat.mean()), "sync_tick_us_min": 1e6 * float(lat.min()),
+            "roofline": {"bound": "hbm" if not cache_resident else "hbm (the 164 MB prefix is Infinity-Cache sized, 256 MiB: part of every re-read is served by the "
+                                  "MALL, so `traffic` counts fabric requests, not DRAM bytes; a pure reader of such a buffer peaks at 7.3 TB/s on this part, profiles/r03_tick_timeline_10k.md)",
+                         "achieved": alg / iso_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / iso_s / 1e9 / HBM_PEAK_GBS,
+                         "frac_kernel": alg / iso_s / 1e9 / HBM_PEAK_GBS, "achieved_kernel": alg / iso_s / 1e9,
+                         "frac_step": alg / step_s / 1e9 / HBM_PEAK_GBS, "achieved_step": alg / step_s / 1e9,
+                         "priced_from": "achieved / frac / frac_kernel: algorithmic bytes / isolated_kernel_ms (one launch alone, hipEvents on its stream); "
+                                        "achieved_step / frac_step: algorithmic bytes / ms_per_step of the pipelined loop, where the launches of consecutive "
+                                        "ticks overlap on four tick streams (the ramp-up of one hides under the drain of the previous)",
+                         "kernel_overlap_in_step": True,
+                         "traffic": sizes_traffic(rows),
+                         "traffic_source": "profiles/scan_traffic_sizes.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this launch shape, synchronous ticks, separate run)"
+                                           if sizes_traffic(rows) is not None else None,
+                         "kernel": "db_scan_topk_rows (row-batched form, R = 1, temporal loads: prefixes <= 768 MiB; the synchronous and the pipelined "
+                                   "tick run it fused: one launch per tick)" if rows_form else "db_scan_topk",
+                         "isolated_kernel_ms": iso_s * 1e3, "launches": cnt, "algorithmic_bytes_per_launch": alg, "cache_resident": cache_resident}}
 
 
 def main():
@@ -375,6 +440,8 @@ def main():
                          "scaling) instead of the default N-way row shard of BASELINE config 4")
     ap.add_argument("--force-sharded", action="store_true",
                     help="testing aid: run the sharded code path (scan -> local merge -> RCCL all-gather -> merge) even with 1 rank")
+    ap.add_argument("--force-group", action="store_true",
+                    help="testing aid for a 1-GPU box: run the one-process group ctx (chip_create_multi, ncclCommInitAll) even with --gpus 1")
     ap.add_argument("--same-device", action="store_true",
                     help="testing aid for a 1-GPU box: one process, --gpus N sub-contexts all on device 0 (device-copy exchange)")
     ap.add_argument("--host-exchange", action="store_true",
@@ -387,7 +454,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    group_mode = world == 1 and args.gpus > 1           # one process drives all GPUs (chip_create_multi)
+    group_mode = world == 1 and (args.gpus > 1 or args.force_group)   # one process drives all GPUs (chip_create_multi)
     if world > 1 and world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     dist = None
@@ -417,7 +484,7 @@ def main():
     # longer scans, so the longer plans keep their revisited rows out of those windows
     # (29k rows = the reference's own capacity, Cerebro.cpp:946)
     leg_rows = [r for r in (10_000, 29_000, 100_000) if r + 4000 < args.rows] if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 \
-        and not args.no_sizes and not args.force_sharded else []
+        and not args.no_sizes and not args.force_sharded and not args.force_group else []
     windows = [(r, r + LAG + 3 * 260 + 3) for r in leg_rows]
     ls, plants, expect = plan_ticks(args.rows, n_ticks, avoid=windows)
     total_rows = ls[-1]
@@ -434,19 +501,39 @@ def main():
     global D
     D = args.dim
     storage = None if args.storage == "f32" else "f64"
+    abandon_process = False
+    group_fallback = None
     if group_mode:
         ndev = torch.cuda.device_count()
         devices = [0] * args.gpus if args.same_device else list(range(args.gpus))
         if not args.same_device and ndev < args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but only {ndev} device(s) visible (use --same-device for a functional run)")
+
+        def make_group(copy_exchange):
+            if os.environ.get("BENCH_HANG_GROUP_CREATE") and not copy_exchange:   # test hook: a create that never returns
+                time.sleep(1e6)
+            return capi.Chip(D, capacity_hint=total_rows, devices=devices, storage=storage, copy_exchange=copy_exchange)
+
+        # chip_create_multi -> ncclCommInitAll is a blocking bootstrap.  The library runs it under its own deadline
+        # (CHIP_COMM_INIT_TIMEOUT_MS) and falls back to the device-copy exchange; the create as a whole runs under a second, outer
+        # deadline here, so that whatever hangs inside it costs this run its RCCL exchange, not its JSON line.
+        os.environ.setdefault("CHIP_COMM_INIT_TIMEOUT_MS", str(int(1000 * float(os.environ.get("BENCH_COMM_INIT_TIMEOUT", "180")))))
         with c_stdout_to_stderr():
-            chip = capi.Chip(D, capacity_hint=total_rows, devices=devices, storage=storage)
+            fin, chip, exc = call_with_deadline(lambda: make_group(False), float(os.environ.get("BENCH_GROUP_CREATE_TIMEOUT", float(os.environ.get("BENCH_COMM_INIT_TIMEOUT", "180")) + 60.0)))
+        if not fin or exc is not None:
+            why = "did not return within its deadline" if not fin else f"failed: {exc}"
+            sys.stderr.write(f"[bench] chip_create_multi over RCCL {why}: rebuilding the group with the device-copy exchange\n")
+            group_fallback = "create hung" if not fin else "create failed"
+            abandon_process = not fin
+            chip = make_group(True)
+        elif chip.info().get("comm_init_abandoned"):
+            abandon_process = True      # a helper thread of the library is still inside ncclCommInitAll
+            group_fallback = "ncclCommInitAll hung (abandoned at the library's deadline)"
     else:
         chip = capi.Chip(D, capacity_hint=total_rows, device=local_rank, shard_rank=0 if replicated else rank,
                          shard_count=1 if replicated else world, storage=storage)
     det = None
     exchange = "none"
-    abandon_process = False
     if (world > 1 and not replicated) or args.force_sharded:
         if args.host_exchange:
             if dist is None:
@@ -476,12 +563,15 @@ def main():
                     attach["ok"] = True
                 except capi.ChipError as e:   # e.g. RCCL refusing the topology
                     attach["err"] = e
+                    # the library's own deadline (CHIP_COMM_INIT_TIMEOUT_MS) fired: ncclCommInitRank is still running on its helper
+                    attach["hung"] = bool(chip.info().get("comm_init_abandoned"))
 
+            os.environ.setdefault("CHIP_COMM_INIT_TIMEOUT_MS", str(int(1000 * float(os.environ.get("BENCH_COMM_INIT_TIMEOUT", "180")))))
             with c_stdout_to_stderr():
                 th = threading.Thread(target=attach_comm, daemon=True)
                 th.start()
-                th.join(float(os.environ.get("BENCH_COMM_INIT_TIMEOUT", "180")))
-            comm_hung = th.is_alive()
+                th.join(float(os.environ.get("BENCH_COMM_INIT_TIMEOUT", "180")) + 30.0)
+            comm_hung = th.is_alive() or bool(attach.get("hung"))
             ok = 1 if attach.get("ok") else 0
             if comm_hung:
                 sys.stderr.write(f"[bench rank {rank}] chip_comm_init_rank did not return within its deadline\n")
@@ -525,57 +615,104 @@ def main():
                 exchange = "host-driven fallback: torch.distributed all_gather_into_tensor (nccl) after chip_comm_init_rank failed"
     elif group_mode:
         exchange = {capi.CHIP_EXCHANGE_RCCL: "in-library RCCL (ncclCommInitAll, one worker thread per device)",
-                    capi.CHIP_EXCHANGE_COPY: "in-library device copies (devices repeat: RCCL refuses two ranks on one device)"}[chip.info()["exchange"]]
-    info = chip.info()
-    wanted_rccl = ((world > 1 and not replicated) or args.force_sharded or (group_mode and not args.same_device)) and not args.host_exchange
-    rccl_ranks = int(info.get("comm_ranks", 0))           # ncclCommCount of the communicator the library's exchange runs over
-    exchange_fallback = bool(wanted_rccl and rccl_ranks != (args.gpus if group_mode else world))
-    t_fill = time.perf_counter()
-    chip.append_synthetic(total_rows, SEED, plants)
-    t_fill = time.perf_counter() - t_fill
+                    capi.CHIP_EXCHANGE_COPY: "in-library device copies" + (" (devices repeat: RCCL refuses two ranks on one device)" if args.same_device else
+                                                                          f" -- FALLBACK, RCCL was asked for: {group_fallback or 'ncclCommInitAll failed: ' + str(chip.last_comm_error())}")}[chip.info()["exchange"]]
     params = capi.default_dot_params()
 
+    def fill(c):
+        t = time.perf_counter()
+        c.append_synthetic(total_rows, SEED, plants)
+        return time.perf_counter() - t
+
+    t_fill = fill(chip)
+
     def barrier():
-        torch.cuda.synchronize()
+        # device-wide synchronisation only while nothing of this process is stuck on the device: after a fallback an abandoned
+        # collective may still sit in a stream of the old ctx, and torch.cuda.synchronize() would wait for it for ever
+        if not abandon_process:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         chip.synchronize()
 
-    if det is None:
-        def run(tick_ls, stamps=None):
-            return run_ticks(chip, tick_ls, params, args.inflight, stamps)
-    else:
-        def run(tick_ls, stamps=None):
-            # host-driven exchange: scan(i+1) on the ctx's scan streams overlaps all-gather(i) + merge(i) on torch's stream
-            out = []
-            W = max(1, min(args.inflight, capi.CHIP_MAX_INFLIGHT - 1))
-            pending = []
-            prev = -1
-            for i, l in enumerate(tick_ls):
-                if len(pending) == W:
+    def make_run(chip, det):
+        if det is None:
+            def run(tick_ls):
+                return run_ticks(chip, tick_ls, params, args.inflight)
+        else:
+            def run(tick_ls):
+                # host-driven exchange: scan(i+1) on the ctx's scan streams overlaps all-gather(i) + merge(i) on torch's stream
+                out = []
+                W = max(1, min(args.inflight, capi.CHIP_MAX_INFLIGHT - 1))
+                pending = []
+                prev = -1
+                for i, l in enumerate(tick_ls):
+                    if len(pending) == W:
+                        out.append(det.collect(pending.pop(0)))
+                    s = i % W
+                    if l <= prev:
+                        chip.loop_reset()   # tick positions wrapped
+                    prev = l
+                    st = det.tick_enqueue(l, s, params)
+                    assert st == capi.CHIP_TICK_SCANNED
+                    pending.append(s)
+                while pending:
                     out.append(det.collect(pending.pop(0)))
-                    if stamps is not None:
-                        stamps.append(time.perf_counter())
-                s = i % W
-                if l <= prev:
-                    chip.loop_reset()   # tick positions wrapped
-                prev = l
-                st = det.tick_enqueue(l, s, params)
-                assert st == capi.CHIP_TICK_SCANNED
-                pending.append(s)
-            while pending:
-                out.append(det.collect(pending.pop(0)))
-                if stamps is not None:
-                    stamps.append(time.perf_counter())
-            return out
+                return out
+        return run
 
+    run = make_run(chip, det)
     chip.loop_reset()
     barrier()
-    run(ls[:args.warmup])
+    # Warmup.  On a multi-GPU exchange inside the library it is also the FIRST execution of the collective (ncclAllGather over
+    # xGMI between real devices): it runs under a deadline, and if it does not come back on some rank every rank rebuilds its
+    # context on an exchange that needs no RCCL -- the run still ends with a JSON line, and the line says what happened.
+    guarded = det is None and ((world > 1 and not replicated) or args.force_sharded or group_mode) and info_exchange(chip) != capi.CHIP_EXCHANGE_NONE
+
+    def warm():
+        if os.environ.get("BENCH_HANG_WARMUP") and guarded and info_exchange(chip) == capi.CHIP_EXCHANGE_RCCL:   # test hook
+            time.sleep(1e6)
+        return run(ls[:args.warmup])
+
+    runtime_fallback = None
+    if guarded:
+        fin, _, exc = call_with_deadline(warm, float(os.environ.get("BENCH_WARMUP_TIMEOUT", "120")))
+        okw = 1 if (fin and exc is None) else 0
+        if dist is not None:
+            flag = torch.tensor([okw], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            okw = int(flag[0].item())
+        if not okw:
+            why = "did not finish within its deadline" if not fin else (f"failed: {exc}" if exc is not None else "failed on another rank")
+            sys.stderr.write(f"[bench rank {rank}] warmup over the in-library exchange {why}: rebuilding on a fallback exchange\n")
+            abandon_process = True            # the old ctx (and whatever is stuck in it) is left alone
+            if group_mode:
+                chip = capi.Chip(D, capacity_hint=total_rows, devices=devices, storage=storage, copy_exchange=True)
+                runtime_fallback = f"in-library device copies -- FALLBACK: the warmup over RCCL {why}"
+            else:
+                chip = capi.Chip(D, capacity_hint=total_rows, device=local_rank, shard_rank=rank, shard_count=world, storage=storage)
+                from cerebro_amd.sharded import ShardedLoopDetector
+                if dist is None:
+                    import torch.distributed as dist
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+                    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+                    dist.init_process_group("gloo")
+                det = ShardedLoopDetector(chip, topk=TOPK, device=torch.device("cuda", local_rank))
+                runtime_fallback = f"host-driven fallback: torch.distributed all_gather_into_tensor ({dist.get_backend()}) -- the warmup over in-library RCCL {why}"
+            exchange = runtime_fallback
+            t_fill = fill(chip)
+            run = make_run(chip, det)
+            chip.loop_reset()
+            run(ls[:args.warmup])
+    else:
+        warm()
+    info = chip.info()
+    wanted_rccl = ((world > 1 and not replicated) or args.force_sharded or (group_mode and not args.same_device)) and not args.host_exchange
+    rccl_ranks = int(info.get("comm_ranks", 0)) if runtime_fallback is None else 0   # ncclCommCount of the communicator the library's exchange runs over
+    exchange_fallback = bool(wanted_rccl and rccl_ranks != (args.gpus if group_mode else world))
     barrier()
-    stamps = []
     t0 = time.perf_counter()
-    results = run(ls[args.warmup:], stamps)
+    results = run(ls[args.warmup:])
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -616,7 +753,6 @@ def main():
                 traffic_source = "profiles/scan_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this launch shape, separate run; not re-measured in this run)"
             except Exception:
                 traffic = None
-        gaps = np.diff(np.array(stamps))
         out = {
             "metric": f"loop-queries/sec (ticks of 3 descriptors vs {D}-D x {fmt_rows(args.rows)} DB)",   # same string at every N; PnP-RANSAC hypotheses/sec: see "pnp" (N = 1)
             "value": (world if replicated else 1) * args.steps / elapsed,   # replicas each run `steps` ticks of their own
@@ -625,7 +761,6 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "ms_per_step_median": 1e3 * float(np.median(gaps)) if gaps.size else None,   # cadence of result collection in steady state (rank 0)
             "higher_is_better": True,
             "scaling": "weak" if replicated else "strong",
             "vs_baseline": None,
@@ -641,6 +776,8 @@ def main():
                        "exchange": exchange,
                        "rccl_ranks": rccl_ranks,                    # 0 = no RCCL communicator inside the library
                        "exchange_fallback": exchange_fallback,      # True: RCCL was asked for and did NOT carry the exchange of all ranks
+                       "exchange_runtime_fallback": runtime_fallback,   # not None: the first collective (warmup) hung / failed and the run was rebuilt on another exchange
+                       "comm_init_abandoned": bool(info.get("comm_init_abandoned")) or abandon_process,   # something of this process is still stuck in RCCL: it leaves through os._exit
                        "control_plane": (dist.get_backend() if dist is not None else None),
                        "sharding": "single GPU" if n_gpus == 1 else (f"{world} replicas of the whole DB, independent tick streams, no collective" if replicated
                                                                      else f"row round-robin over {n_gpus} GPUs + all-gather of top-k"),
@@ -657,7 +794,7 @@ def main():
         if size_plans:
             out["sizes"] = {fmt_rows(r): size_leg(chip, r, plan, params, args.inflight) for r, plan in sorted(size_plans.items())}
             out["sizes"][fmt_rows(args.rows)] = {"db_rows": args.rows, "value": out["value"], "unit": "loop-queries/s", "ms_per_step": out["ms_per_step"],
-                                                 "ms_per_step_median": out["ms_per_step_median"], "steps": args.steps,
+                                                 "steps": args.steps,
                                                  "roofline": out["roofline"]}
         if n_gpus == 1 and world == 1 and not args.no_pnp:
             out["pnp"] = pnp_leg(chip, min(args.cpu_budget, 5.0))
@@ -665,25 +802,31 @@ def main():
             out["batch"] = batch_leg(chip, args.rows)
         if n_gpus == 1 and world == 1 and args.cpu_budget > 0:
             eig = eigen_baseline(args.cpu_sample, min(args.cpu_budget, 10.0))
-            cols_per_s, n, dt = cpu_baseline(args.cpu_sample, args.cpu_budget)
-            if eig is not None:   # the reference's own Eigen statements, on this host: the headline CPU figure when available
+            cols_per_s, n, dt = cpu_baseline(args.cpu_sample, args.cpu_budget * 2 / 3, "eigen")
+            if eig is not None:   # the reference's own Eigen statements, on this host
                 out["cpu_baseline_eigen"] = {"value": eig[0] / args.rows, "unit": "loop-queries/s", "cores": 1, "kind": "eigen",
                                              "sample": f"{eig[1]} ticks of the literal Eigen {eig[3]} statements (Cerebro.cpp:1026-1043) over a "
                                                        f"{args.cpu_sample}-column x {D} MatrixXd ({eig[2]:.1f} s), g++ -O3 -DNDEBUG without -march "
                                                        f"(the reference's Release flags), scaled to {args.rows} columns"}
             out["eigen_probe"] = "Eigen found: cpu_baseline_eigen is the reference's own statements" if eig is not None else \
-                "no <Eigen/Dense> on this host (searched EIGEN3_INCLUDE_DIR, /usr/include/eigen3, /usr/local/include/eigen3, /opt/*): cpu_baseline is the port"
+                "no <Eigen/Dense> on this host (searched EIGEN3_INCLUDE_DIR, /usr/include/eigen3, /usr/local/include/eigen3, /opt/*): cpu_baseline is the Eigen-order port"
+            host = f"host has {os.cpu_count()} logical CPUs ({usable_cpus()} usable under the cgroup quota)"
             out["cpu_baseline"] = {"value": cols_per_s / args.rows, "unit": "loop-queries/s", "cores": 1, "kind": "port",
-                                   "sample": f"{n} ticks of 3 fp64 GEMVs over a {args.cpu_sample}-column x 4096 column-major M "
-                                             f"({dt:.1f} s), scaled to {args.rows} columns; sequential-order port (one s += q[e]*col[e] "
-                                             "chain per column, -O2 -ffp-contract=off: does not vectorise; Eigen itself is probed at run time: see eigen_probe), "
-                                             f"its GEMV would use packet accumulators; host has {os.cpu_count()} logical CPUs ({usable_cpus()} usable under the cgroup quota), "
-                                             "reference path is single-threaded (Eigen without OpenMP)"}
+                                   "port_of": "eigen-order port: Eigen 3.3 row-major GEMV as the reference's SSE2 Release build runs it (four rows at a "
+                                              "time, one Packet2d accumulator each, mul + add, predux, scalar tail; oracle/dot_scan.c "
+                                              "orc_ref_scan_f64_eigen_gemv3, bit-identical to the order emulation: tests/test_oracle_eigen_order.py)",
+                                   "sample": f"{n} ticks of 3 separate fp64 GEMVs + maxCoeff + last-index argmax over a {args.cpu_sample}-column x "
+                                             f"{D} column-major M ({dt:.1f} s), scaled to {args.rows} columns; single thread like the reference's "
+                                             f"dot_product_th (Eigen without OpenMP); {host}"}
+            cols_c, n_c, dt_c = cpu_baseline(args.cpu_sample, args.cpu_budget / 3, "chain")
+            out["cpu_baseline_chain"] = {"value": cols_c / args.rows, "unit": "loop-queries/s", "cores": 1, "kind": "port",
+                                         "sample": f"{n_c} ticks ({dt_c:.1f} s) of the sequential-order port (one s += q[e]*col[e] chain per column, -O2 "
+                                                   "-ffp-contract=off: does not vectorise) -- the secondary figure, the slowest faithful restatement"}
             ac_cols = max(args.cpu_sample, 200_000)      # 6.5 GB of fp64: large enough to defeat the host caches
             cols_per_s, n, dt, nt = cpu_baseline_all_cores(ac_cols, min(args.cpu_budget, 6.0))
             out["cpu_baseline_all_cores"] = {"value": cols_per_s / args.rows, "unit": "loop-queries/s", "cores": nt, "kind": "port",
-                                             "sample": f"{n} ticks over a {ac_cols}-column x 4096 fp64 M ({dt:.1f} s), OpenMP static "
-                                                       f"over columns, same sequential-order port, scaled to {args.rows} columns; {os.cpu_count()} logical CPUs visible, "
+                                             "sample": f"{n} ticks over a {ac_cols}-column x {D} fp64 M ({dt:.1f} s), the same Eigen-order port with OpenMP "
+                                                       f"static over columns, scaled to {args.rows} columns; {os.cpu_count()} logical CPUs visible, "
                                                        f"{nt} usable under the affinity mask / cgroup quota"}
         print(json.dumps(out), flush=True)
 

@@ -86,7 +86,7 @@ class Info(C.Structure):
                 ("shard_count", C.c_int32), ("n_cus", C.c_int32), ("rows_global", C.c_int64),
                 ("rows_local", C.c_int64), ("capacity_local", C.c_int64), ("lossy_rows", C.c_int64),
                 ("arch", C.c_char * 32), ("storage_bytes", C.c_int32), ("n_devices", C.c_int32), ("exchange", C.c_int32),
-                ("comm_ranks", C.c_int32)]
+                ("comm_ranks", C.c_int32), ("comm_init_abandoned", C.c_int32)]
 
 
 # every symbol include/cerebro_hip.h declares: name -> (restype, argtypes)
@@ -271,6 +271,12 @@ class Chip:
                 raise ChipError(st, where, f"ncclResult {r}: {txt.value.decode() if txt.value else ''}")
             hip = self.lib.chip_last_hip_error(self.h, C.byref(txt)) if st in (CHIP_ERR_HIP, CHIP_ERR_OOM) else 0
             raise ChipError(st, where, f"hipError {hip}: {txt.value.decode() if txt.value else ''}" if hip else "")
+
+    def last_comm_error(self) -> str:
+        """chip_last_comm_error: "<code>: <text>" of the last RCCL failure (or abandoned bootstrap) this ctx has seen"""
+        txt = C.c_char_p()
+        r = self.lib.chip_last_comm_error(self.h, C.byref(txt))
+        return f"{r}: {txt.value.decode() if txt.value else ''}"
 
     def set_stream(self, stream_ptr: int | None):
         """None -> back to the ctx's private stream; an int is a hipStream_t handle (0 = HIP's null stream)."""

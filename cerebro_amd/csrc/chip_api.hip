@@ -491,6 +491,7 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
     int rc = tick_prepare(c->xchg ? INT64_MAX : n_pub, c->last_l, l, p, &status, &k);
     if (rc != CHIP_OK) return rc;
     s.prev_last_l = c->last_l;
+    s.tick_l = l;
     s.last_l_ptr = &c->last_l;
     if (status != CHIP_TICK_SCANNED) {
         if (status == CHIP_TICK_TOO_SHORT) c->last_l = l;   // :1098 (the else-branch of :1022 still ends the pass)
@@ -530,7 +531,10 @@ int tick_collect_slot(Ctx *c, Slot &s, chip_tick_result *out)
     *out = *s.host;
     s.in_flight = false;
     if (out->status == CHIP_TICK_FAILED) {   // a shard could not take part: the tick had no effect (:1098 was not reached)
-        if (s.last_l_ptr && *s.last_l_ptr > s.prev_last_l) *s.last_l_ptr = s.prev_last_l;
+        // Roll last_l back only while this tick is still the newest one enqueued.  With ticks pipelined, a later tick may have been
+        // enqueued (and may succeed) meanwhile: its commit of last_l stands, exactly as if the reference's sequential loop had
+        // skipped the failed pass and run the next one.
+        if (s.last_l_ptr && *s.last_l_ptr == s.tick_l) *s.last_l_ptr = s.prev_last_l;
         fill_immediate(out, CHIP_TICK_FAILED);
         return CHIP_ERR_SHARD_FAILED;
     }
@@ -1126,6 +1130,7 @@ int chip_get_info(const chip_ctx *c, chip_info *info)
     info->n_devices = c->group ? group_size(c) : 1;
     info->exchange = c->group ? c->group_transport : (c->xchg ? CHIP_EXCHANGE_RCCL : CHIP_EXCHANGE_NONE);
     info->comm_ranks = exchange_comm_ranks(c->group ? r : c);
+    info->comm_init_abandoned = c->comm_init_abandoned;
     return CHIP_OK;
 }
 

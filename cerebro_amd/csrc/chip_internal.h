@@ -71,7 +71,9 @@ struct Slot {
     bool in_flight = false;
     bool immediate = false;             // result already final on host (skipped / too short)
     int64_t prev_last_l = 0;            // last_l before this tick was enqueued ...
-    int64_t *last_l_ptr = nullptr;      // ... and where to restore it if the tick comes back CHIP_TICK_FAILED
+    int64_t tick_l = 0;                 // ... the l this tick committed ...
+    int64_t *last_l_ptr = nullptr;      // ... and where to restore it if the tick comes back CHIP_TICK_FAILED (only while no newer
+                                        //     tick has been enqueued: *last_l_ptr == tick_l)
 };
 
 struct Exchange;   // chip_multi.hip: how a sharded ctx trades its per-shard top-k lists (RCCL communicator / device copies)
@@ -149,7 +151,8 @@ struct Ctx {
     std::vector<char> qconv;                  // host conversion scratch of external query vectors
     int64_t cap_hint = 0;
     int32_t group_transport = 0;              // CHIP_EXCHANGE_* of a group ctx
-    mutable int last_comm = 0;                // last ncclResult_t
+    mutable int last_comm = 0;                // last ncclResult_t (1000: a bootstrap was abandoned at its deadline)
+    int32_t comm_init_abandoned = 0;          // a helper thread of this ctx is still inside an RCCL bootstrap (chip_multi.hip)
     Exchange *xchg = nullptr;                 // non-null: chip_loop_tick* work on this sharded ctx
     Group *group = nullptr;                   // non-null: this ctx is a group of per-device sub-contexts
     Ctx *parent = nullptr;                    // sub-context of a group

@@ -20,7 +20,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <chrono>
 #include <functional>
+#include <memory>
 #include <new>
 #include <thread>
 
@@ -79,6 +81,75 @@ static const Rccl &rccl()
         }                                           \
     } while (0)
 
+// ---- RCCL bootstraps under a deadline ----------------------------------------------------------------------------------------
+// ncclCommInitAll / ncclCommInitRank are blocking rendezvous (sockets, shared memory, peer-access probing): on a node whose RCCL
+// bootstrap cannot complete they do not fail, they HANG -- and with them the caller's process.  Both run on a helper thread here;
+// if the helper has not returned within the deadline (CHIP_COMM_INIT_TIMEOUT_MS, default 120 s) the call is ABANDONED: the helper
+// is detached and keeps whatever it is blocked on, the library carries on without that communicator (a group falls back to the
+// device-copy exchange, chip_comm_init_rank returns CHIP_ERR_COMM), chip_last_comm_error() says so and
+// chip_get_info().comm_init_abandoned is set, so that the caller knows an orderly process teardown may block (leave through
+// _exit).  Everything the helper touches lives in a shared_ptr'd job: it stays valid however late the helper wakes up.
+constexpr int kCommInitTimedOut = 1000;     // last_comm value of an abandoned bootstrap (not an ncclResult_t)
+
+struct CommInitJob {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false, abandoned = false;
+    ncclResult_t result = ncclSuccess;
+    std::vector<ncclComm_t> comms;
+    std::vector<int> devices;
+    ncclUniqueId id;
+    int n_ranks = 0, rank = 0, device = 0;
+    bool all = false;                        // ncclCommInitAll over `devices` / ncclCommInitRank(rank of n_ranks) on `device`
+};
+
+// Fault injection for the two bootstraps: CHIP_TEST_COMM_INIT=hang | fail.  A test hook inside a production library is announced
+// on stderr every time it fires -- a stray environment variable must not degrade a deployed process silently.
+static int comm_init_test_hook()
+{
+    const char *t = std::getenv("CHIP_TEST_COMM_INIT");
+    if (!t || !*t) return 0;
+    const int mode = std::strcmp(t, "hang") == 0 ? 1 : std::strcmp(t, "fail") == 0 ? 2 : 0;
+    if (mode) std::fprintf(stderr, "[cerebro_hip] TEST HOOK ACTIVE: CHIP_TEST_COMM_INIT=%s -- the RCCL bootstrap is made to %s\n", t, mode == 1 ? "hang" : "fail");
+    return mode;
+}
+
+static int comm_init_timeout_ms()
+{
+    const int v = env_int("CHIP_COMM_INIT_TIMEOUT_MS", 120000);
+    return v > 0 ? v : 120000;
+}
+
+// returns true when the helper finished in time (job->result / job->comms are final), false when it was abandoned
+static bool comm_init_run(const std::shared_ptr<CommInitJob> &job)
+{
+    std::thread([job] {
+        ncclResult_t r;
+        const int hook = comm_init_test_hook();
+        if (hook == 1) {
+            for (;;) std::this_thread::sleep_for(std::chrono::hours(1));   // a bootstrap that never returns
+        } else if (hook == 2) {
+            r = ncclSystemError;
+        } else if (job->all) {
+            r = rccl().CommInitAll(job->comms.data(), (int)job->devices.size(), job->devices.data());
+        } else {
+            r = hipSetDevice(job->device) == hipSuccess ? rccl().CommInitRank(&job->comms[0], job->n_ranks, job->id, job->rank) : ncclUnhandledCudaError;
+        }
+        std::lock_guard<std::mutex> lk(job->m);
+        job->result = r;
+        job->done = true;
+        // nobody is waiting any more: the communicators are left alone (destroying a clique whose creator has moved on to the copy
+        // exchange could block again); the job, and with it this record of them, is released with the last reference
+        job->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(job->m);
+    if (job->cv.wait_for(lk, std::chrono::milliseconds(comm_init_timeout_ms()), [&] { return job->done; })) return true;
+    job->abandoned = true;
+    std::fprintf(stderr, "[cerebro_hip] %s did not return within %d ms (CHIP_COMM_INIT_TIMEOUT_MS): abandoned\n",
+                 job->all ? "ncclCommInitAll" : "ncclCommInitRank", comm_init_timeout_ms());
+    return false;
+}
+
 // Per-shard list buffers.  A tick's buffers are picked by a running counter modulo kXRing (>= the number of ticks a caller
 // can keep in flight), so the buffers of tick i are not rewritten before its merge has run -- no backward dependencies
 // between the streams of different devices.
@@ -114,7 +185,10 @@ static int exchange_create(Ctx *c, int world, bool need_gathered)
     }
     if (const char *t = std::getenv("CHIP_TEST_FAIL_SHARD")) {
         int r = -1, every = 0;
-        if (std::sscanf(t, "%d:%d", &r, &every) == 2 && r == c->rank && every > 0) x->test_fail_every = every;
+        if (std::sscanf(t, "%d:%d", &r, &every) == 2 && r == c->rank && every > 0) {
+            x->test_fail_every = every;
+            std::fprintf(stderr, "[cerebro_hip] TEST HOOK ACTIVE: CHIP_TEST_FAIL_SHARD=%s -- shard %d fails every %d-th collective call\n", t, r, every);
+        }
     }
     return CHIP_OK;
 }
@@ -589,6 +663,7 @@ int group_tick_enqueue(Ctx *gc, int64_t l, const chip_dot_params *p, int32_t slo
     int rc = tick_prepare(n, gc->last_l, l, p, &status, &k);
     if (rc != CHIP_OK) return rc;
     s.prev_last_l = gc->last_l;
+    s.tick_l = l;
     s.last_l_ptr = &gc->last_l;
     if (status != CHIP_TICK_SCANNED) {
         if (status == CHIP_TICK_TOO_SHORT) gc->last_l = l;
@@ -689,7 +764,10 @@ int chip_last_comm_error(const chip_ctx *ctx, const char **text)
     if (ctx->group)
         for (const chip_ctx *s : ctx->group->subs)
             if (s->last_comm) r = s->last_comm;
-    if (text) *text = rccl().ok ? rccl().GetErrorString((ncclResult_t)r) : (r ? "librccl could not be loaded (dlopen): no RCCL exchange available" : "no error");
+    if (text) {
+        if (r == kCommInitTimedOut) *text = "RCCL bootstrap (ncclCommInitAll / ncclCommInitRank) did not return within CHIP_COMM_INIT_TIMEOUT_MS: abandoned";
+        else *text = rccl().ok ? rccl().GetErrorString((ncclResult_t)r) : (r ? "librccl could not be loaded (dlopen): no RCCL exchange available" : "no error");
+    }
     return r;
 }
 
@@ -725,17 +803,26 @@ int chip_create_multi(chip_ctx **out, int32_t D, int64_t capacity_hint, const in
         rc = exchange_create(s, n_devices, G->transport == CHIP_EXCHANGE_RCCL || g == 0);
     }
     if (rc == CHIP_OK && G->transport == CHIP_EXCHANGE_RCCL) {
-        std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
-        const ncclResult_t r = rccl().ok ? rccl().CommInitAll(comms.data(), n_devices, devices) : ncclSystemError;   // no librccl: copy exchange
-        if (r != ncclSuccess) {
-            // No communicator (RCCL absent / misconfigured, peer access refused ...): the lists are 384 B per device and tick, so
-            // the device-copy exchange is a full substitute -- fall back to it instead of failing the create; the ncclResult_t
-            // stays readable through chip_last_comm_error and chip_get_info reports CHIP_EXCHANGE_COPY.
-            gc->last_comm = (int)r;
+        int r = (int)ncclSystemError;          // no librccl: copy exchange
+        std::shared_ptr<CommInitJob> job;
+        if (rccl().ok) {
+            job = std::make_shared<CommInitJob>();
+            job->all = true;
+            job->devices.assign(devices, devices + n_devices);
+            job->comms.assign((size_t)n_devices, nullptr);
+            if (comm_init_run(job)) r = (int)job->result;
+            else { r = kCommInitTimedOut; gc->comm_init_abandoned = 1; }
+        }
+        if (r != (int)ncclSuccess) {
+            // No communicator (RCCL absent / misconfigured, peer access refused, a bootstrap that hangs ...): the lists are 384 B per
+            // device and tick, so the device-copy exchange is a full substitute -- fall back to it instead of failing (or hanging)
+            // the create; the reason stays readable through chip_last_comm_error, chip_get_info reports CHIP_EXCHANGE_COPY.
+            gc->last_comm = r;
             G->transport = CHIP_EXCHANGE_COPY;
             gc->group_transport = CHIP_EXCHANGE_COPY;
+            (void)hipSetDevice(devices[0]);
         } else
-            for (int g = 0; g < n_devices; g++) G->subs[(size_t)g]->xchg->comm = comms[(size_t)g];
+            for (int g = 0; g < n_devices; g++) G->subs[(size_t)g]->xchg->comm = job->comms[(size_t)g];
     }
     if (rc == CHIP_OK) {
         G->workers.assign((size_t)n_devices, nullptr);
@@ -776,9 +863,16 @@ int chip_comm_init_rank(chip_ctx *c, const void *id_in, int32_t n_ranks, int32_t
     if (!c->own_query_stream) return CHIP_ERR_UNSUPPORTED;   // chip_set_stream and an in-library exchange exclude each other
     ncclUniqueId id;
     std::memcpy(&id, id_in, sizeof id);
-    ncclComm_t comm = nullptr;
     if (!rccl().ok) { c->last_comm = (int)ncclSystemError; return CHIP_ERR_COMM; }
-    CHIP_NCCL(c, rccl().CommInitRank(&comm, n_ranks, id, rank));
+    auto job = std::make_shared<CommInitJob>();
+    job->id = id;
+    job->n_ranks = n_ranks;
+    job->rank = rank;
+    job->device = c->device;
+    job->comms.assign(1, nullptr);
+    if (!comm_init_run(job)) { c->last_comm = kCommInitTimedOut; c->comm_init_abandoned = 1; return CHIP_ERR_COMM; }
+    if (job->result != ncclSuccess) { c->last_comm = (int)job->result; return CHIP_ERR_COMM; }
+    ncclComm_t comm = job->comms[0];
     const int rc = exchange_create(c, n_ranks, true);
     if (rc != CHIP_OK) { (void)rccl().CommDestroy(comm); exchange_destroy(c); return rc; }
     c->xchg->comm = comm;

@@ -481,19 +481,29 @@ __device__ __forceinline__ void fused_tick_finish(const ScanArgs &a, char *smem,
     // This workgroup's entries went out as write-through (agent-scope) stores; once they have completed (vmcnt(0)) they are visible
     // device-wide, and the ticket may be taken.  No __threadfence(): an agent-scope release fence writes back this XCD's L2 -- with
     // 256-512 workgroups doing it the tick took 120 us instead of 25 (measured; it is also why round 2's fused merge lost).
+    //   Writers (every workgroup): what stands in for the release is an ISA property of gfx942 / gfx950, not the HIP memory model --
+    //   an sc1 (agent-scope) store is written THROUGH its XCD's L2 to the fabric, and its vmcnt slot is only returned when the
+    //   write has been acknowledged there; "s_waitcnt vmcnt(0)" + the workgroup barrier therefore order this workgroup's entries
+    //   before its ticket increment for every agent-scope observer.  The code object is gfx950-only (chip_create refuses anything
+    //   else), and tests/test_scan_gpu.py::test_fused_tick_handoff_stress compares >= 200k fused ticks with the two-launch path.
+    //   Reader (ONE workgroup): a real agent-scope ACQUIRE after the ticket is won -- it invalidates this XCD's non-coherent L2
+    //   lines and the CU's vector L1 (buffer_inv sc1), so no entry of the launch that used this list buffer 64 ticks ago can be
+    //   served from a cache; one workgroup per tick pays it, which is free (the 120 us were 256-512 workgroups RELEASING).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) *last = atomicAdd(a.fused_ticket, 1) == (int)gridDim.x - 1;
+    if (tid == 0) *last = __hip_atomic_fetch_add(a.fused_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
     __syncthreads();
     if (!*last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     double bs[NQ];
     int64_t bi[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
         bs[q] = -INFINITY; bi[q] = -1;
-        if (tid < (int)gridDim.x) {
-            const chip_topk_entry e = load_entry_agent(a.partial + ((int64_t)tid * NQ + q) * K);   // bypasses this XCD's L2
-            bs[q] = e.score; bi[q] = e.idx;
+        // one entry per workgroup of the launch; grid-stride, so a block smaller than the grid (CHIP_SCAN_BLOCK=256) drops nothing
+        for (int wg = tid; wg < (int)gridDim.x; wg += (int)blockDim.x) {
+            const chip_topk_entry e = load_entry_agent(a.partial + ((int64_t)wg * NQ + q) * K);   // bypasses this XCD's L2
+            if (key_gt(e.score, e.idx, bs[q], bi[q])) { bs[q] = e.score; bi[q] = e.idx; }
         }
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CHIP_ABI_VERSION 3
+#define CHIP_ABI_VERSION 4
 
 /* ------------------------------------------------------------------------------------------ status codes */
 enum {
@@ -116,8 +116,11 @@ int  chip_create_ex(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t de
  *     copies (lists written / copied straight into the root's gather buffer behind events) when CHIP_MULTI_EXCHANGE_COPY is
  *     passed or the list names a device twice (RCCL refuses two ranks on one device) -- the latter lets a 1-GPU box run the
  *     G = 2..8 code path.  RCCL is loaded with dlopen (librccl.so.1, or $CHIP_RCCL_LIBRARY), the library does not link it: if it
- *     is absent or cannot build the communicator the create does not fail, it falls back to the copy exchange
- *     (chip_get_info().exchange / .comm_ranks tell which one is in use and over how many ranks, chip_last_comm_error() why).
+ *     is absent, cannot build the communicator, or its bootstrap does not return within CHIP_COMM_INIT_TIMEOUT_MS (default
+ *     120 s; the blocking rendezvous runs on a helper thread and is abandoned at the deadline) the create neither fails nor
+ *     hangs, it falls back to the copy exchange (chip_get_info().exchange / .comm_ranks / .comm_init_abandoned tell which one
+ *     is in use, over how many ranks, and whether a helper is still stuck; chip_last_comm_error() why).  chip_comm_init_rank
+ *     has the same deadline: it returns CHIP_ERR_COMM instead of hanging.
  * (b) one process PER GPU (torchrun-style launch): create each rank's ctx with chip_create(.., shard_rank, shard_count),
  *     then attach an RCCL communicator: rank 0 calls chip_comm_unique_id, distributes the 128 bytes by any means, every
  *     rank calls chip_comm_init_rank.  From then on chip_loop_tick / _enqueue / _collect and chip_query_* work on the
@@ -206,7 +209,8 @@ enum { CHIP_TICK_SKIPPED = 0,   /* l - last_l < min_new: nothing done, last_l NO
        CHIP_TICK_TOO_SHORT = 1, /* ran, but k = l - lag <= min_k (:1022 else-branch); last_l = l          */
        CHIP_TICK_SCANNED = 2,   /* scan + decision executed; last_l = l                                   */
        CHIP_TICK_FAILED = 3 };  /* sharded ticks only, never returned with CHIP_OK: a shard could not take part; the collecting
-                                   call returns CHIP_ERR_SHARD_FAILED on every rank and last_l is as before the tick       */
+                                   call returns CHIP_ERR_SHARD_FAILED on every rank and last_l is as before the tick -- unless a
+                                   LATER tick had been enqueued by then (pipelined form): that tick's last_l = l stands      */
 
 typedef struct {
     int32_t status;      /* CHIP_TICK_*                                                                   */
@@ -333,6 +337,10 @@ typedef struct {
     int32_t exchange;           /* CHIP_EXCHANGE_*                                                 */
     int32_t comm_ranks;         /* ranks of the RCCL communicator the exchange runs over (ncclCommCount), 0 = none: a caller
                                    that asked for G GPUs can PROVE the collective spans G ranks (and see a copy fallback) */
+    int32_t comm_init_abandoned;/* 1: an RCCL bootstrap of this ctx (ncclCommInitAll in chip_create_multi, ncclCommInitRank in
+                                   chip_comm_init_rank) did not return within CHIP_COMM_INIT_TIMEOUT_MS (default 120 s) and was
+                                   abandoned on its helper thread; the ctx works (a group: over the copy exchange), but process
+                                   teardown may block inside RCCL -- leave through _exit() once the work is done (ABI 4)      */
 } chip_info;
 enum { CHIP_EXCHANGE_NONE = 0, CHIP_EXCHANGE_RCCL = 1, CHIP_EXCHANGE_COPY = 2 };
 int chip_get_info(const chip_ctx *ctx, chip_info *info);

@@ -117,6 +117,10 @@ double orc_dot_eigen_gemv_f64(const double *v, const double *col, int32_t D, int
 void orc_ref_scan_f64_eigen_order(const double *M, int32_t D, int64_t k, const double *v, const double *vm, const double *vmm,
                                   double *u, double *um, double *umm, double maxv[3], int64_t argmax[3],
                                   int32_t packet, int32_t fma_flag, int32_t nthreads);
+/* The same order in the SHAPE Eigen runs it (four rows at a time, one SSE2 Packet2d accumulator each, three SEPARATE GEMVs):
+ * bit-identical to orc_dot_eigen_gemv_f64(.., packet 2, fma 0, aligned_start 0) per entry; bench.py's headline cpu_baseline. */
+void orc_ref_scan_f64_eigen_gemv3(const double *M, int32_t D, int64_t k, const double *v, const double *vm, const double *vmm,
+                                  double *u, double *um, double *umm, double maxv[3], int64_t argmax[3], int32_t nthreads);
 
 
 /* ================================================================== PnP / RANSAC (pnp_ransac.c) */

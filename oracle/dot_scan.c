@@ -444,3 +444,83 @@ void orc_ref_scan_f64_eigen_order(const double *M, int32_t D, int64_t k, const d
     maxv[0] = a; maxv[1] = b; maxv[2] = c;
     argmax[0] = ia; argmax[1] = ib; argmax[2] = ic;
 }
+
+/* ---------------------------------------------------------------- the Eigen-order GEMV at the speed Eigen runs it (cpu_baseline)
+ * orc_dot_eigen_gemv_f64 above states the ORDER; this states the order AND the shape of Eigen 3.3's row-major GEMV kernel for the
+ * reference's build (GeneralMatrixVector.h, RowMajor specialisation; SSE2, CMakeLists.txt:42-44 has no -march): the "rows" of
+ * M^T (= columns of M, D contiguous doubles each) are taken FOUR at a time with one Packet2d accumulator each -- four independent
+ * mulpd + addpd chains over the shared loads of v -- then predux (a0 + a1) per row, then the tail rows one at a time.  The
+ * blocking changes no row's arithmetic: u[i] equals orc_dot_eigen_gemv_f64(v, M + i*D, D, 2, 0, 0) bit for bit
+ * (tests/test_oracle_eigen_order.py), and this is what bench.py times as the headline CPU figure.  x86-64 only (the GPU boxes'
+ * hosts); elsewhere it falls back to the scalar emulation. */
+#if defined(__SSE2__)
+#include <emmintrin.h>
+static void eigen_gemv_rowmajor_sse2(const double *M, int32_t D, int64_t i0, int64_t i1, const double *v, double *u)
+{
+    const int32_t aligned = D & ~1;
+    int64_t i = i0;
+    for (; i + 4 <= i1; i += 4) {
+        const double *r0 = M + (size_t)i * D, *r1 = r0 + D, *r2 = r1 + D, *r3 = r2 + D;
+        __m128d p0 = _mm_setzero_pd(), p1 = p0, p2 = p0, p3 = p0;
+        for (int32_t j = 0; j < aligned; j += 2) {
+            const __m128d b = _mm_loadu_pd(v + j);
+            p0 = _mm_add_pd(_mm_mul_pd(_mm_loadu_pd(r0 + j), b), p0);   /* pmadd without FMA: padd(pmul(a, b), c) */
+            p1 = _mm_add_pd(_mm_mul_pd(_mm_loadu_pd(r1 + j), b), p1);
+            p2 = _mm_add_pd(_mm_mul_pd(_mm_loadu_pd(r2 + j), b), p2);
+            p3 = _mm_add_pd(_mm_mul_pd(_mm_loadu_pd(r3 + j), b), p3);
+        }
+        double t[4][2];
+        _mm_storeu_pd(t[0], p0); _mm_storeu_pd(t[1], p1); _mm_storeu_pd(t[2], p2); _mm_storeu_pd(t[3], p3);
+        const double *r[4] = {r0, r1, r2, r3};
+        for (int c = 0; c < 4; c++) {
+            double tmp = 0.0;
+            tmp += t[c][0] + t[c][1];                                    /* tmp += predux(ptmp) */
+            for (int32_t j = aligned; j < D; j++) tmp += r[c][j] * v[j];
+            u[i + c] = 0.0 + 1.0 * tmp;                                  /* res[i] += alpha * tmp */
+        }
+    }
+    for (; i < i1; i++) u[i] = orc_dot_eigen_gemv_f64(v, M + (size_t)i * D, D, 2, 0, 0);
+}
+#else
+static void eigen_gemv_rowmajor_sse2(const double *M, int32_t D, int64_t i0, int64_t i1, const double *v, double *u)
+{
+    for (int64_t i = i0; i < i1; i++) u[i] = orc_dot_eigen_gemv_f64(v, M + (size_t)i * D, D, 2, 0, 0);
+}
+#endif
+
+/* Cerebro.cpp:1026-1043 as the reference's build executes it: THREE separate GEMVs (M is streamed three times), three maxCoeff,
+ * one last-index argmax loop.  nthreads = 1 is the reference (its dot_product_th is one thread, Eigen GEMV is not parallel without
+ * OpenMP); nthreads > 1 splits every GEMV's columns statically, results unchanged. */
+void orc_ref_scan_f64_eigen_gemv3(const double *M, int32_t D, int64_t k, const double *v, const double *vm, const double *vmm,
+                                  double *u, double *um, double *umm, double maxv[3], int64_t argmax[3], int32_t nthreads)
+{
+    const double *q[3] = {v, vm, vmm};
+    double *out[3] = {u, um, umm};
+    if (nthreads < 1) nthreads = 1;
+    for (int g = 0; g < 3; g++) {
+        if (nthreads == 1) eigen_gemv_rowmajor_sse2(M, D, 0, k, q[g], out[g]);
+        else {
+#pragma omp parallel num_threads(nthreads)
+            {
+#ifdef _OPENMP
+                const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+                const int t = 0, nt = 1;
+#endif
+                const int64_t per = ((k + nt - 1) / nt + 3) & ~(int64_t)3;   /* whole blocks of four rows per thread */
+                const int64_t a = (int64_t)t * per, b = a + per < k ? a + per : k;
+                if (a < b) eigen_gemv_rowmajor_sse2(M, D, a, b, q[g], out[g]);
+            }
+        }
+    }
+    double a = u[0], b = um[0], c = umm[0];
+    for (int64_t i = 1; i < k; i++) { if (u[i] > a) a = u[i]; if (um[i] > b) b = um[i]; if (umm[i] > c) c = umm[i]; }   /* maxCoeff */
+    int64_t ia = -1, ib = -1, ic = -1;
+    for (int64_t ii = 0; ii < k; ii++) {   /* :1038-1043 */
+        if (u[ii] == a) ia = ii;
+        if (um[ii] == b) ib = ii;
+        if (umm[ii] == c) ic = ii;
+    }
+    maxv[0] = a; maxv[1] = b; maxv[2] = c;
+    argmax[0] = ia; argmax[1] = ib; argmax[2] = ic;
+}

@@ -235,6 +235,21 @@ def ref_scan_f64_eigen_order(M: np.ndarray, k: int, v, vm, vmm, packet: int = 2,
     return maxv, arg, (u, um, umm)
 
 
+def ref_scan_f64_eigen_gemv3(M: np.ndarray, k: int, v, vm, vmm, nthreads: int = 1, scratch=None):
+    """Cerebro.cpp:1026-1043 as the reference's SSE2 Release build runs it: three separate Eigen-shaped GEMVs (four rows at a time,
+    one Packet2d accumulator each), maxCoeff, last-index argmax.  Entries are bit-identical to dot_eigen_gemv(packet=2)."""
+    lib = load()
+    lib.orc_ref_scan_f64_eigen_gemv3.restype = None
+    D = M.shape[1]
+    assert M.dtype == np.float64 and M.flags.c_contiguous
+    v, vm, vmm = (np.ascontiguousarray(x, dtype=np.float64) for x in (v, vm, vmm))
+    u, um, umm = scratch if scratch is not None else (np.empty(k), np.empty(k), np.empty(k))
+    maxv = np.empty(3); arg = np.empty(3, dtype=np.int64)
+    lib.orc_ref_scan_f64_eigen_gemv3(_p(M), C.c_int32(D), C.c_int64(k), _p(v), _p(vm), _p(vmm), _p(u), _p(um), _p(umm), _p(maxv), _p(arg),
+                                     C.c_int32(nthreads))
+    return maxv, arg, (u, um, umm)
+
+
 def dot_eigen_gemv(v, col, packet: int = 2, fma: bool = False, aligned_start: int = 0) -> float:
     lib = load()
     lib.orc_dot_eigen_gemv_f64.restype = C.c_double

@@ -405,15 +405,22 @@ def test_failed_shard_marks_the_tick_for_everyone(monkeypatch):
             chip.loop_reset()
             for s_, l in enumerate(chunk):
                 chip.loop_tick_enqueue(l, s_)
+            last_ok = None
             for s_, l in enumerate(chunk):
                 try:
                     g = chip.loop_tick_collect(s_)
                 except capi.ChipError as e:
                     assert e.status == capi.CHIP_ERR_SHARD_FAILED
                     n_failed += 1
+                    last_ok = False
                     continue
+                last_ok = True
                 stateless.state.last_l = 0
                 same_tick(g, stateless.tick(l))
+            # a failed tick rolls last_l back only while it is the newest one enqueued: the commit of a LATER tick that succeeded
+            # stands (with ticks pipelined the old rollback erased it)
+            if last_ok:
+                assert chip.last_l() == chunk[-1]
         assert n_failed >= 10
         # queries carry the mark too
         seen = 0
@@ -426,3 +433,67 @@ def test_failed_shard_marks_the_tick_for_everyone(monkeypatch):
                 assert e.status == capi.CHIP_ERR_SHARD_FAILED
                 seen += 1
         assert seen >= 1
+
+
+@pytest.mark.parametrize("mode", ["hang", "fail"])
+def test_rccl_bootstrap_under_a_deadline(monkeypatch, mode):
+    """ncclCommInitAll / ncclCommInitRank are blocking rendezvous; on a node where they cannot complete they hang.  The library runs
+    them on a helper thread under CHIP_COMM_INIT_TIMEOUT_MS: a group falls back to the device-copy exchange (same answers), a
+    sharded ctx gets CHIP_ERR_COMM, chip_get_info().comm_init_abandoned says a helper is still stuck.  CHIP_TEST_COMM_INIT makes the
+    bootstrap hang / fail on a healthy box (and says so on stderr)."""
+    import time
+    monkeypatch.setenv("CHIP_TEST_COMM_INIT", mode)
+    monkeypatch.setenv("CHIP_COMM_INIT_TIMEOUT_MS", "1500")
+    D, N = 512, 900
+    plants, loops, _ = scenarios.loop_plants(N, 3, seed=29)
+    db = scenarios.build_db(31, N, D, plants)
+    t0 = time.time()
+    with capi.Chip(D, devices=[0]) as chip:                  # distinct devices -> RCCL transport is asked for
+        assert time.time() - t0 < 60
+        info = chip.info()
+        assert info["exchange"] == capi.CHIP_EXCHANGE_COPY and info["comm_ranks"] == 0
+        assert info["comm_init_abandoned"] == (1 if mode == "hang" else 0)
+        assert ("did not return" in chip.last_comm_error()) == (mode == "hang")
+        chip.append_f32(db)
+        _tick_parity(chip, db, N)
+    with capi.Chip(D) as chip:
+        with pytest.raises(capi.ChipError) as e:
+            chip.comm_init_rank(capi.comm_unique_id(), 1, 0)
+        assert e.value.status == capi.CHIP_ERR_COMM
+        assert chip.info()["comm_init_abandoned"] == (1 if mode == "hang" else 0) and chip.info()["exchange"] == capi.CHIP_EXCHANGE_NONE
+        chip.append_f32(db)                                   # the ctx is an ordinary single-GPU ctx still
+        _tick_parity(chip, db, N)
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 GPUs: hipMemcpyPeerAsync between distinct devices")
+def test_group_copy_exchange_distinct_devices():
+    """CHIP_MULTI_EXCHANGE_COPY over DISTINCT devices: the fallback transport of a group whose RCCL bootstrap hung or failed -- per-device
+    lists pulled into the root's gather buffer with hipMemcpyPeerAsync behind events, query rows fetched from their owners with peer
+    copies.  (On one device the same code path runs with plain device copies; this is the cross-device leg.)"""
+    n = min(_n_gpus(), 8)
+    D, N = 1024, 2400
+    plants, loops, ties = scenarios.loop_plants(N, 6, seed=78)
+    db = scenarios.build_db(4200, N, D, plants)
+    with capi.Chip(D, devices=list(range(n)), copy_exchange=True) as chip:
+        info = chip.info()
+        assert info["n_devices"] == n and info["exchange"] == capi.CHIP_EXCHANGE_COPY and info["comm_ranks"] == 0
+        chip.append_f32(db[:1000])
+        chip.append_f64(db[1000:].astype(np.float64))
+        _tick_parity(chip, db, N)
+        for nq, K in ((1, 1), (3, 8), (4, 16)):
+            rows = [N - 1, N - 2, N - 3, loops[0][1]][:nq]      # loops[0][1]: an old row, fetched from its owner by a peer copy
+            got, want = chip.query_rows(N - 50, rows, K), oracle_lib.scan_topk(db, N - 50, db[rows], K)
+            assert np.array_equal(got[1], want[1]) and np.array_equal(bits(got[0]), bits(want[0]))
+        u = chip.query_scores(N - 50, 7)
+        assert np.array_equal(bits(u), bits(oracle_lib.scores(db, N - 50, db[7])))
+    # BASELINE config 4's shard size over the copy exchange
+    D, N, seed = 4096, 125_000 * n + 53, 20190412
+    l = N
+    q, p = l - 1, N // 2
+    plants = [(q - j, p - j, 1) for j in range(3)] + [(p + 4, p, 2)]
+    with capi.Chip(D, capacity_hint=N, devices=list(range(n)), copy_exchange=True) as chip:
+        chip.append_synthetic(N, seed, plants)
+        r = chip.loop_tick(l)
+        wsc, wix = scenarios.cached_scan_topk_synth(seed, l - 50, D, [l - 1, l - 2, l - 3], 8, plants, nthreads=min(os.cpu_count() or 1, 128))
+        assert r.found == 1 and r.idx_prev == p + 4 and list(r.argmax) == list(wix[:, 0])
+        assert [float(x).hex() for x in r.maxv] == [float(x).hex() for x in wsc[:, 0]]

@@ -158,3 +158,22 @@ def test_where_the_orders_could_differ_is_a_measure_zero_tie():
         sc, ix = oracle_lib.scan_topk(db, l - 50, db[[l - 1]], 2)
         gaps.append(sc[0][0] - sc[0][1])
     assert min(gaps) > 1e-6
+
+
+@pytest.mark.parametrize("D,k", [(4096, 1203), (4095, 301), (130, 77), (2, 9)])
+def test_eigen_shaped_gemv3_is_the_eigen_order_bit_for_bit(D, k):
+    """bench.py's headline cpu_baseline (orc_ref_scan_f64_eigen_gemv3: three separate GEMVs, four rows at a time, one SSE2 Packet2d
+    accumulator per row -- the shape Eigen 3.3's row-major kernel runs in the reference's build) is the Eigen-order emulation bit for
+    bit: every score, the three maxima and the three last-index argmax, single- and multi-threaded, odd D (scalar tail) included."""
+    Dp = D + (D % 4 and 4 - D % 4)
+    M = oracle_lib.synth_rows(11, range(k + 3), Dp)[:, :D].astype(np.float64).copy()
+    M[k // 2] = M[k // 3]                                   # an exact duplicate: the LAST index attaining the maximum must win
+    v, vm, vmm = M[k + 2].copy(), M[k + 1].copy(), M[k // 3].copy()
+    want = oracle_lib.ref_scan_f64_eigen_order(M, k, v, vm, vmm, 2, False)
+    for nt in (1, 3):
+        got = oracle_lib.ref_scan_f64_eigen_gemv3(M, k, v, vm, vmm, nt)
+        for a, b in zip(want[2], got[2]):
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+        assert np.array_equal(want[0].view(np.uint64), got[0].view(np.uint64)) and np.array_equal(want[1], got[1])
+    if D >= 100:                                            # (near-)unit-norm rows: the duplicate of the query row is the maximum
+        assert got[1][2] == k // 2

@@ -361,3 +361,46 @@ def test_sharded_tick_over_rccl_world1():
             det.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_fused_tick_handoff_stress(monkeypatch):
+    """The fused tick's cross-workgroup hand-off (kernels.hip fused_tick_finish: write-through stores + vmcnt(0) + ticket on the
+    writers' side, an agent-scope ACQUIRE + L2-bypassing loads on the last workgroup's side) against the two-launch path
+    (CHIP_TICK_FUSED=0: K1 lists -> K2 merge, ordinary kernel-boundary visibility): >= 200 000 pipelined fused ticks at full grid
+    cycling over THREE query triples -- the list buffers are a ring of 64 and 64 % 3 != 0, so the launch that last used a tick's
+    list buffer had a different triple and different per-workgroup bests in every workgroup: a stale entry read by the reducing
+    workgroup would change argmax / maxv.  Every record is compared byte for byte with the unfused result of the same tick."""
+    import ctypes
+    D, seed = 4096, 77
+    n_rows = 20_200
+    n_ticks = int(os.environ.get("CHIP_STRESS_TICKS", "200000"))
+    # two prefix lengths: 10k rows (cache-sized: half of every CU's workgroup slots, 256 workgroups) and 20k rows (512 workgroups)
+    tick_sets = [[10_050 + 3 * j for j in range(3)], [20_150 + 3 * j for j in range(3)]]
+    plants = [(tick_sets[0][0] - 1 - j, 5000 - j, 1) for j in range(3)] + [(tick_sets[1][1] - 1 - j, 15_000 - j, 1) for j in range(3)]
+    p = capi.default_dot_params()
+    p.min_new = -(1 << 30)                                   # every tick runs, whatever the previous l was
+    monkeypatch.setenv("CHIP_TICK_FUSED", "0")
+    with capi.Chip(D, capacity_hint=n_rows) as ref:
+        ref.append_synthetic(n_rows, seed, plants)
+        want = {l: bytes(ref.loop_tick(l, p)) for ls in tick_sets for l in ls}
+    assert len(set(want.values())) == 6
+    found = [capi.TickResult.from_buffer_copy(w).found for w in want.values()]
+    assert sum(found) == 2
+    monkeypatch.delenv("CHIP_TICK_FUSED")
+    W = 16
+    with capi.Chip(D, capacity_hint=n_rows) as chip:
+        chip.append_synthetic(n_rows, seed, plants)
+        for ls, share in zip(tick_sets, (0.6, 0.4)):
+            n = int(n_ticks * share)
+            pending = []
+            bad = 0
+            for i in range(n):
+                if len(pending) == W:
+                    s, l = pending.pop(0)
+                    bad += bytes(chip.loop_tick_collect(s)) != want[l]
+                l = ls[i % 3]
+                chip.loop_tick_enqueue(l, i % W, p)
+                pending.append((i % W, l))
+            for s, l in pending:
+                bad += bytes(chip.loop_tick_collect(s)) != want[l]
+            assert bad == 0, (ls, bad, n)
