@@ -543,6 +543,7 @@ struct GroupScan {
     const chip_dot_params *p = nullptr; // non-null: tick (decision into slot)
     Slot *slot = nullptr;
     bool tick = false;
+    bool from_ring = false;             // tick whose three query rows are still in every device's replicated ring (the live path)
 };
 
 // Query rows of a group scan on device g.  Ticks read them from the device's replicated ring (the live path: no copy).  Any other
@@ -552,7 +553,7 @@ struct GroupScan {
 static int sub_query_rows(Group *G, int g, const GroupScan &j, const void **q)
 {
     Ctx *c = G->subs[(size_t)g];
-    if (j.tick) return query_row_ptrs(c, j.rows, j.nq, j.n_global, q);
+    if (j.from_ring) return query_row_ptrs(c, j.rows, j.nq, j.n_global, q);
     const size_t rb = (size_t)c->D * c->elem;
     const int ng = (int)G->subs.size();
     for (int i = 0; i < j.nq; i++) {
@@ -594,7 +595,8 @@ static int sub_scan(Group *G, int g, const GroupScan &j, int b, std::atomic<int>
     const bool direct = G->transport == CHIP_EXCHANGE_COPY && G->same_dev[(size_t)g];   // straight into the root's gather buffer
     chip_topk_entry *dst = direct ? root->xchg->gathered(b) + (size_t)g * list : x->local(b);
     int rc;
-    if (!soft) rc = enqueue_scan_merge(c, j.k, q, j.nq, j.K, j.l, nullptr, dst, nullptr, j.tick, nullptr);
+    // (fetched query rows were copied on s_scan: such a scan must run there too, i.e. not as a stream-alternating "tick")
+    if (!soft) rc = enqueue_scan_merge(c, j.k, q, j.nq, j.K, j.l, nullptr, dst, nullptr, j.tick && j.from_ring, nullptr);
     else rc = hipMemcpyAsync(dst, x->failed_list, sizeof(chip_topk_entry) * list, hipMemcpyDeviceToDevice, c->s_query) == hipSuccess ? CHIP_OK : CHIP_ERR_HIP;
     if (rc != CHIP_OK) return fail_hard(rc);
     if (G->transport == CHIP_EXCHANGE_RCCL) {
@@ -672,11 +674,13 @@ int group_tick_enqueue(Ctx *gc, int64_t l, const chip_dot_params *p, int32_t slo
         s.in_flight = true;
         return CHIP_OK;
     }
-    // the documented limit of sharded ticks, the same on every device: the three query rows must still be in the replicated ring
-    if (G->subs.size() > 1 && n - l > CHIP_RING_ROWS - 3) return CHIP_ERR_RANGE;
     const int64_t rows[3] = {l - 1, l - 2, l - 3};  // v, vm, vmm (Cerebro.cpp:987-989)
     GroupScan j;
     j.k = k; j.l = l; j.nq = 3; j.K = CHIP_DEFAULT_TOPK; j.rows = rows; j.n_global = l; j.p = p; j.slot = &s; j.tick = true;
+    // Live ticks trail the append head by a few rows and read their three query rows from every device's replicated ring (no copy).
+    // A tick further back than the ring -- replaying an old schedule over a cold-started DB (cerebro_replay --state --devices ...) --
+    // fetches them from the sub-contexts that own them, exactly as chip_query_rows does; the decision is one, from the group's length.
+    j.from_ring = G->subs.size() == 1 || n - l <= CHIP_RING_ROWS - 3;
     rc = group_scan(G, j);
     if (rc != CHIP_OK) return rc;
     gc->last_l = l;   // :1098

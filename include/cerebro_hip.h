@@ -70,9 +70,11 @@ int chip_last_comm_error(const chip_ctx *ctx, const char **text);
  *
  * Sharding (BASELINE config 4): with shard_count = G > 1 the ctx of rank r stores global rows i with
  * i % G == r (round-robin keeps every prefix [0,k) balanced) plus a replicated ring of the most recent
- * CHIP_RING_ROWS rows (64 MiB at D=4096), from which the tick's three query descriptors are read: a sharded
- * tick at l therefore needs chip_db_size() - l <= CHIP_RING_ROWS - 3 (else CHIP_ERR_RANGE) -- always true in
- * live operation, where ticks trail the append head by a few rows.  Every rank must be fed the same append
+ * CHIP_RING_ROWS rows (64 MiB at D=4096), from which the tick's three query descriptors are read: a tick at l
+ * on a one-process-per-GPU ctx therefore needs chip_db_size() - l <= CHIP_RING_ROWS - 3 (else CHIP_ERR_RANGE /
+ * CHIP_ERR_SHARD_FAILED) -- always true in live operation, where ticks trail the append head by a few rows; a
+ * chip_create_multi ctx has no such limit (older query rows are fetched from the devices that own them, so a whole
+ * recorded schedule can be replayed over a cold-started DB).  Every rank must be fed the same append
  * stream.  One process per GPU; the per-shard top-k lists are exchanged INSIDE the library once an RCCL
  * communicator is attached (chip_comm_init_rank below), or by the HOST (any transport) between
  * chip_scan_local and chip_merge_decide.  Query rows of chip_query_rows / chip_query_scores: with an exchange

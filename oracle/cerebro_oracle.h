@@ -123,6 +123,14 @@ void orc_ref_scan_f64_eigen_gemv3(const double *M, int32_t D, int64_t k, const d
                                   double *u, double *um, double *umm, double maxv[3], int64_t argmax[3], int32_t nthreads);
 
 
+/* ------------------------------------------------------------------ EuRoC-shaped surrogate run (surrogate.c) */
+/* one step of a unit-norm AR(1) descriptor walk in plain sequential C (bit-reproducible on any machine) */
+void orc_ar1_step(const double *prev, const float *noise, double alpha, int32_t D, int32_t round_f32, double *out);
+/* One tick in a chosen summation order (0 = the device's fixed tree, 1 = Eigen 3.3 SSE2 GEMV order; order 1 needs elem == 8),
+ * OpenMP over rows; gap[q] (may be NULL) = best - second-best score of query q (0 for an exact tie). */
+void orc_loop_tick_order(orc_loop_state *st, const orc_dot_params *p, const void *db, int32_t elem, int32_t D, int64_t l,
+                         int32_t order, int32_t nthreads, orc_tick_result *out, double gap[3]);
+
 /* ================================================================== PnP / RANSAC (pnp_ransac.c) */
 typedef struct {
     double  error_thresh;        /* 0.03   DlsPnpWithRansac.cpp:208 */

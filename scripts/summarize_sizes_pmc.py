@@ -15,7 +15,7 @@ N_SYNC = 60
 
 
 def last_sync(con, table, cols, where_name):
-    rows = con.execute(f"select {cols} from {table} where {where_name} like '%db_scan_topk%' order by rowid").fetchall()
+    rows = con.execute(f"select {cols} from {table} where {where_name} like '%db_scan_topk%' order by start").fetchall()
     return rows[-N_SYNC:]
 
 
@@ -38,7 +38,7 @@ def main(src):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             for db in glob.glob(str(src / f"{rows}_{ctr}" / "**" / "*_results.db"), recursive=True):
                 con = sqlite3.connect(db)
-                r = con.execute("select value from counters_collection where kernel_name like '%db_scan_topk%' and counter_name=? order by rowid", (ctr,)).fetchall()[-N_SYNC:]
+                r = con.execute("select value from counters_collection where kernel_name like '%db_scan_topk%' and counter_name=? order by start", (ctr,)).fetchall()[-N_SYNC:]
                 if r:
                     v = [x[0] for x in r]
                     e[ctr.lower() + "_kib_avg"] = sum(v) / len(v)

@@ -233,13 +233,16 @@ def test_state_json_untrusted_input(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cold_start_from_state_json_matches_oracle(tmp_path):
-    D, N = 1024, 700
+@pytest.mark.parametrize("D,N,devices", [(1024, 700, None), (64, 4600, "0,0,0")])
+def test_cold_start_from_state_json_matches_oracle(tmp_path, D, N, devices):
+    """--devices + a checkpoint longer than the replicated ring (CHIP_RING_ROWS = 4096): after the cold start the schedule starts at
+    l = 56, 4500 rows behind the append head -- those ticks fetch their query rows from the sub-contexts that own them."""
     plants, loops, ties = scenarios.loop_plants(N, 4, seed=8)
     db = scenarios.build_db(19, N, D, plants)
     stamps = [1403636579_000000000 + i * 50_000_000 for i in range(N)]
     write_state_json(tmp_path / "state.json", db, stamps)
-    r = subprocess.run([str(LIB / "cerebro_replay"), "--state", str(tmp_path / "state.json"), str(tmp_path / "o.json")], capture_output=True, text=True)
+    r = subprocess.run([str(LIB / "cerebro_replay")] + (["--devices", devices] if devices else []) +
+                       ["--state", str(tmp_path / "state.json"), str(tmp_path / "o.json")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     got = json.loads((tmp_path / "o.json").read_text())
     orc = oracle_lib.LoopOracle(db)                                     # the float32 descriptors the checkpoint was made from

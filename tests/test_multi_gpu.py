@@ -332,16 +332,30 @@ def test_group_bulk_append_owner_only(G):
             assert chip.size() == at and chip.info()["rows_local"] == len(range(0, at, G))
         rows = list(range(0, N, 613)) + [4095, 4096, 4097, 5000, 5001, N - 1]
         assert chip.read_rows(rows).tobytes() == db[rows].tobytes()
-        # ticks read their query rows from the replicated ring: they must trail the append head by < CHIP_RING_ROWS - 3 rows
+        # live ticks read their query rows from the replicated ring (they trail the append head by < CHIP_RING_ROWS - 3 rows) ...
         sched = [l for l in scenarios.default_schedule(N) if l >= N - 4000]
         sched = sorted(set(sched[::5]) | {lp[0] for lp in loops if lp[0] >= N - 4000})
         orc = oracle_lib.LoopOracle(db)
         for l in sched:
             same_tick(chip.loop_tick(l), orc.tick(l))
+        # ... and a tick further back than the ring fetches them from the sub-contexts that own them: the WHOLE schedule of a run can
+        # be replayed over the cold-started group (cerebro_replay --state --devices ...; round 3 returned CHIP_ERR_RANGE here),
+        # synchronously and pipelined across the ring boundary
         chip.loop_reset()
-        with pytest.raises(capi.ChipError) as e:
-            chip.loop_tick(N - 4200)                      # its query rows have left the ring: the documented limit, deterministic
-        assert e.value.status == capi.CHIP_ERR_RANGE
+        orc = oracle_lib.LoopOracle(db)
+        old = sorted(set(scenarios.default_schedule(N)[::9]) | {lp[0] for lp in loops})
+        assert old[0] < N - 15000 and sum(1 for l in old if N - l > 4093) > 100
+        for l in old:
+            same_tick(chip.loop_tick(l), orc.tick(l))
+        chip.loop_reset()
+        orc = oracle_lib.LoopOracle(db)
+        around = [l for l in scenarios.default_schedule(N) if N - 4200 <= l <= N - 3990]
+        for base in range(0, len(around), 16):
+            chunk = around[base:base + 16]
+            for s_, l in enumerate(chunk):
+                chip.loop_tick_enqueue(l, s_)
+            for s_, l in enumerate(chunk):
+                same_tick(chip.loop_tick_collect(s_), orc.tick(l))
         # a batch with a non-finite value is rejected as a whole on every device, whichever device owns the bad row
         bad = db[:G + 2].astype(np.float64).copy()
         bad[G, 3] = np.nan
