@@ -398,6 +398,10 @@ struct BatchState {
     uint32_t *tile_ctr = nullptr;     // one counter per query tile (kMaxQTiles)
     chip_topk_entry *partial = nullptr, *out = nullptr, *h_out = nullptr;
     int64_t cap_q = 0, cap_partial = 0, cap_out = 0;
+    // sharded DBs (chip_multi.hip): every shard's [Qpad][K] list side by side, and the merged result of the whole DB
+    chip_topk_entry *gathered = nullptr, *merged = nullptr;
+    int64_t cap_gathered = 0, cap_merged = 0;
+    hipEvent_t ev_done = nullptr;     // this shard's list is complete (recorded on its scan stream)
 };
 
 void batch_destroy(Ctx *c)
@@ -405,27 +409,17 @@ void batch_destroy(Ctx *c)
     BatchState *st = static_cast<BatchState *>(c->batch_state);
     if (!st) return;
     (void)hipFree(st->Q); (void)hipFree(st->Qt); (void)hipFree(st->tile_ctr); (void)hipFree(st->partial); (void)hipFree(st->out); (void)hipHostFree(st->h_out);
+    (void)hipFree(st->gathered); (void)hipFree(st->merged);
+    if (st->ev_done) (void)hipEventDestroy(st->ev_done);
     delete st;
     c->batch_state = nullptr;
 }
 
-}  // namespace chip
-
-using namespace chip;
-
-extern "C" int chip_query_batch_f32(chip_ctx *c, int64_t k, const float *queries, int32_t Q, int32_t topk, float *scores, int64_t *idx)
+// This ctx's share of a many-query call, enqueued on its scan stream: Q queries (host, Q x D fp32) against its LOCAL rows of the global
+// prefix [0, k) -- the whole prefix on a plain ctx, rows i % G == rank of it on a shard -- leaving one sorted [Qpad][topk] list of
+// (score, GLOBAL index) entries in device memory (*out_dev).  No host synchronisation.  Caller: query lock held, device current.
+int batch_local_enqueue(Ctx *c, int64_t k, const float *queries, int32_t Q, int32_t topk, chip_topk_entry **out_dev, int32_t *Qpad_out)
 {
-    if (!c || !queries || Q < 1) return CHIP_ERR_INVALID_ARG;
-    if (topk < 1 || topk > CHIP_MAX_TOPK || c->D % 32 != 0) return CHIP_ERR_UNSUPPORTED;
-    if (c->group || c->elem != 4) return CHIP_ERR_UNSUPPORTED;   // fp32 GEMM over float rows of one device (faiss casts to float, Cerebro.cpp:422)
-    int64_t n_global;
-    {
-        std::lock_guard<std::mutex> lk(c->mu);
-        n_global = c->rows_global;
-    }
-    if (k < 0 || k > n_global) return CHIP_ERR_RANGE;
-    std::lock_guard<std::mutex> qlk(c->query_mu);
-    CHIP_HIP(c, hipSetDevice(c->device));
     if (!c->batch_state) {
         c->batch_state = new (std::nothrow) BatchState();
         if (!c->batch_state) return CHIP_ERR_OOM;
@@ -514,11 +508,87 @@ extern "C" int chip_query_batch_f32(chip_ctx *c, int64_t k, const float *queries
     m.in = st->partial; m.n_lists = (int)P; m.Qpad = Qpad; m.K = topk; m.out = st->out;
     hipLaunchKernelGGL(topk_merge_batch, dim3((Q + 3) / 4), dim3(512), 0, s, m);
     CHIP_HIP(c, hipGetLastError());
-    CHIP_HIP(c, hipMemcpyAsync(st->h_out, st->out, sizeof(chip_topk_entry) * (size_t)Q * topk, hipMemcpyDeviceToHost, s));
+    *out_dev = st->out;
+    *Qpad_out = Qpad;
+    return CHIP_OK;
+}
+
+// D2H of a finished [Q][topk] list on the ctx's scan stream + conversion to the caller's arrays (synchronises that stream)
+int batch_deliver(Ctx *c, const chip_topk_entry *list_dev, int32_t Q, int32_t topk, float *scores, int64_t *idx)
+{
+    BatchState *st = static_cast<BatchState *>(c->batch_state);
+    hipStream_t s = c->s_scan;
+    CHIP_HIP(c, hipMemcpyAsync(st->h_out, list_dev, sizeof(chip_topk_entry) * (size_t)Q * topk, hipMemcpyDeviceToHost, s));
     CHIP_HIP(c, hipStreamSynchronize(s));
+    if (st->h_out[0].idx == kFailedShardIdx) return CHIP_ERR_SHARD_FAILED;   // a shard took part with the failure mark (chip_multi.hip)
     for (int64_t i = 0; i < (int64_t)Q * topk; i++) {
         if (scores) scores[i] = (float)st->h_out[i].score;
         if (idx) idx[i] = st->h_out[i].idx;
     }
     return CHIP_OK;
+}
+
+// buffers of the cross-shard merge on the ctx that merges: gathered [n_lists][Qpad][topk], merged [Qpad][topk]
+int batch_exchange_buffers(Ctx *c, int n_lists, int32_t Qpad, int32_t topk, chip_topk_entry **gathered, chip_topk_entry **merged, hipEvent_t *ev_done)
+{
+    if (!c->batch_state) {
+        c->batch_state = new (std::nothrow) BatchState();
+        if (!c->batch_state) return CHIP_ERR_OOM;
+    }
+    BatchState *st = static_cast<BatchState *>(c->batch_state);
+    const int64_t ng = (int64_t)n_lists * Qpad * topk, nm = (int64_t)Qpad * topk;
+    if (ng > st->cap_gathered) {
+        (void)hipFree(st->gathered); st->gathered = nullptr; st->cap_gathered = 0;
+        CHIP_HIP(c, hipMalloc(&st->gathered, sizeof(chip_topk_entry) * (size_t)ng));
+        st->cap_gathered = ng;
+    }
+    if (nm > st->cap_merged) {
+        (void)hipFree(st->merged); st->merged = nullptr; st->cap_merged = 0;
+        CHIP_HIP(c, hipMalloc(&st->merged, sizeof(chip_topk_entry) * (size_t)nm));
+        st->cap_merged = nm;
+    }
+    if (!st->ev_done) CHIP_HIP(c, hipEventCreateWithFlags(&st->ev_done, hipEventDisableTiming));
+    if (gathered) *gathered = st->gathered;
+    if (merged) *merged = st->merged;
+    if (ev_done) *ev_done = st->ev_done;
+    return CHIP_OK;
+}
+
+// merge of n_lists per-shard lists [n_lists][Qpad][topk] -> out [Qpad][topk] on stream s (the same exact selection as within a device)
+int batch_merge_lists(Ctx *c, hipStream_t s, const chip_topk_entry *in, int n_lists, int32_t Qpad, int32_t Q, int32_t topk, chip_topk_entry *out)
+{
+    BatchMergeArgs m;
+    m.in = in; m.n_lists = n_lists; m.Qpad = Qpad; m.K = topk; m.out = out;
+    hipLaunchKernelGGL(topk_merge_batch, dim3((Q + 3) / 4), dim3(512), 0, s, m);
+    CHIP_HIP(c, hipGetLastError());
+    return CHIP_OK;
+}
+
+}  // namespace chip
+
+using namespace chip;
+
+extern "C" int chip_query_batch_f32(chip_ctx *c, int64_t k, const float *queries, int32_t Q, int32_t topk, float *scores, int64_t *idx)
+{
+    if (!c || !queries || Q < 1) return CHIP_ERR_INVALID_ARG;
+    if (topk < 1 || topk > CHIP_MAX_TOPK || c->D % 32 != 0) return CHIP_ERR_UNSUPPORTED;
+    if ((int64_t)(Q + BM - 1) / BM > kMaxQTiles) return CHIP_ERR_UNSUPPORTED;
+    if (c->group) return group_query_batch(c, k, queries, Q, topk, scores, idx);   // G per-device passes -> one merge on devices[0]
+    if (c->elem != 4) return CHIP_ERR_UNSUPPORTED;   // fp32 GEMM over float rows (faiss casts to float, Cerebro.cpp:422)
+    int64_t n_global;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        n_global = c->rows_global;
+    }
+    if (k < 0) return CHIP_ERR_RANGE;
+    const bool collective = c->xchg != nullptr;      // sharded ctx with an in-library exchange: every rank makes the same call
+    if (k > n_global && !collective) return CHIP_ERR_RANGE;
+    std::lock_guard<std::mutex> qlk(c->query_mu);
+    CHIP_HIP(c, hipSetDevice(c->device));
+    if (collective) return xchg_query_batch(c, k, queries, Q, topk, scores, idx, k > n_global);
+    chip_topk_entry *out = nullptr;
+    int32_t Qpad = 0;
+    const int rc = batch_local_enqueue(c, k, queries, Q, topk, &out, &Qpad);
+    if (rc != CHIP_OK) return rc;
+    return batch_deliver(c, out, Q, topk, scores, idx);
 }

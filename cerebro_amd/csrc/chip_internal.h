@@ -267,6 +267,14 @@ int group_profile_enable(Ctx *gc, int on);
 Ctx *group_root(Ctx *gc);
 int group_size(const Ctx *gc);
 
+// batch.hip: the many-query (MFMA) mode in pieces, so that chip_multi.hip can run it over the shards of a DB
+int batch_local_enqueue(Ctx *c, int64_t k, const float *queries, int32_t Q, int32_t topk, chip_topk_entry **out_dev, int32_t *Qpad_out);
+int batch_deliver(Ctx *c, const chip_topk_entry *list_dev, int32_t Q, int32_t topk, float *scores, int64_t *idx);
+int batch_exchange_buffers(Ctx *c, int n_lists, int32_t Qpad, int32_t topk, chip_topk_entry **gathered, chip_topk_entry **merged, hipEvent_t *ev_done);
+int batch_merge_lists(Ctx *c, hipStream_t s, const chip_topk_entry *in, int n_lists, int32_t Qpad, int32_t Q, int32_t topk, chip_topk_entry *out);
+int group_query_batch(Ctx *gc, int64_t k, const float *queries, int32_t Q, int32_t topk, float *scores, int64_t *idx);
+int xchg_query_batch(Ctx *c, int64_t k, const float *queries, int32_t Q, int32_t topk, float *scores, int64_t *idx, bool fail_local);
+
 // pnp.hip
 int pnp_create(Ctx *c);
 void pnp_destroy(Ctx *c);

@@ -737,6 +737,95 @@ int group_scores(Ctx *gc, int64_t k, int64_t query_row, double *u)
     });
 }
 
+// Many-query (MFMA) mode on a group (SURVEY 8f N4 where the DB outgrows one GPU -- the offline all-vs-all of the faiss-style policies
+// on a long run, Cerebro.cpp:506-722): every device runs db_gemm_topk over ITS rows of the prefix (global indices), leaving one
+// sorted [Qpad][topk] list; the root pulls the G lists side by side (device / peer copies behind events -- Q x topk x 16 B per
+// device, 32 KiB at Q = 256, topk = 8: the transport does not matter) and merges them with the same exact selection that merges
+// the workgroups of one device (topk_merge_batch): the result is that of one device holding the whole DB, bit for bit.
+int group_query_batch(Ctx *gc, int64_t k, const float *queries, int32_t Q, int32_t topk, float *scores, int64_t *idx)
+{
+    Group *G = gc->group;
+    Ctx *root = G->subs[0];
+    std::lock_guard<std::mutex> qlk(gc->query_mu);
+    if (G->broken) return CHIP_ERR_GROUP_BROKEN;
+    int64_t n;
+    int elem;
+    {
+        std::lock_guard<std::mutex> lk(gc->mu);
+        n = gc->rows_global;
+        elem = gc->elem;
+    }
+    if (elem != 4) return CHIP_ERR_UNSUPPORTED;
+    if (k < 0 || k > n) return CHIP_ERR_RANGE;
+    const int ng = (int)G->subs.size();
+    std::vector<chip_topk_entry *> lists((size_t)ng, nullptr);
+    std::vector<hipEvent_t> evs((size_t)ng, nullptr);
+    std::vector<int32_t> qpads((size_t)ng, 0);
+    int rc = run_all(G, [&](int g) -> int {
+        Ctx *c = G->subs[(size_t)g];
+        std::lock_guard<std::mutex> lk(c->query_mu);
+        CHIP_HIP(c, hipSetDevice(c->device));
+        int r = batch_local_enqueue(c, k, queries, Q, topk, &lists[(size_t)g], &qpads[(size_t)g]);
+        if (r != CHIP_OK) return r;
+        r = batch_exchange_buffers(c, g == 0 ? ng : 0, qpads[(size_t)g], topk, nullptr, nullptr, &evs[(size_t)g]);
+        if (r != CHIP_OK) return r;
+        CHIP_HIP(c, hipEventRecord(evs[(size_t)g], c->s_scan));
+        return CHIP_OK;
+    });
+    if (rc != CHIP_OK) return rc;   // nothing collective was enqueued: the group stays usable
+    std::lock_guard<std::mutex> rlk(root->query_mu);
+    CHIP_HIP(root, hipSetDevice(root->device));
+    const int32_t Qpad = qpads[0];
+    chip_topk_entry *gathered = nullptr, *merged = nullptr;
+    rc = batch_exchange_buffers(root, ng, Qpad, topk, &gathered, &merged, nullptr);
+    if (rc != CHIP_OK) return rc;
+    const size_t list_bytes = sizeof(chip_topk_entry) * (size_t)Qpad * topk;
+    for (int g = 0; g < ng; g++) {
+        Ctx *c = G->subs[(size_t)g];
+        if (g > 0) CHIP_HIP(root, hipStreamWaitEvent(root->s_scan, evs[(size_t)g], 0));
+        chip_topk_entry *dst = gathered + (size_t)g * Qpad * topk;
+        if (c->device == root->device) CHIP_HIP(root, hipMemcpyAsync(dst, lists[(size_t)g], list_bytes, hipMemcpyDeviceToDevice, root->s_scan));
+        else CHIP_HIP(root, hipMemcpyPeerAsync(dst, root->device, lists[(size_t)g], c->device, list_bytes, root->s_scan));
+    }
+    rc = batch_merge_lists(root, root->s_scan, gathered, ng, Qpad, Q, topk, merged);
+    if (rc != CHIP_OK) return rc;
+    rc = batch_deliver(root, merged, Q, topk, scores, idx);
+    // the sub-contexts' list buffers are reused by their next call: it is posted after this one returns (group query lock), and the
+    // root's copies above have completed by then (batch_deliver synchronised the root's scan stream)
+    return rc;
+}
+
+// The same on a sharded ctx of the one-process-per-GPU layout with its exchange inside the library: local pass -> ncclAllGather of
+// the [Qpad][topk] lists -> merge on every rank (collective: every rank makes the same call; a rank whose own arguments are out of
+// range takes part with the failure mark, like xchg_query).
+int xchg_query_batch(Ctx *c, int64_t k, const float *queries, int32_t Q, int32_t topk, float *scores, int64_t *idx, bool fail_local)
+{
+    Exchange *x = c->xchg;
+    if (c->elem != 4) return CHIP_ERR_UNSUPPORTED;      // the storage type is the same on every rank (same append stream)
+    if (test_fail_now(x)) fail_local = true;
+    chip_topk_entry *mine = nullptr, *gathered = nullptr, *merged = nullptr;
+    int32_t Qpad = (Q + 127) / 128 * 128;
+    int rc = batch_exchange_buffers(c, x->world, Qpad, topk, &gathered, &merged, nullptr);
+    if (rc != CHIP_OK) return rc;
+    const size_t list_entries = (size_t)Qpad * topk;
+    if (!fail_local) {
+        rc = batch_local_enqueue(c, k, queries, Q, topk, &mine, &Qpad);
+        if (rc != CHIP_OK) return rc;
+    } else {   // the marked neutral list, built on the host (rare path): merged + 0 is free until the merge below
+        std::vector<chip_topk_entry> mark(list_entries);
+        for (chip_topk_entry &e : mark) { e.score = -INFINITY; e.idx = kFailedShardIdx; }
+        CHIP_HIP(c, hipMemcpyAsync(merged, mark.data(), sizeof(chip_topk_entry) * list_entries, hipMemcpyHostToDevice, c->s_scan));
+        CHIP_HIP(c, hipStreamSynchronize(c->s_scan));
+        mine = merged;
+    }
+    CHIP_NCCL(c, rccl().AllGather(mine, gathered, sizeof(chip_topk_entry) * list_entries, ncclChar, x->comm, c->s_scan));
+    chip_topk_entry *out = fail_local ? gathered : merged;   // (a failed rank's `merged` is its send buffer; its result is an error anyway)
+    if (fail_local) { CHIP_HIP(c, hipStreamSynchronize(c->s_scan)); return CHIP_ERR_SHARD_FAILED; }
+    rc = batch_merge_lists(c, c->s_scan, gathered, x->world, Qpad, Q, topk, out);
+    if (rc != CHIP_OK) return rc;
+    return batch_deliver(c, out, Q, topk, scores, idx);
+}
+
 int group_synchronize(Ctx *gc)
 {
     for (chip_ctx *s : gc->group->subs) {

@@ -107,8 +107,9 @@ int  chip_create_ex(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t de
  *     bulk load moves ~1x the batch over PCIe, not Gx; the validation decision is one, from all devices),
  *     chip_db_read_rows_*, chip_loop_tick* = G local scans -> per-device local top-k -> exchange -> merge + decision on
  *     devices[0], chip_query_rows / _vectors_* / _scores, chip_synchronize, chip_profile_*, PnP / ICP (on devices[0]).
+ *     chip_query_batch_f32 (the MFMA many-query mode: one pass per device over its rows, the per-device lists merged on devices[0]).
  *     NOT on a group ctx (CHIP_ERR_UNSUPPORTED): chip_set_stream / chip_reset_stream, chip_scan_local, chip_merge_decide*,
- *     chip_comm_init_rank (the group owns its exchange) and chip_query_batch_f32 (the MFMA many-query mode is single-GPU).
+ *     chip_comm_init_rank (the group owns its exchange).
  *     One host worker thread per device enqueues that device's work, so the host cost of a tick does not grow with G.
  *     Failure containment: a call that fails on SOME devices before anything became visible changes nothing; a shard that
  *     cannot take part in one tick sends a marked neutral list, the tick fails everywhere alike (CHIP_ERR_SHARD_FAILED) and the
@@ -190,7 +191,11 @@ int chip_query_scores(chip_ctx *ctx, int64_t k, int64_t query_row, double *u);
  * the reference's compiled-out faiss variants (IndexFlatIP on float descriptors, src/Cerebro.cpp:390,422,455-472):
  * score = fp32 inner product, here defined as ONE k-ordered fmaf chain (bit-reproducible; differs from the fp64 scores
  * of chip_query_* by fp32 round-off, ~1e-7).  Ordering (score desc, index desc); unused slots -inf / -1.
- * Requires D % 32 == 0.  Worth it from Q ~ 40 upwards (arithmetic intensity Q/2 flop/B vs the 19.7 flop/B ridge). */
+ * Requires D % 32 == 0 and float rows.  Worth it from Q ~ 40 upwards (arithmetic intensity Q/2 flop/B vs the 19.7 flop/B ridge).
+ * Sharded DBs: a chip_create_multi ctx runs one pass per device over the rows it owns and merges the per-device lists on
+ * devices[0]; a sharded ctx with an attached communicator does the same collectively (ncclAllGather of Q x topk entries per rank,
+ * the same result on every rank); a sharded ctx WITHOUT an exchange answers for its own rows only (global indices) -- the host
+ * merges.  Results are those of one device holding the whole DB, bit for bit (exact selection under a total order).            */
 int chip_query_batch_f32(chip_ctx *ctx, int64_t k, const float *queries, int32_t Q, int32_t topk,
                          float *scores /* Q x topk */, int64_t *idx /* Q x topk */);
 

@@ -84,3 +84,55 @@ def test_batch_claimed_tiles(Q, wgs, monkeypatch):
         for k in (N, N - 257, 4097, 1023):
             check(chip, db, k, q, 8)
         check(chip, db, N, q[:40], 16)
+
+
+@pytest.mark.parametrize("G,D,N,Q", [(8, 512, 9000, 256), (3, 128, 4100, 70), (2, 4096, 1500, 130)])
+def test_batch_on_a_group_ctx(G, D, N, Q):
+    """The many-query mode where the DB is row-sharded over the devices of a chip_create_multi ctx (round 3: CHIP_ERR_UNSUPPORTED):
+    one db_gemm_topk pass per device over the rows it owns, the per-device lists merged on devices[0] -- bit for bit the result of one
+    device holding the whole DB (indices and fp32 scores vs orc_scan_topk_fmaf_f32), at every prefix that cuts through the shards."""
+    plants, loops, ties = scenarios.loop_plants(N, 4, seed=G + Q)
+    db = scenarios.build_db(3 * D + G, N, D, plants)
+    rng = np.random.default_rng(G * Q)
+    q = db[rng.choice(N, Q, replace=False)]
+    q[0] = db[loops[0][1]]
+    with capi.Chip(D, devices=[0] * G) as chip:
+        chip.append_f32(db[:N // 2])
+        chip.append_f64(db[N // 2:].astype(np.float64))
+        for K in (1, 8, 16):
+            for k in (0, 1, G - 1, G, G + 1, 257, N - 50, N):
+                check(chip, db, k, q, K)
+        if ties:
+            s, t1, t2 = ties[0]                         # the duplicates live on different devices: index-descending tie rule across shards
+            sc, ix = chip.query_batch(N, db[[s]], 3)
+            assert list(ix[0]) == [t2, t1, s] and sc[0][0] == sc[0][1] == sc[0][2]
+        with pytest.raises(capi.ChipError) as e:
+            chip.query_batch(N + 1, q, 4)
+        assert e.value.status == capi.CHIP_ERR_RANGE
+        # the tick path of the same group still works between batch calls (shared scan streams / query buffers)
+        orc = oracle_lib.LoopOracle(db)
+        for l in scenarios.default_schedule(N)[-20:]:
+            chip.loop_reset()
+            orc.state.last_l = 0
+            g_, o_ = chip.loop_tick(l).as_dict(), orc.tick(l)
+            assert (g_["found"], g_["argmax"]) == (o_["found"], o_["argmax"])
+        check(chip, db, N, q, 8)
+
+
+def test_batch_on_a_sharded_ctx_with_the_in_library_exchange():
+    """One process per GPU layout at world size 1 (RCCL refuses two ranks on one device): local pass -> ncclAllGather of the
+    [Q][topk] lists -> merge, through chip_query_batch_f32 on the sharded ctx."""
+    D, N, Q = 256, 2100, 140
+    db = scenarios.build_db(17, N, D, [])
+    q = db[np.random.default_rng(3).choice(N, Q, replace=False)]
+    with capi.Chip(D) as chip:
+        chip.comm_init_rank(capi.comm_unique_id(), 1, 0)
+        assert chip.info()["exchange"] == capi.CHIP_EXCHANGE_RCCL
+        chip.append_f32(db)
+        for K in (1, 8):
+            for k in (0, 129, N):
+                check(chip, db, k, q, K)
+        with pytest.raises(capi.ChipError) as e:
+            chip.query_batch(N + 5, q, 8)               # beyond what this rank has published: the failure mark, not a hang
+        assert e.value.status == capi.CHIP_ERR_SHARD_FAILED
+        check(chip, db, N, q, 8)                         # and the communicator is still in step

@@ -233,7 +233,7 @@ def test_state_json_untrusted_input(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D,N,devices", [(1024, 700, None), (64, 4600, "0,0,0")])
+@pytest.mark.parametrize("D,N,devices", [(1024, 700, None), (256, 4600, "0,0,0")])
 def test_cold_start_from_state_json_matches_oracle(tmp_path, D, N, devices):
     """--devices + a checkpoint longer than the replicated ring (CHIP_RING_ROWS = 4096): after the cold start the schedule starts at
     l = 56, 4500 rows behind the append head -- those ticks fetch their query rows from the sub-contexts that own them."""
