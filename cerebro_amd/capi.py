@@ -13,7 +13,7 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "lib" / "libcerebro_hip.so"
+LIB_PATH = Path(os.environ["CHIP_LIB"]).resolve() if os.environ.get("CHIP_LIB") else _HERE / "lib" / "libcerebro_hip.so"   # CHIP_LIB: A/B runs of another build
 
 CHIP_OK = 0
 CHIP_ERR_INVALID_ARG = -1

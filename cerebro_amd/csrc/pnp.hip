@@ -798,11 +798,40 @@ __device__ __forceinline__ double sqrt_normal_range(double t)
 // wave-uniform broadcasts -- one DS read instead of two v_readlane per term --, and (2) keep the NEXT four terms' reads in flight
 // underneath the current four terms' arithmetic (LDS returns in order: counted lgkmcnt waits).  Term order is the reference's.
 //   dot_desc:  f = sum_{i = hi, hi-1, .., lo} a[i] * b[i * SB]     (f starts at +0.0, one rounding per multiply and per add)
+// The n % 4 leading terms of a serial sum are straight-line code behind ONE wave-uniform switch (n is uniform: it derives from the
+// reduction step m), the rest runs in whole groups of four.  Round 3 handled the 0..3 left-over terms at the END with three guarded
+// blocks that hipcc if-converted into ~35-45 executed instructions per sum whatever the remainder was.  (Measured on the same box,
+// round 4: 1000-hypothesis call 884 -> 866 us, reference mode 623 -> 611 us, bits unchanged.  Forcing the next group's LDS reads in
+// front of the current group's arithmetic with sched_barrier + two alternating register sets was measured too: SLOWER by 0.5-1 %
+// -- these loops are bound by their instruction count, ~8.5 cycles per instruction of a lone wave, not by LDS latency.)
 template <int SB>
 __device__ __forceinline__ double dot_desc(const double *a, const double *b, int hi, int lo)
 {
     double f = 0.0;
     int i = hi;
+    switch ((hi - lo + 1) & 3) {
+        case 3: {
+            const double a0 = a[i], a1 = a[i - 1], a2 = a[i - 2];
+            const double b0 = b[i * SB], b1 = b[(i - 1) * SB], b2 = b[(i - 2) * SB];
+            f = f + a0 * b0; f = f + a1 * b1; f = f + a2 * b2;
+            i -= 3;
+            break;
+        }
+        case 2: {
+            const double a0 = a[i], a1 = a[i - 1];
+            const double b0 = b[i * SB], b1 = b[(i - 1) * SB];
+            f = f + a0 * b0; f = f + a1 * b1;
+            i -= 2;
+            break;
+        }
+        case 1: {
+            const double a0 = a[i], b0 = b[i * SB];
+            f = f + a0 * b0;
+            i -= 1;
+            break;
+        }
+        default: break;
+    }
     if (i - 3 >= lo) {
         double a0 = a[i], a1 = a[i - 1], a2 = a[i - 2], a3 = a[i - 3];
         double b0 = b[i * SB], b1 = b[(i - 1) * SB], b2 = b[(i - 2) * SB], b3 = b[(i - 3) * SB];
@@ -816,14 +845,6 @@ __device__ __forceinline__ double dot_desc(const double *a, const double *b, int
         }
         f = f + a0 * b0; f = f + a1 * b1; f = f + a2 * b2; f = f + a3 * b3;
     }
-    const int rem = i - lo + 1;   // 0..3 terms left: all reads first, then the chain
-    double ra0 = 0.0, ra1 = 0.0, ra2 = 0.0, rb0 = 0.0, rb1 = 0.0, rb2 = 0.0;
-    if (rem > 0) { ra0 = a[i]; rb0 = b[i * SB]; }
-    if (rem > 1) { ra1 = a[i - 1]; rb1 = b[(i - 1) * SB]; }
-    if (rem > 2) { ra2 = a[i - 2]; rb2 = b[(i - 2) * SB]; }
-    if (rem > 0) f = f + ra0 * rb0;
-    if (rem > 1) f = f + ra1 * rb1;
-    if (rem > 2) f = f + ra2 * rb2;
     return f;
 }
 //   dot_asc:  g = sum_{i = lo, lo+1, .., hi} a[i] * b[i * SB]
@@ -832,6 +853,29 @@ __device__ __forceinline__ double dot_asc(const double *a, const double *b, int 
 {
     double f = 0.0;
     int i = lo;
+    switch ((hi - lo + 1) & 3) {
+        case 3: {
+            const double a0 = a[i], a1 = a[i + 1], a2 = a[i + 2];
+            const double b0 = b[i * SB], b1 = b[(i + 1) * SB], b2 = b[(i + 2) * SB];
+            f = f + a0 * b0; f = f + a1 * b1; f = f + a2 * b2;
+            i += 3;
+            break;
+        }
+        case 2: {
+            const double a0 = a[i], a1 = a[i + 1];
+            const double b0 = b[i * SB], b1 = b[(i + 1) * SB];
+            f = f + a0 * b0; f = f + a1 * b1;
+            i += 2;
+            break;
+        }
+        case 1: {
+            const double a0 = a[i], b0 = b[i * SB];
+            f = f + a0 * b0;
+            i += 1;
+            break;
+        }
+        default: break;
+    }
     if (i + 3 <= hi) {
         double a0 = a[i], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3];
         double b0 = b[i * SB], b1 = b[(i + 1) * SB], b2 = b[(i + 2) * SB], b3 = b[(i + 3) * SB];
@@ -845,14 +889,6 @@ __device__ __forceinline__ double dot_asc(const double *a, const double *b, int 
         }
         f = f + a0 * b0; f = f + a1 * b1; f = f + a2 * b2; f = f + a3 * b3;
     }
-    const int rem = hi - i + 1;
-    double ra0 = 0.0, ra1 = 0.0, ra2 = 0.0, rb0 = 0.0, rb1 = 0.0, rb2 = 0.0;
-    if (rem > 0) { ra0 = a[i]; rb0 = b[i * SB]; }
-    if (rem > 1) { ra1 = a[i + 1]; rb1 = b[(i + 1) * SB]; }
-    if (rem > 2) { ra2 = a[i + 2]; rb2 = b[(i + 2) * SB]; }
-    if (rem > 0) f = f + ra0 * rb0;
-    if (rem > 1) f = f + ra1 * rb1;
-    if (rem > 2) f = f + ra2 * rb2;
     return f;
 }
 //   abs_sum_asc:  acc + |b[lo * SB]| + |b[(lo+1) * SB]| + .. + |b[hi * SB]|, ascending, next four reads in flight under the current four adds
@@ -860,6 +896,12 @@ template <int SB>
 __device__ __forceinline__ double abs_sum_asc(const double *b, int lo, int hi, double acc)
 {
     int i = lo;
+    switch ((hi - lo + 1) & 3) {
+        case 3: { const double c0 = b[i * SB], c1 = b[(i + 1) * SB], c2 = b[(i + 2) * SB]; acc = acc + fabs(c0); acc = acc + fabs(c1); acc = acc + fabs(c2); i += 3; break; }
+        case 2: { const double c0 = b[i * SB], c1 = b[(i + 1) * SB]; acc = acc + fabs(c0); acc = acc + fabs(c1); i += 2; break; }
+        case 1: { const double c0 = b[i * SB]; acc = acc + fabs(c0); i += 1; break; }
+        default: break;
+    }
     if (i + 3 <= hi) {
         double b0 = b[i * SB], b1 = b[(i + 1) * SB], b2 = b[(i + 2) * SB], b3 = b[(i + 3) * SB];
         i += 4;
@@ -871,14 +913,6 @@ __device__ __forceinline__ double abs_sum_asc(const double *b, int lo, int hi, d
         }
         acc = acc + fabs(b0); acc = acc + fabs(b1); acc = acc + fabs(b2); acc = acc + fabs(b3);
     }
-    const int rem = hi - i + 1;
-    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
-    if (rem > 0) c0 = b[i * SB];
-    if (rem > 1) c1 = b[(i + 1) * SB];
-    if (rem > 2) c2 = b[(i + 2) * SB];
-    if (rem > 0) acc = acc + fabs(c0);
-    if (rem > 1) acc = acc + fabs(c1);
-    if (rem > 2) acc = acc + fabs(c2);
     return acc;
 }
 //   axpy_rows:  b[i * SB] = b[i * SB] + c * a[i],  i = lo .. hi  (independent per i; c = -f gives the reference's  b - f * a:
@@ -887,19 +921,52 @@ template <int SB>
 __device__ __forceinline__ void axpy_rows(const double *a, double *b, double c, int lo, int hi)
 {
     int i = lo;
+    switch ((hi - lo + 1) & 3) {
+        case 3: {
+            const double a0 = a[i], a1 = a[i + 1], a2 = a[i + 2];
+            const double b0 = b[i * SB], b1 = b[(i + 1) * SB], b2 = b[(i + 2) * SB];
+            b[i * SB] = b0 + c * a0; b[(i + 1) * SB] = b1 + c * a1; b[(i + 2) * SB] = b2 + c * a2;
+            i += 3;
+            break;
+        }
+        case 2: {
+            const double a0 = a[i], a1 = a[i + 1];
+            const double b0 = b[i * SB], b1 = b[(i + 1) * SB];
+            b[i * SB] = b0 + c * a0; b[(i + 1) * SB] = b1 + c * a1;
+            i += 2;
+            break;
+        }
+        case 1: {
+            const double a0 = a[i], b0 = b[i * SB];
+            b[i * SB] = b0 + c * a0;
+            i += 1;
+            break;
+        }
+        default: break;
+    }
     for (; i + 3 <= hi; i += 4) {
         const double a0 = a[i], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3];
         const double b0 = b[i * SB], b1 = b[(i + 1) * SB], b2 = b[(i + 2) * SB], b3 = b[(i + 3) * SB];
         b[i * SB] = b0 + c * a0; b[(i + 1) * SB] = b1 + c * a1; b[(i + 2) * SB] = b2 + c * a2; b[(i + 3) * SB] = b3 + c * a3;
     }
-    const int rem = hi - i + 1;
-    double ra0 = 0.0, ra1 = 0.0, ra2 = 0.0, rb0 = 0.0, rb1 = 0.0, rb2 = 0.0;
-    if (rem > 0) { ra0 = a[i]; rb0 = b[i * SB]; }
-    if (rem > 1) { ra1 = a[i + 1]; rb1 = b[(i + 1) * SB]; }
-    if (rem > 2) { ra2 = a[i + 2]; rb2 = b[(i + 2) * SB]; }
-    if (rem > 0) b[i * SB] = rb0 + c * ra0;
-    if (rem > 1) b[(i + 1) * SB] = rb1 + c * ra1;
-    if (rem > 2) b[(i + 2) * SB] = rb2 + c * ra2;
+}
+
+//   sumsq_desc:  h = sum_{i = hi, hi-1, .., lo} u[i]^2  (wave-uniform broadcast reads, two elements per ds_read2)
+__device__ __forceinline__ double sumsq_desc(const double *u, int hi, int lo)
+{
+    double h = 0.0;
+    int i = hi;
+    switch ((hi - lo + 1) & 3) {
+        case 3: { const double o0 = u[i], o1 = u[i - 1], o2 = u[i - 2]; h = h + o0 * o0; h = h + o1 * o1; h = h + o2 * o2; i -= 3; break; }
+        case 2: { const double o0 = u[i], o1 = u[i - 1]; h = h + o0 * o0; h = h + o1 * o1; i -= 2; break; }
+        case 1: { const double o0 = u[i]; h = h + o0 * o0; i -= 1; break; }
+        default: break;
+    }
+    for (; i - 3 >= lo; i -= 4) {
+        const double o0 = u[i], o1 = u[i - 1], o2 = u[i - 2], o3 = u[i - 3];
+        h = h + o0 * o0; h = h + o1 * o1; h = h + o2 * o2; h = h + o3 * o3;
+    }
+    return h;
 }
 
 struct EigArgs {
@@ -992,21 +1059,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             if (lane < EN + 5) us[lane] = mine ? ov : 0.0;
             WAVE_SYNC();
             double h = 0.0;                                  // h = sum_{i = high..m} u_i^2, descending
-            {
-                int i = high;
-                for (; i - 3 >= m; i -= 4) {
-                    const double o0 = us[i], o1 = us[i - 1], o2 = us[i - 2], o3 = us[i - 3];
-                    h = h + o0 * o0; h = h + o1 * o1; h = h + o2 * o2; h = h + o3 * o3;
-                }
-                const int rem = i - m + 1;
-                double o0 = 0.0, o1 = 0.0, o2 = 0.0;
-                if (rem > 0) o0 = us[i];
-                if (rem > 1) o1 = us[i - 1];
-                if (rem > 2) o2 = us[i - 2];
-                if (rem > 0) h = h + o0 * o0;
-                if (rem > 1) h = h + o1 * o1;
-                if (rem > 2) h = h + o2 * o2;
-            }
+            h = sumsq_desc(us, high, m);
             double g = sqrt(h);
             const double om = us[m];
             if (om > 0) g = -g;
