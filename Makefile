@@ -17,7 +17,7 @@ HIP_SRCS   := $(CSRC)/kernels.hip $(CSRC)/chip_api.hip $(CSRC)/chip_multi.hip $(
 HIP_OBJS   := $(HIP_SRCS:$(CSRC)/%.hip=$(LIBDIR)/%.o)
 ORC_SRCS   := $(wildcard oracle/*.c)
 
-all: lib oracle host
+all: lib oracle host verify
 lib: $(LIBDIR)/libcerebro_hip.so
 oracle: oracle/_build/liboracle.so oracle/_build/liboracle_eispack.so
 host: $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay $(LIBDIR)/minimal_loop_detector
@@ -52,7 +52,16 @@ oracle/_build/liboracle_eispack.so: $(ORC_SRCS) oracle/cerebro_oracle.h
 $(LIBDIR)/minimal_loop_detector: examples/minimal_loop_detector.cc include/cerebro_hip.h $(LIBDIR)/libcerebro_hip.so
 	$(CXX) -O2 -std=c++17 -Wall -Wextra -Iinclude $< -o $@ -L$(LIBDIR) -lcerebro_hip -Wl,-rpath,'$$ORIGIN'
 
+# ---- build-time check of what the inline asm of the scan kernels relies on: the physical-VGPR partition of
+# db_scan_topk_rows (amdgpu_num_vgpr(40) -> 80 ArchVGPRs on this hipcc; v[80:127] written by the asm loads only), no touch of an
+# in-flight load register in the one-row kernel, pnp_build_solve <= 128 VGPRs.  A toolchain that allocates differently fails the
+# BUILD here instead of producing silently wrong scores.  (The same checks are tests/test_codeobj_registers.py.)
+verify: $(LIBDIR)/.codeobj_verified
+$(LIBDIR)/.codeobj_verified: $(LIBDIR)/libcerebro_hip.so tests/test_codeobj_registers.py oracle/_build/liboracle.so $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay $(LIBDIR)/minimal_loop_detector
+	python3 -m pytest tests/test_codeobj_registers.py -q -x -p no:cacheprovider
+	@touch $@
+
 clean:
 	rm -rf $(LIBDIR) oracle/_build
 
-.PHONY: all lib oracle host clean
+.PHONY: all lib oracle host verify clean

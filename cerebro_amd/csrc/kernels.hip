@@ -432,6 +432,9 @@ __device__ __forceinline__ void block_merge_lists(const ScanArgs &a, const chip_
 // outputs -- wait and first read are one asm block.  tests/test_codeobj_registers.py disassembles the built library and checks
 // the partition: nothing but these loads writes v[80..127], nothing but the take statements reads them.
 constexpr int kRowsVgprBase = 80;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "db_scan_topk_rows names physical VGPRs and uses global_load_lds_dwordx4: gfx950 (MI355X) only -- build with --offload-arch=gfx950"
+#endif
 #define CHIP_ROWS_CLOBBERS                                                                                                      \
     "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97",   \
     "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", \

@@ -1268,72 +1268,88 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             // them ~50).  The row modification's inputs H(k..k+2, lane) are final once step k-1 has written (the LDS executes a
             // wave's accesses in order), so they are read at the TOP of the step and land underneath the reflector's sqrt -> division
             // chain.  Same operations on the same values: bits unchanged.
+            // Per-lane activity limit of the column modification, once per sweep: H lanes (< 32) work on rows arow <= min(n, k + 3), i.e.
+            // "arow <= n and arow - 3 <= k"; V lanes 32..58 always; lanes 27..31 / 59..63 never.  One v_cmp per step instead of
+            // s_min / v_mov / v_cndmask / v_cmp (round 4: the step is bound by its instruction COUNT, ~8.5 cycles each for a lone wave).
+            const int col_lim = (lane < 32) ? ((lane <= n && lane < EN) ? lane - 3 : 0x7fffffff) : ((lane - 32 <= high) ? -0x7fffffff : 0x7fffffff);
             auto qr_step = [&](int k, auto notlast_tag) {
                 constexpr bool NOTLAST = decltype(notlast_tag)::value;
+                double pk = p, qk = q, rk = r;   // (k == m: from the m search)
                 if (k != m) {   // (the rare LDS reads of p, q, r come BEFORE the prefetch: LDS returns in order, so the wait for them
                                 //  then leaves the younger prefetch in flight; the other way round it drained the prefetch as well)
-                    if (fwd) { p = fp; q = fq; r = fr; }
-                    else { p = HH(k, k - 1); q = HH(k + 1, k - 1); r = NOTLAST ? HH(k + 2, k - 1) : 0.0; }
+                    if (fwd) { pk = fp; qk = fq; rk = fr; }
+                    else { pk = HH(k, k - 1); qk = HH(k + 1, k - 1); rk = NOTLAST ? HH(k + 2, k - 1) : 0.0; }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                // row-modification inputs H(k..k+2, lane): every lane reads its own column (lanes outside k..26 read elements they
+                // do not use -- inside the LDS allocation or past it, where reads return zero -- instead of a selected valid one)
                 const bool rowact = lane >= k && lane < nn;
-                const int jr = rowact ? lane : k;                       // idle lanes read a valid element
-                const double h0 = HH(k, jr), h1 = HH(k + 1, jr);
+                const double h0 = Hs[k * EN + lane], h1 = Hs[(k + 1) * EN + lane];
                 double h2 = 0.0;
-                if constexpr (NOTLAST) h2 = HH(k + 2, jr);
+                if constexpr (NOTLAST) h2 = Hs[(k + 2) * EN + lane];
                 __builtin_amdgcn_sched_barrier(0);
                 int ex = 0;
                 if (k != m) {
                     fwd = false;
-                    x = fabs(p) + fabs(q) + fabs(r);
-                    if (x == 0.0) return;
+                    const double ax = fabs(pk) + fabs(qk) + fabs(rk);
+                    if (ax == 0.0) return;
                     // overflow protection by an exact power-of-two scale 2^-ex, |p|+|q|+|r| = f * 2^ex (three v_ldexp instead of
                     // the division chain EISPACK has here; the oracle defines it the same way)
-                    (void)frexp(x, &ex);
-                    p = ldexp(p, -ex); q = ldexp(q, -ex); r = ldexp(r, -ex);
+                    (void)frexp(ax, &ex);
+                    pk = ldexp(pk, -ex); qk = ldexp(qk, -ex); rk = ldexp(rk, -ex);
                 }
                 fwd = false;
                 // p, q, r are scaled so that |p| + |q| + |r| is in [0.5, 1) on both ways in (frexp above / in the m search), hence
                 // p^2 + q^2 + r^2 is in [1/12, 1): sqrt_normal_range is IEEE sqrt there, without the range handling on the chain
-                s = sqrt_normal_range(p * p + q * q + r * r);
-                if (p < 0) s = -s;
-                if (k == m && s == 0.0) return;   // k != m: |p|+|q|+|r| is in [0.5, 1) after the scaling above, s cannot be 0
-                const double hkk1 = (k != m) ? ldexp(-s, ex) : ((l != m) ? -HH(k, k - 1) : 0.0);
+                double sk = sqrt_normal_range(pk * pk + qk * qk + rk * rk);
+                if (pk < 0) sk = -sk;
+                if (k == m && sk == 0.0) return;   // k != m: |p|+|q|+|r| is in [0.5, 1) after the scaling above, s cannot be 0
+                const double hkk1 = (k != m) ? ldexp(-sk, ex) : ((l != m) ? -HH(k, k - 1) : 0.0);
                 const bool wr_sub = (k != m) || (l != m);
-                p = p + s;
+                pk = pk + sk;
+                double xk, yk, zk, qq, rq;
                 {   // x = p/s, y = q/s, z = r/s, q = q/p, r = r/p as one vector division over lanes 0..4
-                    const double num = (lane == 0) ? p : ((lane & 1) ? q : r);
-                    const double den = (lane < 3) ? s : p;
+                    const double num = (lane == 0) ? pk : ((lane & 1) ? qk : rk);
+                    const double den = (lane < 3) ? sk : pk;
                     const double quo = num / den;
-                    x = lane_value_f64(quo, 0); y = lane_value_f64(quo, 1); z = lane_value_f64(quo, 2);
-                    q = lane_value_f64(quo, 3); r = lane_value_f64(quo, 4);
+                    xk = lane_value_f64(quo, 0); yk = lane_value_f64(quo, 1); zk = lane_value_f64(quo, 2);
+                    qq = lane_value_f64(quo, 3); rq = lane_value_f64(quo, 4);
                 }
                 PNP_STAMP(1);
                 WAVE_SYNC();
                 if (wr_sub && lane == 63) HH(k, k - 1) = hkk1;
-                if (rowact) {  // row modification, column j = lane
-                    const int j = lane;
-                    double pp = h0 + q * h1;
-                    if constexpr (NOTLAST) { pp = pp + r * h2; HH(k + 2, j) = h2 - pp * z; }
-                    HH(k, j) = h0 - pp * x;
-                    HH(k + 1, j) = h1 - pp * y;
+                {   // row modification, column j = lane: the arithmetic runs on every lane, only the stores are predicated
+                    double pp = h0 + qq * h1;
+                    if constexpr (NOTLAST) pp = pp + rq * h2;
+                    const double n0 = h0 - pp * xk, n1 = h1 - pp * yk;
+                    double n2 = 0.0;
+                    if constexpr (NOTLAST) n2 = h2 - pp * zk;
+                    if (rowact) {
+                        if constexpr (NOTLAST) Hs[(k + 2) * EN + lane] = n2;
+                        Hs[k * EN + lane] = n0;
+                        Hs[(k + 1) * EN + lane] = n1;
+                    }
                 }
                 WAVE_SYNC();
                 PNP_STAMP(2);
-                const int imax = (n < k + 3) ? n : k + 3;
-                double c0 = 0.0;
-                if (arow <= ((lane < 32) ? imax : high)) {  // H rows 0..imax | V rows 0..26 (one compare: the two-sided form compiled to divergent control flow)
+                double c0;
+                {   // column modification (H rows 0..min(n, k+3) on lanes 0..26 | V rows 0..26 on lanes 32..58): reads and arithmetic on
+                    // every lane (idle lanes touch rows 27..31 of their matrix: inside / past the LDS allocation, unused), stores predicated
                     double *row = Abase + arow * EN + k;
                     const double a0 = row[0], a1 = row[1];
                     double a2 = 0.0;
                     if constexpr (NOTLAST) a2 = row[2];
-                    double pp = x * a0 + y * a1;
-                    if constexpr (NOTLAST) { pp = pp + z * a2; row[2] = a2 - pp * r; }
+                    double pp = xk * a0 + yk * a1;
+                    if constexpr (NOTLAST) pp = pp + zk * a2;
                     c0 = a0 - pp;
-                    row[0] = c0;
-                    row[1] = a1 - pp * q;
+                    const double c1 = a1 - pp * qq;
+                    if (col_lim <= k) {
+                        if constexpr (NOTLAST) row[2] = a2 - pp * rq;
+                        row[0] = c0;
+                        row[1] = c1;
+                    }
                 }
-                // next reflector: H(k+1,k), H(k+2,k), H(k+3,k) as just computed by lanes k+1, k+2, k+3 (<= imax)
+                // next reflector: H(k+1,k), H(k+2,k), H(k+3,k) as just computed by lanes k+1, k+2, k+3 (<= min(n, k+3): active lanes)
                 if constexpr (NOTLAST) {
                     fp = lane_value_f64(c0, k + 1);
                     fq = lane_value_f64(c0, k + 2);
