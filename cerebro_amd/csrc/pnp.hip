@@ -971,20 +971,28 @@ __device__ __forceinline__ double sumsq_desc(const double *u, int hi, int lo)
 
 __device__ __forceinline__ uint32_t lds_addr32(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p; }
 
-// The steady-state double-shift steps of one Francis sweep, k = k0 .. k1, as ONE hand-scheduled instruction stream (round 4).
-// Same operations on the same values in the same order as qr_step<NOTLAST = true> with k != m and a forwarded reflector -- so the
-// same bits -- but: the activity masks of the row / column modification are kept in SGPR pairs and advanced by SALU bit
-// instructions (no v_cmp -> s_and_saveexec -> s_cbranch_execz crossing from the vector to the scalar pipe, three per step in the
-// compiled form, each stalling the lone wave ~30 cycles); the test |p|+|q|+|r| == 0 is issued at the top and branched on five
-// instructions later; one v_mov instead of three at the top (the scaled p and r are produced by v_ldexp straight from the SGPR
-// pairs the previous step's v_readlane left them in); addresses advance by one v_add each; no exec save / restore pairs.  ~108
-// instructions per step against ~140.  Registers v72..v127 and s40..s69 belong to this block (clobber list: the compiler keeps
-// nothing there across it); wait states follow the compiler's own code for the same sequences on gfx950 (one state between a
-// transcendental and its consumer, four between a VALU write of vcc and v_div_fmas, one between a VALU write and v_readlane).
+// The three-row double-shift steps of one Francis sweep with a forwarded reflector, k = k0 .. k1 <= n-2, as ONE hand-scheduled
+// instruction stream (round 4).  Same operations on the same values in the same order as qr_step<NOTLAST = true> with k != m -- so
+// the same bits -- but:
+//   * the activity masks of the row / column modification live in SGPR pairs advanced by SALU bit instructions (the compiled form
+//     crossed from the vector to the scalar pipe three times per step: v_cmp -> s_and_saveexec -> s_cbranch_execz, ~30 cycles each
+//     for a lone wave) and exec is simply written, not saved / restored;
+//   * the test |p|+|q|+|r| == 0 is issued at the top and branched on five instructions later;
+//   * the scalar bookkeeping of step k+1 (counters, masks) sits between the issue of the column modification's LDS reads and the
+//     wait for them -- the one LDS write -> read round trip of a step that no layout removes;
+//   * the wait states of the IEEE division (transcendental -> consumer, vcc -> v_div_fmas) are filled with address bumps and the
+//     sub-diagonal value instead of s_nop; one v_mov_b64 instead of three v_mov at the top (the scaled p and r come out of
+//     v_ldexp straight from the SGPR pairs the previous step's v_readlane left them in); addresses advance by one v_add each.
+//   * H(k+3, k) of the step k = n-2 is 0: its v_readlane reads lane n+1, whose c0 register no step writes (lanes > n are masked
+//     out of the column modification) and which is zeroed on entry.
+// ~112 instructions per step against ~140 compiled.  Registers v72..v127 and s40..s69 belong to this block (clobber list: the
+// compiler keeps nothing there across it); wait states follow the compiler's own code for the same sequences on gfx950 (one state
+// between a transcendental and its consumer, four between a VALU write of vcc and v_div_fmas, one between a VALU write and
+// v_readlane).
 //   in : k0 <= k1, (p, q, r) = H(k0.., k0-1) as forwarded, LDS byte addresses of HH(k0, lane), A(arow, k0), HH(k0, k0-1), lane masks
 //   out: k = first step NOT executed (k1 + 1, or the step whose |p|+|q|+|r| is 0: zero = 1), (p, q, r) for that step
 __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &q, double &r, uint32_t rowaddr, uint32_t coladdr,
-                                             uint32_t subaddr, uint64_t rowmask, uint64_t colmask, int &zero)
+                                             uint32_t subaddr, uint64_t rowmask, uint64_t colmask, uint64_t nmask, int &zero)
 {
     const uint64_t m_odd = 0xAAAAAAAAAAAAAAAAull, m_l0 = 1ull, m_lt3 = 7ull, m_l63 = 1ull << 63;
     int kk = k, z = 0;
@@ -999,19 +1007,21 @@ __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &
         "s_add_u32 s58, s56, 1\n\t"
         "s_add_u32 s59, s56, 2\n\t"
         "s_add_u32 s60, s56, 3\n\t"
-        "s_mov_b32 s61, %[subaddr]\n\t"
         "s_mov_b64 s[62:63], %[rowmask]\n\t"
         "s_mov_b64 s[64:65], %[colmask]\n\t"
-        "v_mov_b32 v72, %[rowaddr]\n\t"
+        "v_subrev_u32 v72, 0xd8, %[rowaddr]\n\t"                           // one row behind: reads at +216.., bumped before the writes
         "v_mov_b32 v73, %[coladdr]\n\t"
+        "s_sub_u32 s61, %[subaddr], 0xe0\n\t"
+        "v_mov_b32 v74, s61\n\t"                                            // one step behind, bumped before its write
+        "v_mov_b32 v118, 0\n\t"
+        "v_mov_b32 v119, 0\n\t"
         "s_mov_b32 %[z], 0\n"
         "Lqr_step_%=:\n\t"
         // row-modification inputs H(k..k+2, lane): in flight underneath the reflector chain
-        "ds_read_b64 v[80:81], v72\n\t"
-        "ds_read2_b64 v[82:85], v72 offset0:27 offset1:54\n\t"
+        "ds_read_b64 v[80:81], v72 offset:216\n\t"
+        "ds_read2_b64 v[82:85], v72 offset0:54 offset1:81\n\t"
         // reflector: x = |p| + |q| + |r|, exact power-of-two scaling, s = sqrt(p^2 + q^2 + r^2) with the sign of p
-        "v_mov_b32 v88, s42\n\t"
-        "v_mov_b32 v89, s43\n\t"
+        "v_mov_b64 v[88:89], s[42:43]\n\t"
         "v_add_f64 v[92:93], |s[40:41]|, |v[88:89]|\n\t"
         "v_add_f64 v[92:93], v[92:93], |s[44:45]|\n\t"
         "v_cmp_eq_f64 vcc, 0, v[92:93]\n\t"
@@ -1039,7 +1049,6 @@ __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &
         "v_fma_f64 v[110:111], v[108:109], v[106:107], v[104:105]\n\t"
         "v_xor_b32 v75, 0x80000000, v111\n\t"
         "v_cndmask_b32 v111, v111, v75, vcc\n\t"
-        "v_ldexp_f64 v[112:113], -v[110:111], v94\n\t"                       // H(k, k-1) = -s * 2^ex
         "v_add_f64 v[86:87], v[86:87], v[110:111]\n\t"                       // p = p + s
         // x = p/s, y = q/s, z = r/s, q = q/p, r = r/p as one vector division over lanes 0..4
         "v_cndmask_b32 v114, v90, v88, %[modd]\n\t"
@@ -1048,19 +1057,20 @@ __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &
         "v_cndmask_b32 v115, v115, v87, %[ml0]\n\t"
         "v_cndmask_b32 v116, v86, v110, %[mlt3]\n\t"
         "v_cndmask_b32 v117, v87, v111, %[mlt3]\n\t"
-        "v_div_scale_f64 v[118:119], s[68:69], v[116:117], v[116:117], v[114:115]\n\t"
-        "v_rcp_f64 v[120:121], v[118:119]\n\t"
-        "s_nop 0\n\t"
-        "v_fma_f64 v[122:123], -v[118:119], v[120:121], 1.0\n\t"
+        "v_div_scale_f64 v[76:77], s[68:69], v[116:117], v[116:117], v[114:115]\n\t"
+        "v_rcp_f64 v[120:121], v[76:77]\n\t"
+        "v_add_u32 v72, 0xd8, v72\n\t"                                       // (wait state) row address -> HH(k, lane)
+        "v_fma_f64 v[122:123], -v[76:77], v[120:121], 1.0\n\t"
         "v_fma_f64 v[120:121], v[120:121], v[122:123], v[120:121]\n\t"
-        "v_fma_f64 v[122:123], -v[118:119], v[120:121], 1.0\n\t"
+        "v_fma_f64 v[122:123], -v[76:77], v[120:121], 1.0\n\t"
         "v_fma_f64 v[120:121], v[120:121], v[122:123], v[120:121]\n\t"
         "v_div_scale_f64 v[124:125], vcc, v[114:115], v[116:117], v[114:115]\n\t"
         "v_mul_f64 v[126:127], v[124:125], v[120:121]\n\t"
-        "v_fma_f64 v[118:119], -v[118:119], v[126:127], v[124:125]\n\t"
-        "s_nop 1\n\t"
-        "v_div_fmas_f64 v[118:119], v[118:119], v[120:121], v[126:127]\n\t"
-        "v_div_fixup_f64 v[96:97], v[118:119], v[116:117], v[114:115]\n\t"
+        "v_fma_f64 v[76:77], -v[76:77], v[126:127], v[124:125]\n\t"
+        "v_ldexp_f64 v[112:113], -v[110:111], v94\n\t"                       // (wait state) H(k, k-1) = -s * 2^ex
+        "v_add_u32 v74, 0xe0, v74\n\t"                                       // (wait state) its address
+        "v_div_fmas_f64 v[76:77], v[76:77], v[120:121], v[126:127]\n\t"
+        "v_div_fixup_f64 v[96:97], v[76:77], v[116:117], v[114:115]\n\t"
         "s_nop 0\n\t"
         "v_readlane_b32 s46, v96, 0\n\t"
         "v_readlane_b32 s47, v97, 0\n\t"
@@ -1074,7 +1084,6 @@ __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &
         "v_readlane_b32 s55, v97, 4\n\t"
         // H(k, k-1) by lane 63
         "s_mov_b64 exec, %[ml63]\n\t"
-        "v_mov_b32 v74, s61\n\t"
         "ds_write_b64 v74, v[112:113]\n\t"
         // row modification, column j = lane, lanes k..26
         "s_mov_b64 exec, s[62:63]\n\t"
@@ -1091,10 +1100,18 @@ __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &
         "v_add_f64 v[102:103], v[82:83], -v[98:99]\n\t"
         "ds_write_b64 v72, v[100:101]\n\t"
         "ds_write2_b64 v72, v[102:103], v[104:105] offset0:27 offset1:54\n\t"
-        // column modification: H rows 0..k+3 (lanes 0..k+3) and V rows 0..26 (lanes 32..58), one stream
+        // column modification: H rows 0..min(n, k+3) (lanes 0..) and V rows 0..26 (lanes 32..58), one stream
         "s_mov_b64 exec, s[64:65]\n\t"
         "ds_read2_b64 v[106:109], v73 offset1:1\n\t"
         "ds_read_b64 v[110:111], v73 offset:16\n\t"
+        // ... while those reads make their round trip: counters and masks of step k + 1
+        "s_bitset0_b64 s[62:63], s56\n\t"
+        "s_add_u32 s56, s56, 1\n\t"
+        "s_add_u32 s58, s58, 1\n\t"
+        "s_add_u32 s59, s59, 1\n\t"
+        "s_add_u32 s60, s60, 1\n\t"
+        "s_bitset1_b64 s[64:65], s60\n\t"
+        "s_and_b64 s[64:65], s[64:65], %[nmask]\n\t"
         "s_waitcnt lgkmcnt(1)\n\t"
         "v_mul_f64 v[114:115], s[46:47], v[106:107]\n\t"
         "v_mul_f64 v[116:117], s[48:49], v[108:109]\n\t"
@@ -1110,22 +1127,13 @@ __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &
         "ds_write_b64 v73, v[122:123] offset:16\n\t"
         "ds_write2_b64 v73, v[118:119], v[120:121] offset1:1\n\t"
         "s_mov_b64 exec, s[66:67]\n\t"
-        // the next reflector comes from H(k+1..k+3, k) as just computed by lanes k+1..k+3
-        "v_readlane_b32 s40, v118, s58\n\t"
-        "v_readlane_b32 s41, v119, s58\n\t"
-        "v_readlane_b32 s42, v118, s59\n\t"
-        "v_readlane_b32 s43, v119, s59\n\t"
-        "v_readlane_b32 s44, v118, s60\n\t"
-        "v_readlane_b32 s45, v119, s60\n\t"
-        // advance to step k + 1
-        "s_bitset0_b64 s[62:63], s56\n\t"
-        "s_add_u32 s60, s60, 1\n\t"
-        "s_bitset1_b64 s[64:65], s60\n\t"
-        "s_add_u32 s56, s56, 1\n\t"
-        "s_add_u32 s58, s58, 1\n\t"
-        "s_add_u32 s59, s59, 1\n\t"
-        "s_addk_i32 s61, 0xe0\n\t"
-        "v_add_u32 v72, 0xd8, v72\n\t"
+        // the next reflector comes from H(k+1..k+3, k) as just computed by lanes k+1..k+3 (counters are already those of step k + 1)
+        "v_readlane_b32 s40, v118, s56\n\t"
+        "v_readlane_b32 s41, v119, s56\n\t"
+        "v_readlane_b32 s42, v118, s58\n\t"
+        "v_readlane_b32 s43, v119, s58\n\t"
+        "v_readlane_b32 s44, v118, s59\n\t"
+        "v_readlane_b32 s45, v119, s59\n\t"
         "v_add_u32 v73, 8, v73\n\t"
         "s_cmp_le_u32 s56, s57\n\t"
         "s_cbranch_scc1 Lqr_step_%=\n\t"
@@ -1141,8 +1149,8 @@ __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &
         "s_mov_b64 %[rout], s[44:45]"
         : [z] "=&s"(z), [kout] "=&s"(kk), [pout] "=&s"(po), [qout] "=&s"(qo), [rout] "=&s"(ro)
         : [p] "s"(p), [q] "s"(q), [r] "s"(r), [k] "s"(k), [k1] "s"(k1), [subaddr] "s"(subaddr), [rowmask] "s"(rowmask),
-          [colmask] "s"(colmask), [rowaddr] "v"(rowaddr), [coladdr] "v"(coladdr), [modd] "s"(m_odd), [ml0] "s"(m_l0), [mlt3] "s"(m_lt3),
-          [ml63] "s"(m_l63)
+          [colmask] "s"(colmask), [nmask] "s"(nmask), [rowaddr] "v"(rowaddr), [coladdr] "v"(coladdr), [modd] "s"(m_odd), [ml0] "s"(m_l0),
+          [mlt3] "s"(m_lt3), [ml63] "s"(m_l63)
         : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
           "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "v72", "v73", "v74", "v75", "v76",
           "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
@@ -1545,19 +1553,20 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             qr_step(m, std::true_type());
             int k = m + 1;
             if constexpr (!STAMP) {
-                // Steady-state steps k = m+1 .. n-3 (reflector forwarded from the previous step, three-row reflector, bulge row k+3
-                // inside the active window) run in ONE hand-scheduled asm loop: qr_steps_asm below.  Everything else -- the first
-                // step of a sweep, the last two, and the rare step that finds |p|+|q|+|r| == 0 -- stays with qr_step.
-                while (k <= n - 3) {
+                // The three-row steps k = m+1 .. n-2 with a forwarded reflector run in ONE hand-scheduled asm loop (qr_steps_asm).
+                // The first step of a sweep, the last (two-row) one, and the rare step that finds |p|+|q|+|r| == 0 stay with qr_step.
+                while (k <= n - 2) {
                     if (!fwd) { qr_step(k, std::true_type()); k++; continue; }
                     const uint32_t hs0 = lds_addr32(Hs), vs0 = lds_addr32(Vs);
                     const uint32_t rowaddr = hs0 + (uint32_t)(k * EN + lane) * 8u;
                     const uint32_t coladdr = ((lane < 32) ? hs0 : vs0) + (uint32_t)(arow * EN + k) * 8u;
                     const uint32_t subaddr = hs0 + (uint32_t)(k * EN + k - 1) * 8u;
+                    const uint64_t vmask = ((1ull << EN) - 1) << 32;                                      // V rows 0..26 on lanes 32..58
+                    const uint64_t nmask = ((1ull << (n + 1)) - 1) | vmask;                               // H rows 0..n
                     const uint64_t rowmask = ((1ull << EN) - 1) & (~0ull << k);                          // lanes k..26
-                    const uint64_t colmask = ((1ull << (k + 4)) - 1) | (((1ull << EN) - 1) << 32);       // H rows 0..k+3 | V rows 0..26
+                    const uint64_t colmask = (((1ull << (k + 4)) - 1) | vmask) & nmask;                   // H rows 0..min(n, k+3) | V rows
                     int zero = 0;
-                    qr_steps_asm(k, n - 3, fp, fq, fr, rowaddr, coladdr, subaddr, rowmask, colmask, zero);
+                    qr_steps_asm(k, n - 2, fp, fq, fr, rowaddr, coladdr, subaddr, rowmask, colmask, nmask, zero);
                     if (zero) { qr_step(k, std::true_type()); k++; }   // that step sees the zero itself and returns with fwd = false
                 }
             }
