@@ -989,10 +989,10 @@ __device__ __forceinline__ uint32_t lds_addr32(const void *p) { return (uint32_t
 // compiler keeps nothing there across it); wait states follow the compiler's own code for the same sequences on gfx950 (one state
 // between a transcendental and its consumer, four between a VALU write of vcc and v_div_fmas, one between a VALU write and
 // v_readlane).
-//   in : k0 <= k1, (p, q, r) = H(k0.., k0-1) as forwarded, LDS byte addresses of HH(k0, lane), A(arow, k0), HH(k0, k0-1), lane masks
+//   in : k0 <= k1, (p, q, r) = H(k0.., k0-1) as forwarded (or from the m search: first63 = 0 masks the first step's H(k, k-1) store), LDS byte addresses of HH(k0, lane), A(arow, k0), HH(k0, k0-1), lane masks
 //   out: k = first step NOT executed (k1 + 1, or the step whose |p|+|q|+|r| is 0: zero = 1), (p, q, r) for that step
 __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &q, double &r, uint32_t rowaddr, uint32_t coladdr,
-                                             uint32_t subaddr, uint64_t rowmask, uint64_t colmask, uint64_t nmask, int &zero)
+                                             uint32_t subaddr, uint64_t rowmask, uint64_t colmask, uint64_t nmask, uint64_t first63, int &zero)
 {
     const uint64_t m_odd = 0xAAAAAAAAAAAAAAAAull, m_l0 = 1ull, m_lt3 = 7ull, m_l63 = 1ull << 63;
     int kk = k, z = 0;
@@ -1009,6 +1009,7 @@ __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &
         "s_add_u32 s60, s56, 3\n\t"
         "s_mov_b64 s[62:63], %[rowmask]\n\t"
         "s_mov_b64 s[64:65], %[colmask]\n\t"
+        "s_mov_b64 s[70:71], %[first63]\n\t"                                // lanes that store H(k, k-1) in the FIRST step run here (none: the caller does it)
         "v_subrev_u32 v72, 0xd8, %[rowaddr]\n\t"                           // one row behind: reads at +216.., bumped before the writes
         "v_mov_b32 v73, %[coladdr]\n\t"
         "s_sub_u32 s61, %[subaddr], 0xe0\n\t"
@@ -1083,7 +1084,7 @@ __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &
         "v_readlane_b32 s54, v96, 4\n\t"
         "v_readlane_b32 s55, v97, 4\n\t"
         // H(k, k-1) by lane 63
-        "s_mov_b64 exec, %[ml63]\n\t"
+        "s_mov_b64 exec, s[70:71]\n\t"
         "ds_write_b64 v74, v[112:113]\n\t"
         // row modification, column j = lane, lanes k..26
         "s_mov_b64 exec, s[62:63]\n\t"
@@ -1112,6 +1113,7 @@ __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &
         "s_add_u32 s60, s60, 1\n\t"
         "s_bitset1_b64 s[64:65], s60\n\t"
         "s_and_b64 s[64:65], s[64:65], %[nmask]\n\t"
+        "s_mov_b64 s[70:71], %[ml63]\n\t"
         "s_waitcnt lgkmcnt(1)\n\t"
         "v_mul_f64 v[114:115], s[46:47], v[106:107]\n\t"
         "v_mul_f64 v[116:117], s[48:49], v[108:109]\n\t"
@@ -1150,8 +1152,8 @@ __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &
         : [z] "=&s"(z), [kout] "=&s"(kk), [pout] "=&s"(po), [qout] "=&s"(qo), [rout] "=&s"(ro)
         : [p] "s"(p), [q] "s"(q), [r] "s"(r), [k] "s"(k), [k1] "s"(k1), [subaddr] "s"(subaddr), [rowmask] "s"(rowmask),
           [colmask] "s"(colmask), [nmask] "s"(nmask), [rowaddr] "v"(rowaddr), [coladdr] "v"(coladdr), [modd] "s"(m_odd), [ml0] "s"(m_l0),
-          [mlt3] "s"(m_lt3), [ml63] "s"(m_l63)
-        : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+          [mlt3] "s"(m_lt3), [ml63] "s"(m_l63), [first63] "s"(first63)
+        : "memory", "vcc", "scc", "s70", "s71", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
           "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "v72", "v73", "v74", "v75", "v76",
           "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
           "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
@@ -1550,13 +1552,19 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                 PNP_STAMP(3);
                 if constexpr (STAMP) clk[4] += 1;
             };
-            qr_step(m, std::true_type());
-            int k = m + 1;
+            int k = m;
             if constexpr (!STAMP) {
-                // The three-row steps k = m+1 .. n-2 with a forwarded reflector run in ONE hand-scheduled asm loop (qr_steps_asm).
-                // The first step of a sweep, the last (two-row) one, and the rare step that finds |p|+|q|+|r| == 0 stay with qr_step.
+                // The three-row steps k = m .. n-2 run in ONE hand-scheduled asm loop (qr_steps_asm).  The first step of a sweep takes
+                // the same path as a forwarded one: its (p, q, r) come out of the m search scaled to |p|+|q|+|r| in [0.5, 1), so the
+                // loop's own power-of-two scaling is the identity (exponent 0) and the arithmetic is the reference's; only its
+                // sub-diagonal differs -- H(m, m-1) is negated in place iff l != m -- which is done here, after the loop has run it
+                // with the sub-diagonal store masked off.  The last (two-row) step and the rare step that finds |p|+|q|+|r| == 0
+                // stay with qr_step.
+                const double hm = (l != m) ? HH(m, m - 1) : 0.0;
                 while (k <= n - 2) {
-                    if (!fwd) { qr_step(k, std::true_type()); k++; continue; }
+                    const bool first = k == m;
+                    if (!first && !fwd) { qr_step(k, std::true_type()); k++; continue; }
+                    double ap = first ? p : fp, aq = first ? q : fq, ar = first ? r : fr;
                     const uint32_t hs0 = lds_addr32(Hs), vs0 = lds_addr32(Vs);
                     const uint32_t rowaddr = hs0 + (uint32_t)(k * EN + lane) * 8u;
                     const uint32_t coladdr = ((lane < 32) ? hs0 : vs0) + (uint32_t)(arow * EN + k) * 8u;
@@ -1566,9 +1574,14 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                     const uint64_t rowmask = ((1ull << EN) - 1) & (~0ull << k);                          // lanes k..26
                     const uint64_t colmask = (((1ull << (k + 4)) - 1) | vmask) & nmask;                   // H rows 0..min(n, k+3) | V rows
                     int zero = 0;
-                    qr_steps_asm(k, n - 2, fp, fq, fr, rowaddr, coladdr, subaddr, rowmask, colmask, nmask, zero);
+                    qr_steps_asm(k, n - 2, ap, aq, ar, rowaddr, coladdr, subaddr, rowmask, colmask, nmask, first ? 0ull : (1ull << 63), zero);
+                    if (first && k > m && l != m && lane == 63) HH(m, m - 1) = -hm;
+                    if (k > m) { fp = ap; fq = aq; fr = ar; fwd = true; }
                     if (zero) { qr_step(k, std::true_type()); k++; }   // that step sees the zero itself and returns with fwd = false
                 }
+            } else {
+                qr_step(m, std::true_type());
+                k = m + 1;
             }
             for (; k <= n - 2; k++) qr_step(k, std::true_type());
             qr_step(n - 1, std::false_type());
