@@ -969,6 +969,13 @@ __device__ __forceinline__ double sumsq_desc(const double *u, int hi, int lo)
     return h;
 }
 
+// a wave-uniform double as an SGPR pair (asm "s" operands must not be handed a VGPR: the compiler does not insert the readfirstlane itself)
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ uint32_t lds_addr32(const void *p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p; }
 
 // The three-row double-shift steps of one Francis sweep with a forwarded reflector, k = k0 .. k1 <= n-2, as ONE hand-scheduled
@@ -1161,6 +1168,153 @@ __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &
     k = kk; zero = z; p = po; q = qo; r = ro;
 }
 
+// The head of one Francis sweep on the common path (no deflation this sweep, no exceptional shift) as one hand-scheduled block:
+// the deflation test (l search), the shifts x, y, w, the search for two consecutive small sub-diagonal elements (m search: p, q, r of
+// the first reflector, scaled by an exact power of two) and the zeroing of H(i, i-2), H(i, i-3) below the bulge's start.  Same
+// per-lane arithmetic and the same selections (largest passing lane) as the compiled code it replaces, which read its operands with
+// ten LDS loads behind four exec-masked regions and two ballots (~2 k cycles per sweep): here every lane loads the seven entries of its
+// 3 x 3 diagonal neighbourhood with four LDS instructions off one base address, together with the four entries the shifts need, all
+// lanes compute, and the valid-lane ranges are applied to the compare masks by SALU.  Registers v72..v127 / s40..s71 as qr_steps_asm.
+//   status 0: proceed with the double-shift steps from m (l, m, p, q, r valid, zeroing done)
+//   status 1: l >= n - 1 (one or two roots to deflate): nothing was written, the caller's compiled path handles the sweep
+__device__ __forceinline__ void qr_sweep_head_asm(int n, uint32_t hs0, int lane, double norm, int &status, int &l_out, int &m_out,
+                                                  double &p, double &q, double &r)
+{
+    const uint32_t base = hs0 + (uint32_t)lane * 224u - 224u;     // &HH(lane - 1, lane - 1): every operand of lane `lane` is base + const
+    const uint32_t nbase = hs0 + (uint32_t)(n - 1) * 224u;        // &HH(n - 1, n - 1)
+    const uint64_t lvalid = ((1ull << (n + 1)) - 1) & ~1ull;      // lanes 1..n take part in the l search
+    int st = 0, lo = 0, mo = 0;
+    double po = 0.0, qo = 0.0, ro = 0.0;
+    asm volatile(
+        "s_mov_b64 s[66:67], exec\n\t"
+        "v_mov_b32 v72, %[base]\n\t"
+        "v_mov_b32 v73, %[nbase]\n\t"
+        // per lane i: dm1 = H(i-1,i-1) [v80], sub = H(i,i-1) [v82], d0 = H(i,i) [v84], sup = H(i,i+1) [v86],
+        //             subp1 = H(i+1,i) [v88], dp1 = H(i+1,i+1) [v90], subp2 = H(i+2,i+1) [v92];  uniform: y, H(n-1,n) [v94..97], H(n,n-1), x [v98..101]
+        "ds_read2_b64 v[80:83], v72 offset1:27\n\t"
+        "ds_read2_b64 v[84:87], v72 offset0:28 offset1:29\n\t"
+        "ds_read2_b64 v[88:91], v72 offset0:55 offset1:56\n\t"
+        "ds_read_b64 v[92:93], v72 offset:664\n\t"
+        "ds_read2_b64 v[94:97], v73 offset1:1\n\t"
+        "ds_read2_b64 v[98:101], v73 offset0:27 offset1:28\n\t"
+        "s_mov_b32 s40, %[n]\n\t"
+        "s_waitcnt lgkmcnt(4)\n\t"
+        // ---- l search: small = |H(i,i-1)| < eps * (|H(i-1,i-1)| + |H(i,i)|  (or norm if that sum is 0)), lanes 1..n
+        "v_add_f64 v[102:103], |v[80:81]|, |v[84:85]|\n\t"
+        "v_cmp_eq_f64 vcc, 0, v[102:103]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32 v103, v103, %[normhi], vcc\n\t"
+        "v_cndmask_b32 v102, v102, %[normlo], vcc\n\t"
+        "v_ldexp_f64 v[102:103], v[102:103], %[m52]\n\t"
+        "v_cmp_lt_f64 s[42:43], |v[82:83]|, v[102:103]\n\t"
+        "s_nop 1\n\t"
+        "s_and_b64 s[42:43], s[42:43], %[lvalid]\n\t"
+        "s_flbit_i32_b64 s44, s[42:43]\n\t"
+        "s_sub_u32 s44, 63, s44\n\t"
+        "s_cmp_eq_u64 s[42:43], 0\n\t"
+        "s_cselect_b32 s44, 0, s44\n\t"                                      // s44 = l
+        "s_sub_u32 s45, s40, 1\n\t"
+        "s_cmp_ge_u32 s44, s45\n\t"
+        "s_cbranch_scc1 Lsw_defl_%=\n\t"
+        // ---- shifts: x = H(n,n), y = H(n-1,n-1), w = H(n,n-1) * H(n-1,n)
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mul_f64 v[104:105], v[98:99], v[96:97]\n\t"                       // w
+        // ---- m search, lane mm = i in l..n-2
+        "v_add_f64 v[106:107], v[100:101], -v[84:85]\n\t"                    // rr = x - zz
+        "v_add_f64 v[108:109], v[94:95], -v[84:85]\n\t"                      // ss = y - zz
+        "v_mul_f64 v[110:111], v[106:107], v[108:109]\n\t"
+        "v_add_f64 v[110:111], v[110:111], -v[104:105]\n\t"                  // rr*ss - w
+        "v_div_scale_f64 v[112:113], s[68:69], v[88:89], v[88:89], v[110:111]\n\t"
+        "v_rcp_f64 v[114:115], v[112:113]\n\t"
+        "v_add_f64 v[122:123], v[90:91], -v[84:85]\n\t"                      // (wait state) qm = H(i+1,i+1) - zz ...
+        "v_fma_f64 v[116:117], -v[112:113], v[114:115], 1.0\n\t"
+        "v_fma_f64 v[114:115], v[114:115], v[116:117], v[114:115]\n\t"
+        "v_fma_f64 v[116:117], -v[112:113], v[114:115], 1.0\n\t"
+        "v_fma_f64 v[114:115], v[114:115], v[116:117], v[114:115]\n\t"
+        "v_div_scale_f64 v[118:119], vcc, v[110:111], v[88:89], v[110:111]\n\t"
+        "v_mul_f64 v[120:121], v[118:119], v[114:115]\n\t"
+        "v_fma_f64 v[112:113], -v[112:113], v[120:121], v[118:119]\n\t"
+        "v_add_f64 v[122:123], v[122:123], -v[106:107]\n\t"                  // (wait state) ... - rr
+        "v_add_f64 v[122:123], v[122:123], -v[108:109]\n\t"                  // (wait state) ... - ss
+        "v_div_fmas_f64 v[112:113], v[112:113], v[114:115], v[120:121]\n\t"
+        "v_div_fixup_f64 v[110:111], v[112:113], v[88:89], v[110:111]\n\t"
+        "v_add_f64 v[110:111], v[110:111], v[86:87]\n\t"                     // pm = (rr*ss - w) / H(i+1,i) + H(i,i+1)
+        "v_add_f64 v[124:125], |v[110:111]|, |v[122:123]|\n\t"
+        "v_add_f64 v[124:125], v[124:125], |v[92:93]|\n\t"                   // |pm| + |qm| + |rm|
+        "v_frexp_exp_i32_f64 v74, v[124:125]\n\t"
+        "v_sub_u32 v74, 0, v74\n\t"
+        "v_ldexp_f64 v[110:111], v[110:111], v74\n\t"                        // pm, qm, rm scaled by the exact power of two
+        "v_ldexp_f64 v[122:123], v[122:123], v74\n\t"
+        "v_ldexp_f64 v[126:127], v[92:93], v74\n\t"
+        "v_add_f64 v[124:125], |v[122:123]|, |v[126:127]|\n\t"
+        "v_mul_f64 v[124:125], v[124:125], |v[82:83]|\n\t"                   // |H(i,i-1)| * (|qm| + |rm|)
+        "v_add_f64 v[116:117], |v[80:81]|, |v[84:85]|\n\t"
+        "v_add_f64 v[116:117], v[116:117], |v[90:91]|\n\t"                   // |H(i-1,i-1)| + |zz| + |H(i+1,i+1)|
+        "v_mul_f64 v[116:117], |v[110:111]|, v[116:117]\n\t"
+        "v_ldexp_f64 v[116:117], v[116:117], %[m52]\n\t"
+        "v_cmp_lt_f64 s[46:47], v[124:125], v[116:117]\n\t"
+        // lanes l..n-2 take part; lane l always passes
+        "s_lshl_b64 s[48:49], 1, s44\n\t"                                    // bit l
+        "s_sub_u32 s50, s40, 1\n\t"
+        "s_lshl_b64 s[50:51], 1, s50\n\t"
+        "s_sub_u32 s50, s50, 1\n\t"
+        "s_subb_u32 s51, s51, 0\n\t"                                         // bits 0..n-2
+        "s_sub_u32 s52, s48, 1\n\t"
+        "s_subb_u32 s53, s49, 0\n\t"                                         // bits 0..l-1
+        "s_andn2_b64 s[50:51], s[50:51], s[52:53]\n\t"                       // bits l..n-2
+        "s_or_b64 s[46:47], s[46:47], s[48:49]\n\t"
+        "s_and_b64 s[46:47], s[46:47], s[50:51]\n\t"
+        "s_flbit_i32_b64 s45, s[46:47]\n\t"
+        "s_sub_u32 s45, 63, s45\n\t"                                         // s45 = m
+        "v_readlane_b32 s54, v110, s45\n\t"
+        "v_readlane_b32 s55, v111, s45\n\t"
+        "v_readlane_b32 s56, v122, s45\n\t"
+        "v_readlane_b32 s57, v123, s45\n\t"
+        "v_readlane_b32 s58, v126, s45\n\t"
+        "v_readlane_b32 s59, v127, s45\n\t"
+        // H(i, i-2) = 0 for i in m+2..n, H(i, i-3) = 0 for i in m+3..n
+        "s_add_u32 s60, s40, 1\n\t"
+        "s_lshl_b64 s[60:61], 1, s60\n\t"
+        "s_sub_u32 s60, s60, 1\n\t"
+        "s_subb_u32 s61, s61, 0\n\t"                                         // bits 0..n
+        "s_add_u32 s62, s45, 2\n\t"
+        "s_lshl_b64 s[62:63], -1, s62\n\t"                                   // bits m+2..63
+        "s_and_b64 s[62:63], s[62:63], s[60:61]\n\t"
+        "v_mov_b32 v76, 0\n\t"
+        "v_mov_b32 v77, 0\n\t"
+        "s_mov_b64 exec, s[62:63]\n\t"
+        "ds_write_b64 v72, v[76:77] offset:208\n\t"                          // &H(i, i-2) = base + 224 - 16
+        "s_add_u32 s64, s45, 2\n\t"
+        "s_bitset0_b64 s[62:63], s64\n\t"
+        "s_mov_b64 exec, s[62:63]\n\t"
+        "ds_write_b64 v72, v[76:77] offset:200\n\t"                          // &H(i, i-3)
+        "s_mov_b64 exec, s[66:67]\n\t"
+        "s_mov_b32 %[st], 0\n\t"
+        "s_branch Lsw_done_%=\n"
+        "Lsw_defl_%=:\n\t"
+        "s_mov_b32 %[st], 1\n\t"
+        "s_mov_b32 s45, 0\n\t"
+        "s_mov_b64 s[54:55], 0\n\t"
+        "s_mov_b64 s[56:57], 0\n\t"
+        "s_mov_b64 s[58:59], 0\n"
+        "Lsw_done_%=:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b32 %[lo], s44\n\t"
+        "s_mov_b32 %[mo], s45\n\t"
+        "s_mov_b64 %[po], s[54:55]\n\t"
+        "s_mov_b64 %[qo], s[56:57]\n\t"
+        "s_mov_b64 %[ro], s[58:59]"
+        : [st] "=&s"(st), [lo] "=&s"(lo), [mo] "=&s"(mo), [po] "=&s"(po), [qo] "=&s"(qo), [ro] "=&s"(ro)
+        : [base] "v"(base), [nbase] "s"(nbase), [n] "s"(n), [lvalid] "s"(lvalid), [normlo] "v"(__double2loint(norm)),
+          [normhi] "v"(__double2hiint(norm)), [m52] "s"(-52)
+        : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+          "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "v72", "v73", "v74", "v75", "v76",
+          "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
+          "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",
+          "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+    status = st; l_out = lo; m_out = mo; p = po; q = qo; r = ro;
+}
+
 struct EigArgs {
     PnpProblem prob[kPnpMaxBatch];
     int32_t H, S;
@@ -1319,8 +1473,16 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
         // l = largest index in (low, n] whose sub-diagonal element is negligible (else low).  The reference scans
         // l = n, n-1, ... sequentially; every index is independent, so lane l tests its own and a ballot picks the
         // same l (exact reformulation: same arithmetic per index, same selection).
-        int l;
-        {
+        int l = 0, m = 0;
+        bool head = false;   // the sweep's head (l search, shifts, m search, zeroing) was done by qr_sweep_head_asm
+        if constexpr (!STAMP) {
+            if (n >= 2 && iter != 10 && iter != 30 && iter < 60) {   // (exceptional shifts and the iteration limit stay compiled)
+                int st = 1;
+                qr_sweep_head_asm(n, lds_addr32(Hs), lane, norm, st, l, m, p, q, r);
+                head = st == 0;
+            }
+        }
+        if (!head) {
             bool small = false;
             if (lane > low && lane <= n) {
                 double ss = fabs(HH(lane - 1, lane - 1)) + fabs(HH(lane, lane));
@@ -1330,13 +1492,13 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             const unsigned long long bm = __builtin_amdgcn_ballot_w64(small);
             l = bm ? 63 - __builtin_clzll(bm) : low;
         }
-        if (l == n) {  // one root
+        if (!head && l == n) {  // one root
             const double v = HH(n, n) + exshift;
             WAVE_SYNC();
             if (lane == 0) { HH(n, n) = v; wr[n] = v; wi[n] = 0.0; }
             WAVE_SYNC();
             n--; iter = 0;
-        } else if (l == n - 1) {  // two roots
+        } else if (!head && l == n - 1) {  // two roots
             w = HH(n, n - 1) * HH(n - 1, n);
             p = (HH(n - 1, n - 1) - HH(n, n)) / 2.0;
             q = p * p + w;
@@ -1384,6 +1546,9 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             }
             n -= 2; iter = 0;
         } else {
+          if (head) {
+            iter++;
+          } else {
             x = HH(n, n); y = 0.0; w = 0.0;
             if (l < n) { y = HH(n - 1, n - 1); w = HH(n, n - 1) * HH(n - 1, n); }
             if (iter == 10) {  // Wilkinson's exceptional shift
@@ -1414,7 +1579,6 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             // two consecutive small sub-diagonal elements: the reference scans m = n-2, n-3, ..., l and stops at the first
             // m that passes the test (or at m == l).  Lane m evaluates its own candidate (p,q,r normalised as in the
             // reference); the ballot selects the largest passing m; p,q,r come from that lane.  Exact reformulation.
-            int m;
             {
                 double pm = 0.0, qm = 0.0, rm = 0.0;
                 bool pass = false;
@@ -1442,6 +1606,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             WAVE_SYNC();
             if (lane >= m + 2 && lane <= n) { HH(lane, lane - 2) = 0.0; if (lane > m + 2) HH(lane, lane - 3) = 0.0; }
             WAVE_SYNC();
+          }
             // Double QR step on rows l..n, columns m..n.  Per step: (1) the reflector from column k-1, (2) row modification
             // (lane = column j of H), (3) column modification (lane = row i of H) together with the accumulation into V
             // (lanes 32..58 = row i of V): both have the form  pp = x*A(i,k) + y*A(i,k+1) [+ z*A(i,k+2)], so one
@@ -1564,7 +1729,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                 while (k <= n - 2) {
                     const bool first = k == m;
                     if (!first && !fwd) { qr_step(k, std::true_type()); k++; continue; }
-                    double ap = first ? p : fp, aq = first ? q : fq, ar = first ? r : fr;
+                    double ap = uniform_f64(first ? p : fp), aq = uniform_f64(first ? q : fq), ar = uniform_f64(first ? r : fr);
                     const uint32_t hs0 = lds_addr32(Hs), vs0 = lds_addr32(Vs);
                     const uint32_t rowaddr = hs0 + (uint32_t)(k * EN + lane) * 8u;
                     const uint32_t coladdr = ((lane < 32) ? hs0 : vs0) + (uint32_t)(arow * EN + k) * 8u;
