@@ -1352,6 +1352,117 @@ struct EigArgs {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        \
     } while (0)
 
+// ---- Hessenberg reduction with compile-time step index (round 4) ------------------------------------------------------------------
+// orthes / ortran step M works on rows / columns M..26: L = 27 - M terms per serial sum.  With M a template parameter every sum is
+// straight-line code -- no loop counters, no remainder handling, the operands of a sum loaded once and kept in registers for the
+// update that follows it (the looped form re-read them) -- in the reference's term order.  25 + 25 instantiations, executed once each.
+template <int M>
+__device__ __forceinline__ void orthes_step(double *Hs, double *us, double *ortm, int lane)
+{
+    constexpr int L = EN - M, high = EN - 1;
+    double scale = 0.0;                                   // scale = sum_{i = M..high} |H(i, M-1)|, ascending (wave-uniform chain)
+    {
+        double c[L];
+#pragma unroll
+        for (int t = 0; t < L; t++) c[t] = HH(M + t, M - 1);
+#pragma unroll
+        for (int t = 0; t < L; t++) scale = scale + fabs(c[t]);
+    }
+    if (scale != 0.0) {
+        const bool mine = lane >= M && lane <= high;
+        const double colv = mine ? HH(lane, M - 1) : 0.0;
+        const double ov = colv / scale;                   // u_i = H(i, M-1) / scale on lanes M..high
+        if (lane < EN + 5) us[lane] = mine ? ov : 0.0;
+        WAVE_SYNC();
+        double h = 0.0;                                   // h = sum_{i = high..M} u_i^2, descending
+        {
+            double u[L];
+#pragma unroll
+            for (int t = 0; t < L; t++) u[t] = us[M + t];
+#pragma unroll
+            for (int t = L - 1; t >= 0; t--) h = h + u[t] * u[t];
+        }
+        double g = sqrt(h);
+        const double om = us[M];
+        if (om > 0) g = -g;
+        h = h - om * g;
+        WAVE_SYNC();
+        if (lane == M) us[M] = om - g;
+        WAVE_SYNC();
+        if (lane >= M && lane < EN) {                     // H = (I - u u^T/h) H, column j = lane
+            double b[L];
+#pragma unroll
+            for (int t = 0; t < L; t++) b[t] = HH(M + t, lane);
+            double f = 0.0;
+#pragma unroll
+            for (int t = L - 1; t >= 0; t--) f = f + us[M + t] * b[t];
+            f = f / h;
+            const double c = -f;
+#pragma unroll
+            for (int t = 0; t < L; t++) HH(M + t, lane) = b[t] + c * us[M + t];
+        }
+        WAVE_SYNC();
+        if (lane <= high) {                               // H = H (I - u u^T/h), row i = lane
+            double b[L];
+#pragma unroll
+            for (int t = 0; t < L; t++) b[t] = HH(lane, M + t);
+            double f = 0.0;
+#pragma unroll
+            for (int t = L - 1; t >= 0; t--) f = f + us[M + t] * b[t];
+            f = f / h;
+            const double c = -f;
+#pragma unroll
+            for (int t = 0; t < L; t++) HH(lane, M + t) = b[t] + c * us[M + t];
+        }
+        WAVE_SYNC();
+        if (lane == 0) {
+            ortm[M] = scale * (om - g);
+            HH(M, M - 1) = scale * g;
+        }
+        WAVE_SYNC();
+    } else {
+        if (lane == 0) ortm[M] = 0.0;
+        WAVE_SYNC();
+    }
+}
+template <int M>
+__device__ __forceinline__ void ortran_step(double *Hs, double *Vs, double *us, const double *ortm, int lane)
+{
+    constexpr int L = EN - M, high = EN - 1;
+    const double hmm = HH(M, M - 1);
+    if (hmm != 0.0) {
+        const double om = ortm[M];
+        // u = (ort[M], H(M+1, M-1), .., H(high, M-1)) staged contiguously for the broadcast reads
+        if (lane >= M && lane <= high) us[lane] = (lane == M) ? om : HH(lane, M - 1);
+        WAVE_SYNC();
+        if (lane >= M && lane <= high) {
+            double b[L];
+#pragma unroll
+            for (int t = 0; t < L; t++) b[t] = VV(M + t, lane);
+            double g = 0.0;
+#pragma unroll
+            for (int t = 0; t < L; t++) g = g + us[M + t] * b[t];
+            g = (g / om) / hmm;
+#pragma unroll
+            for (int t = 0; t < L; t++) VV(M + t, lane) = b[t] + g * us[M + t];
+        }
+        WAVE_SYNC();
+    }
+}
+template <int M>
+struct HessenbergSteps {
+    static __device__ __forceinline__ void orthes(double *Hs, double *us, double *ortm, int lane)
+    {
+        orthes_step<M>(Hs, us, ortm, lane);
+        if constexpr (M < EN - 2) HessenbergSteps<M + 1>::orthes(Hs, us, ortm, lane);
+    }
+    static __device__ __forceinline__ void ortran(double *Hs, double *Vs, double *us, const double *ortm, int lane)
+    {
+        ortran_step<M>(Hs, Vs, us, ortm, lane);
+        if constexpr (M > 1) HessenbergSteps<M - 1>::ortran(Hs, Vs, us, ortm, lane);
+    }
+};
+
 // STAMP = true (CHIP_PNP_STAMPS=1, tuning only): the wave accumulates s_memtime differences per segment of the QR iteration and
 // leaves them in a.stamps[hyp][0..7]: 0 sweep overhead (deflation test, shifts, m search), 1 reflector (|p|+|q|+|r| .. quotients
 // read back), 2 row modification, 3 column modification + forwarding, 4 number of double-shift steps, 5 number of sweeps,
@@ -1395,6 +1506,11 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     // ================= Householder reduction to Hessenberg form (orthes) =================
     // The reflector u (EISPACK's ort[]) lives in LDS (us[], zero outside m..high): the serial sums read it as wave-uniform
     // broadcasts, four terms ahead of the arithmetic (dot_desc / dot_asc / axpy_rows above).  Term order is the reference's.
+#ifndef CHIP_PNP_HESS_LOOPED
+    HessenbergSteps<1>::orthes(Hs, us, ortm, lane);
+    // accumulate the reflectors into V (ortran)
+    HessenbergSteps<EN - 2>::ortran(Hs, Vs, us, ortm, lane);
+#else
     for (int m = low + 1; m <= high - 1; m++) {
         // scale = sum_{i = m..high} |H(i, m-1)|, ascending: every lane runs the same chain on broadcast reads of the column
         const double scale = abs_sum_asc<EN>(&HH(0, m - 1), m, high, 0.0);
@@ -1454,6 +1570,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             WAVE_SYNC();
         }
     }
+#endif
     for (int e = lane; e < EN * EN; e += 64) {
         const int i = e / EN, j = e % EN;
         if (j < i - 1) Hs[e] = 0.0;
