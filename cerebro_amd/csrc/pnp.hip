@@ -206,6 +206,13 @@ struct SolveArgs {
     int32_t *sample;    // [H][kSampleMax]
     int32_t *ok;        // [H] 1 = S valid, 0 = singular D
     unsigned long long *stamps;   // tuning only (CHIP_PNP_STAMPS): [H][8] s_memtime at the phase boundaries of pnp_build_solve
+    // The correspondences arrive in pinned, device-mapped HOST memory (no H2D copy in front of the launch: 6 us of copy + ~10 us of
+    // dependent-launch latency on a 0.5 ms call).  prob[].X / .uv of THIS kernel point there: a workgroup reads its 15 sample points across
+    // PCIe (one ~2 us round trip underneath the sampler), and all workgroups together copy the n_in doubles to in_dev, which is what
+    // pnp_eig_score's prob[] points at -- it scores every hypothesis against all N points and must not do that over PCIe.
+    const double *in_host;
+    double *in_dev;
+    int64_t n_in;
 };
 
 constexpr int kSolveThreads = 448;   // waves 0..5 hold the Macaulay block (3 row groups x 128 columns), wave 6 factorises panels
@@ -258,6 +265,8 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
 
 #define SOLVE_STAMP(i) do { if (STAMP && tid == 0) a.stamps[(size_t)slot * 24 + (i)] = __builtin_readcyclecounter(); } while (0)
     SOLVE_STAMP(0);
+    if (a.in_host != nullptr)   // this launch's share of the host -> device copy of the correspondences (see SolveArgs)
+        for (int64_t e = (int64_t)blockIdx.x * kSolveThreads + tid; e < a.n_in; e += (int64_t)gridDim.x * kSolveThreads) a.in_dev[e] = a.in_host[e];
     // ---- sampler: partial Fisher-Yates over a virtual identity permutation (theia::RandomSampler restated) ----
     if (wave == 0) {
         const int sv = ransac_sample_wave(pr.seed, hyp, pr.N, n, lane);
@@ -2023,7 +2032,8 @@ struct PnpState {
     PnpTables *tab_dev = nullptr;
     // device scratch, grown on demand
     double *X = nullptr, *uv = nullptr;   // device: one allocation, [X of all problems | uv of all problems]
-    double *h_in = nullptr;               // pinned staging of the same layout: one DMA per call instead of 2 pageable copies per problem
+    double *h_in = nullptr;               // pinned, device-mapped staging of the same layout: pnp_build_solve reads it in place (d_hin)
+    double *d_hin = nullptr;              // device view of h_in
     int32_t cap_N = 0;
     double *Sg = nullptr, *Tg = nullptr;
     int32_t *sample = nullptr, *ok = nullptr;
@@ -2087,6 +2097,7 @@ static int pnp_reserve(Ctx *c, PnpState *st, int N, int H, int words, int P)
         st->X = st->uv = st->h_in = nullptr; st->cap_N = 0;
         CHIP_HIP(c, hipMalloc(&st->X, sizeof(double) * 5 * (size_t)N));
         CHIP_HIP(c, hipHostMalloc(&st->h_in, sizeof(double) * 5 * (size_t)N, hipHostMallocDefault));
+        CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->d_hin, st->h_in, 0));
         st->cap_N = N;
     }
     if (H > st->cap_H || words > st->cap_words) {
@@ -2153,13 +2164,20 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
         PnpProblem pr;
         pr.X = st->X + 3 * (size_t)off; pr.uv = st->uv + 2 * (size_t)off; pr.N = N[i]; pr.pad_ = 0;
         pr.seed = seeds ? seeds[i] : p->seed;
-        sa.prob[i] = pr;
-        ea.prob[i] = pr;
+        ea.prob[i] = pr;                                   // pnp_eig_score: the device copy (made by pnp_build_solve)
+        pr.X = st->d_hin + 3 * (size_t)off; pr.uv = st->d_hin + 3 * (size_t)Ntot + 2 * (size_t)off;
+        sa.prob[i] = pr;                                   // pnp_build_solve: the pinned host buffer, in place
     }
-    CHIP_HIP(c, hipMemcpyAsync(st->X, st->h_in, sizeof(double) * 5 * (size_t)Ntot, hipMemcpyHostToDevice, s));
+    // no H2D copy: see SolveArgs.  (CHIP_PNP_H2D=1 restores it for A/B runs.)
+    static const bool want_h2d = std::getenv("CHIP_PNP_H2D") != nullptr;
+    if (want_h2d) {
+        CHIP_HIP(c, hipMemcpyAsync(st->X, st->h_in, sizeof(double) * 5 * (size_t)Ntot, hipMemcpyHostToDevice, s));
+        for (int i = 0; i < P; i++) sa.prob[i] = ea.prob[i];
+    }
     if (ht.on) ht1 = ht_now();
     sa.H = H; sa.S = S; sa.tab = st->tab_dev;
     sa.Sg = st->Sg; sa.Tg = st->Tg; sa.sample = st->sample; sa.ok = st->ok;
+    sa.in_host = want_h2d ? nullptr : st->d_hin; sa.in_dev = st->X; sa.n_in = 5 * (int64_t)Ntot;
     const size_t lds = kSolveLds;
     static const bool want_stamps = std::getenv("CHIP_PNP_STAMPS") != nullptr;
     if (want_stamps) {
