@@ -1006,9 +1006,11 @@ __device__ __forceinline__ uint32_t lds_addr32(const void *p) { return (uint32_t
 // between a transcendental and its consumer, four between a VALU write of vcc and v_div_fmas, one between a VALU write and
 // v_readlane).
 //   in : k0 <= k1, (p, q, r) = H(k0.., k0-1) as forwarded (or from the m search: first63 = 0 masks the first step's H(k, k-1) store), LDS byte addresses of HH(k0, lane), A(arow, k0), HH(k0, k0-1), lane masks
+//   do_last (k1 == n-2 only): after step n-2 also run the sweep's LAST, two-row step k = n-1 (k comes back as n); zero = 2: that step
+//   found |p|+|q|+|r| == 0 and was not executed (k comes back as n-1)
 //   out: k = first step NOT executed (k1 + 1, or the step whose |p|+|q|+|r| is 0: zero = 1), (p, q, r) for that step
 __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &q, double &r, uint32_t rowaddr, uint32_t coladdr,
-                                             uint32_t subaddr, uint64_t rowmask, uint64_t colmask, uint64_t nmask, uint64_t first63, int &zero)
+                                             uint32_t subaddr, uint64_t rowmask, uint64_t colmask, uint64_t nmask, uint64_t first63, int do_last, int &zero)
 {
     const uint64_t m_odd = 0xAAAAAAAAAAAAAAAAull, m_l0 = 1ull, m_lt3 = 7ull, m_l63 = 1ull << 63;
     int kk = k, z = 0;
@@ -1155,6 +1157,93 @@ __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &
         "v_add_u32 v73, 8, v73\n\t"
         "s_cmp_le_u32 s56, s57\n\t"
         "s_cbranch_scc1 Lqr_step_%=\n\t"
+        // ---- the LAST step of the sweep, k = n-1: the reflector spans two rows (r = 0 arrives as the forwarded H(k+3, k) of step n-2);
+        //      same arithmetic as qr_step<NOTLAST = false>: no third row / column, nothing forwarded
+        "s_cmp_eq_u32 %[dolast], 0\n\t"
+        "s_cbranch_scc1 Lqr_done_%=\n\t"
+        "ds_read_b64 v[80:81], v72 offset:216\n\t"
+        "ds_read_b64 v[82:83], v72 offset:432\n\t"
+        "v_mov_b64 v[88:89], s[42:43]\n\t"
+        "v_add_f64 v[92:93], |s[40:41]|, |v[88:89]|\n\t"
+        "v_add_f64 v[92:93], v[92:93], |s[44:45]|\n\t"
+        "v_cmp_eq_f64 vcc, 0, v[92:93]\n\t"
+        "v_frexp_exp_i32_f64 v94, v[92:93]\n\t"
+        "v_sub_u32 v95, 0, v94\n\t"
+        "v_ldexp_f64 v[86:87], s[40:41], v95\n\t"
+        "v_ldexp_f64 v[88:89], v[88:89], v95\n\t"
+        "v_ldexp_f64 v[90:91], s[44:45], v95\n\t"
+        "s_cbranch_vccnz Lqr_zero_last_%=\n\t"
+        "v_mul_f64 v[96:97], v[86:87], v[86:87]\n\t"
+        "v_mul_f64 v[98:99], v[88:89], v[88:89]\n\t"
+        "v_add_f64 v[96:97], v[96:97], v[98:99]\n\t"
+        "v_mul_f64 v[98:99], v[90:91], v[90:91]\n\t"
+        "v_add_f64 v[100:101], v[96:97], v[98:99]\n\t"
+        "v_rsq_f64 v[102:103], v[100:101]\n\t"
+        "v_cmp_gt_f64 vcc, 0, v[86:87]\n\t"
+        "v_mul_f64 v[104:105], v[100:101], v[102:103]\n\t"
+        "v_mul_f64 v[106:107], v[102:103], 0.5\n\t"
+        "v_fma_f64 v[108:109], -v[106:107], v[104:105], 0.5\n\t"
+        "v_fma_f64 v[104:105], v[104:105], v[108:109], v[104:105]\n\t"
+        "v_fma_f64 v[106:107], v[106:107], v[108:109], v[106:107]\n\t"
+        "v_fma_f64 v[108:109], -v[104:105], v[104:105], v[100:101]\n\t"
+        "v_fma_f64 v[104:105], v[108:109], v[106:107], v[104:105]\n\t"
+        "v_fma_f64 v[108:109], -v[104:105], v[104:105], v[100:101]\n\t"
+        "v_fma_f64 v[110:111], v[108:109], v[106:107], v[104:105]\n\t"
+        "v_xor_b32 v75, 0x80000000, v111\n\t"
+        "v_cndmask_b32 v111, v111, v75, vcc\n\t"
+        "v_add_f64 v[86:87], v[86:87], v[110:111]\n\t"
+        "v_cndmask_b32 v114, v90, v88, %[modd]\n\t"
+        "v_cndmask_b32 v115, v91, v89, %[modd]\n\t"
+        "v_cndmask_b32 v114, v114, v86, %[ml0]\n\t"
+        "v_cndmask_b32 v115, v115, v87, %[ml0]\n\t"
+        "v_cndmask_b32 v116, v86, v110, %[mlt3]\n\t"
+        "v_cndmask_b32 v117, v87, v111, %[mlt3]\n\t"
+        "v_div_scale_f64 v[76:77], s[68:69], v[116:117], v[116:117], v[114:115]\n\t"
+        "v_rcp_f64 v[120:121], v[76:77]\n\t"
+        "v_add_u32 v72, 0xd8, v72\n\t"
+        "v_fma_f64 v[122:123], -v[76:77], v[120:121], 1.0\n\t"
+        "v_fma_f64 v[120:121], v[120:121], v[122:123], v[120:121]\n\t"
+        "v_fma_f64 v[122:123], -v[76:77], v[120:121], 1.0\n\t"
+        "v_fma_f64 v[120:121], v[120:121], v[122:123], v[120:121]\n\t"
+        "v_div_scale_f64 v[124:125], vcc, v[114:115], v[116:117], v[114:115]\n\t"
+        "v_mul_f64 v[126:127], v[124:125], v[120:121]\n\t"
+        "v_fma_f64 v[76:77], -v[76:77], v[126:127], v[124:125]\n\t"
+        "v_ldexp_f64 v[112:113], -v[110:111], v94\n\t"
+        "v_add_u32 v74, 0xe0, v74\n\t"
+        "v_div_fmas_f64 v[76:77], v[76:77], v[120:121], v[126:127]\n\t"
+        "v_div_fixup_f64 v[96:97], v[76:77], v[116:117], v[114:115]\n\t"
+        "s_nop 0\n\t"
+        "v_readlane_b32 s46, v96, 0\n\t"
+        "v_readlane_b32 s47, v97, 0\n\t"
+        "v_readlane_b32 s48, v96, 1\n\t"
+        "v_readlane_b32 s49, v97, 1\n\t"
+        "v_readlane_b32 s52, v96, 3\n\t"
+        "v_readlane_b32 s53, v97, 3\n\t"
+        "s_mov_b64 exec, s[70:71]\n\t"
+        "ds_write_b64 v74, v[112:113]\n\t"
+        "s_mov_b64 exec, s[62:63]\n\t"
+        "s_waitcnt lgkmcnt(1)\n\t"
+        "v_mul_f64 v[98:99], s[52:53], v[82:83]\n\t"
+        "v_add_f64 v[96:97], v[80:81], v[98:99]\n\t"                       // pp = h0 + q * h1
+        "v_mul_f64 v[98:99], v[96:97], s[46:47]\n\t"
+        "v_add_f64 v[100:101], v[80:81], -v[98:99]\n\t"
+        "v_mul_f64 v[98:99], v[96:97], s[48:49]\n\t"
+        "v_add_f64 v[102:103], v[82:83], -v[98:99]\n\t"
+        "ds_write2_b64 v72, v[100:101], v[102:103] offset1:27\n\t"
+        "s_mov_b64 exec, s[64:65]\n\t"
+        "ds_read2_b64 v[106:109], v73 offset1:1\n\t"
+        "s_add_u32 s56, s56, 1\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_mul_f64 v[114:115], s[46:47], v[106:107]\n\t"
+        "v_mul_f64 v[116:117], s[48:49], v[108:109]\n\t"
+        "v_add_f64 v[112:113], v[114:115], v[116:117]\n\t"                 // pp = x * a0 + y * a1
+        "v_add_f64 v[118:119], v[106:107], -v[112:113]\n\t"
+        "v_mul_f64 v[116:117], v[112:113], s[52:53]\n\t"
+        "v_add_f64 v[120:121], v[108:109], -v[116:117]\n\t"
+        "ds_write2_b64 v73, v[118:119], v[120:121] offset1:1\n\t"
+        "s_branch Lqr_done_%=\n"
+        "Lqr_zero_last_%=:\n\t"
+        "s_mov_b32 %[z], 2\n\t"
         "s_branch Lqr_done_%=\n"
         "Lqr_zero_%=:\n\t"
         "s_mov_b32 %[z], 1\n"
@@ -1168,7 +1257,7 @@ __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &
         : [z] "=&s"(z), [kout] "=&s"(kk), [pout] "=&s"(po), [qout] "=&s"(qo), [rout] "=&s"(ro)
         : [p] "s"(p), [q] "s"(q), [r] "s"(r), [k] "s"(k), [k1] "s"(k1), [subaddr] "s"(subaddr), [rowmask] "s"(rowmask),
           [colmask] "s"(colmask), [nmask] "s"(nmask), [rowaddr] "v"(rowaddr), [coladdr] "v"(coladdr), [modd] "s"(m_odd), [ml0] "s"(m_l0),
-          [mlt3] "s"(m_lt3), [ml63] "s"(m_l63), [first63] "s"(first63)
+          [mlt3] "s"(m_lt3), [ml63] "s"(m_l63), [first63] "s"(first63), [dolast] "s"(do_last)
         : "memory", "vcc", "scc", "s70", "s71", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
           "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "v72", "v73", "v74", "v75", "v76",
           "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95",
@@ -1490,7 +1579,11 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             t_prev = t_;                                                    \
         }                                                                   \
     } while (0)
-    __shared__ double Hs[EN * EN], Vs[EN * EN];
+    // H sits 28 doubles (one row + one element) into its allocation: qr_sweep_head_asm addresses every operand of lane i relative to
+    // &H(i-1, i-1), which for lane 0 lies 224 bytes in front of H -- inside this pad, not below LDS address 0 (no address wrap-around;
+    // the pad's content is never used: lane 0's H(-1,-1) / H(0,-1) only feed a comparison whose result is overridden)
+    __shared__ double HsPad[28 + EN * EN], Vs[EN * EN];
+    double *const Hs = HsPad + 28;
     __shared__ double ortm[EN], wr[EN], wi[EN], Tf[27], sxs[kSampleMax * 3], model[16];
     __shared__ __attribute__((aligned(16))) double us[EN + 5];   // the current Householder vector (orthes / ortran)
     const int lane = threadIdx.x;
@@ -1600,15 +1693,17 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
         // l = n, n-1, ... sequentially; every index is independent, so lane l tests its own and a ballot picks the
         // same l (exact reformulation: same arithmetic per index, same selection).
         int l = 0, m = 0;
-        bool head = false;   // the sweep's head (l search, shifts, m search, zeroing) was done by qr_sweep_head_asm
+        bool head = false;       // the sweep's head (l search, shifts, m search, zeroing) was done by qr_sweep_head_asm
+        bool have_l = false;     // ... or at least its deflation test (l is valid: one or two roots to split off)
         if constexpr (!STAMP) {
             if (n >= 2 && iter != 10 && iter != 30 && iter < 60) {   // (exceptional shifts and the iteration limit stay compiled)
                 int st = 1;
                 qr_sweep_head_asm(n, lds_addr32(Hs), lane, norm, st, l, m, p, q, r);
                 head = st == 0;
+                have_l = true;
             }
         }
-        if (!head) {
+        if (!have_l) {
             bool small = false;
             if (lane > low && lane <= n) {
                 double ss = fabs(HH(lane - 1, lane - 1)) + fabs(HH(lane, lane));
@@ -1865,17 +1960,17 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                     const uint64_t rowmask = ((1ull << EN) - 1) & (~0ull << k);                          // lanes k..26
                     const uint64_t colmask = (((1ull << (k + 4)) - 1) | vmask) & nmask;                   // H rows 0..min(n, k+3) | V rows
                     int zero = 0;
-                    qr_steps_asm(k, n - 2, ap, aq, ar, rowaddr, coladdr, subaddr, rowmask, colmask, nmask, first ? 0ull : (1ull << 63), zero);
+                    qr_steps_asm(k, n - 2, ap, aq, ar, rowaddr, coladdr, subaddr, rowmask, colmask, nmask, first ? 0ull : (1ull << 63), 1, zero);
                     if (first && k > m && l != m && lane == 63) HH(m, m - 1) = -hm;
                     if (k > m) { fp = ap; fq = aq; fr = ar; fwd = true; }
-                    if (zero) { qr_step(k, std::true_type()); k++; }   // that step sees the zero itself and returns with fwd = false
+                    if (zero == 1) { qr_step(k, std::true_type()); k++; }   // that step sees the zero itself and returns with fwd = false
                 }
             } else {
                 qr_step(m, std::true_type());
                 k = m + 1;
             }
             for (; k <= n - 2; k++) qr_step(k, std::true_type());
-            qr_step(n - 1, std::false_type());
+            if (k == n - 1) qr_step(n - 1, std::false_type());   // (k == n: the asm loop has run the last step as well)
         }
         PNP_STAMP(0);
     }

@@ -1,10 +1,21 @@
-mkdir -p gpurun_out/prof_pnp; rm -rf gpurun_out/prof_pnp/*
+# SQ counters + kernel durations of the PnP kernel pair, 1000 hypotheses x 5 calls (rocprofv3; counters in passes of their own with --kernel-trace only)
+O=gpurun_out/r04/pnp_pmc
+mkdir -p $O; rm -rf $O/*
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 -L 2>/dev/null | grep -E "SQ_INSTS_VALU|SQ_ACTIVE_INST_VALU|SQ_INSTS_LDS|SQ_WAIT_INST_LDS|SQ_INST_CYCLES_VMEM|SQ_WAVE_CYCLES|SQ_BUSY_CYCLES|SQ_INSTS_SALU|SQ_ACTIVE_INST_LDS|SQ_WAIT_ANY|SQ_WAIT_INST_ANY|SQ_THREAD_CYCLES_VALU|SQ_LDS_BANK_CONFLICT" | cut -c1-120 | sort -u | head -40 > gpurun_out/prof_pnp/counters.txt
-cat gpurun_out/prof_pnp/counters.txt
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_pnp/trace -o r01 -- python scripts/run_pnp_once.py > gpurun_out/prof_pnp/trace.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d gpurun_out/prof_pnp/pmc_valu -o r01 -- python scripts/run_pnp_once.py > gpurun_out/prof_pnp/pmc_valu.log 2>&1
-tail -1 gpurun_out/prof_pnp/pmc_valu.log
-timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -d gpurun_out/prof_pnp/pmc_lds -o r01 -- python scripts/run_pnp_once.py > gpurun_out/prof_pnp/pmc_lds.log 2>&1
-tail -1 gpurun_out/prof_pnp/pmc_lds.log
-ls gpurun_out/prof_pnp/*/
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o p -- python scripts/run_pnp_once.py > $O/trace.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc_valu -o p -- python scripts/run_pnp_once.py > $O/pmc_valu.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -d $O/pmc_lds -o p -- python scripts/run_pnp_once.py > $O/pmc_lds.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_ANY --kernel-trace -d $O/pmc_salu -o p -- python scripts/run_pnp_once.py > $O/pmc_salu.log 2>&1
+python - <<'PY' | tee gpurun_out/r04/pnp_pmc.txt
+import sqlite3, glob
+O = "gpurun_out/r04/pnp_pmc"
+for db in glob.glob(O + "/trace/**/*_results.db", recursive=True):
+    con = sqlite3.connect(db)
+    for n, c, a, mn, mx in con.execute("select name,count(*),avg(duration)/1e3,min(duration)/1e3,max(duration)/1e3 from kernels where name like '%pnp_%' group by name"):
+        print(f"{n[:44]:44s} calls {c}  avg {a:.1f} us  min {mn:.1f}  max {mx:.1f}")
+for pas in ("pmc_valu", "pmc_lds", "pmc_salu"):
+    for db in glob.glob(O + f"/{pas}/**/*_results.db", recursive=True):
+        con = sqlite3.connect(db)
+        for n, cn, c, a in con.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection where kernel_name like '%pnp_%' group by kernel_name, counter_name"):
+            print(f"{n[:44]:44s} {cn:24s} {c:3d} dispatches  avg {a:.4e}")
+PY
