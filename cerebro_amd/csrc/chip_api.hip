@@ -269,8 +269,9 @@ int ctx_create(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device,
     const uint32_t store = flags & kCreateStoreMask;
     if (store == kCreateStoreMask) return CHIP_ERR_INVALID_ARG;
     if (D % 4 != 0 || (size_t)D * 4 * CHIP_MAX_NQ > 160 * 1024) return CHIP_ERR_UNSUPPORTED;
-    // double rows: the three queries of a tick (3 x D x 8 B) must fit the 160 KiB of LDS
-    if (store == CHIP_CREATE_STORE_F64 && (size_t)D * 8 * 3 > 160 * 1024) return CHIP_ERR_UNSUPPORTED;
+    // double rows: two query descriptors (2 x D x 8 B) must fit the 160 KiB of LDS; further ones are read in place (db_scan_topk_wide).
+    // D <= 10 240 for either storage type -- the reference's default 8192-D model included (Cerebro.cpp:1021)
+    if (store == CHIP_CREATE_STORE_F64 && (size_t)D * 8 * 2 > 160 * 1024) return CHIP_ERR_UNSUPPORTED;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return CHIP_ERR_NO_DEVICE;
     if (device < 0 || device >= ndev) return CHIP_ERR_NO_DEVICE;
@@ -615,7 +616,7 @@ int append_store_db(Ctx *c, const void *desc, int src_elem, int64_t first, int64
 
 // Genuinely float64 descriptors (e.g. ReljaNetVLAD's numpy WPCA output, whole_image_desc_compute_server.py:148-149): an
 // undecided, still EMPTY DB becomes a double-row DB -- as the reference's MatrixXd M (Cerebro.cpp:946).
-bool append_can_switch_to_double(const Ctx *c, int64_t first) { return c->store_auto && first == 0 && (size_t)c->D * 8 * 3 <= 160 * 1024; }
+bool append_can_switch_to_double(const Ctx *c, int64_t first) { return c->store_auto && first == 0 && (size_t)c->D * 8 * 2 <= 160 * 1024; }
 
 int append_switch_to_double(Ctx *c, int64_t n)
 {

@@ -306,6 +306,70 @@ __global__ __launch_bounds__(1024) void db_scan_topk(ScanArgs a)
     block_merge_store<NQ>(a, smem, my_s, my_i, K, lane, wave, wpb);
 }
 
+// ------------------------------------------------------------------------------------------------ K1, wide double rows
+// Double rows whose NQ query descriptors do not fit the 160 KiB of LDS (the reference's default D = 8192, src/Cerebro.cpp:1021, as a
+// MatrixXd of genuine float64 values: 3 x 8192 x 8 B = 192 KiB).  The first NQ - NG queries are staged as usual; the last NG are read
+// from global memory next to the row -- every wave of the launch reads the same D x 8 bytes, so they come out of the L2 -- with the
+// same per-lane element order as rows_dot (lane L: elements j*128 + 2L + c, j ascending, fma; then the xor butterfly), hence the
+// same bits as the staged form and as the oracle (orc_dot_tree_f64).  A rare configuration: plain compiler-scheduled loads.
+template <int NQ, int NG, bool FULL>
+__global__ __launch_bounds__(1024) void db_scan_topk_wide(ScanArgs a)
+{
+    static_assert(NG >= 1 && NG < NQ, "at least one query staged, at least one read in place");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *qs = reinterpret_cast<double *>(smem);  // [NQ - NG][D]
+    constexpr int NL = NQ - NG, U = 4, CH = 128;
+    const int D = a.D, K = a.K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wpb = blockDim.x >> 6;
+    stage_queries<double, NL>(a, qs, tid, blockDim.x);
+    __syncthreads();
+    const double *qg[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) qg[g] = static_cast<const double *>(a.q[NL + g]);
+
+    double my_s[NQ], thr_s[NQ];
+    int64_t my_i[NQ], thr_i[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) { my_s[q] = -INFINITY; my_i[q] = -1; thr_s[q] = -INFINITY; thr_i[q] = -1; }
+    const int e0 = lane * 2;
+    const int64_t tw = (int64_t)gridDim.x * wpb;
+    for (int64_t r = (int64_t)blockIdx.x * wpb + wave; r < a.n_rows; r += tw) {
+        const double *row = row_base<double>(a, r);
+        double acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) acc[q] = 0.0;
+        for (int base = 0; base < D; base += CH * U) {
+            f64x2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = base + u * CH + e0;
+                if (FULL || e < D) v[u] = __builtin_nontemporal_load(as_global(reinterpret_cast<const f64x2 *>(row + e)));
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int e = base + u * CH + e0;
+                if (FULL || e < D) {
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const f64x2 w = q < NL ? *reinterpret_cast<const f64x2 *>(qs + q * D + e)
+                                               : *as_global(reinterpret_cast<const f64x2 *>(qg[q < NL ? 0 : q - NL] + e));
+                        acc[q] = __builtin_fma(w[0], v[u][0], acc[q]);
+                        acc[q] = __builtin_fma(w[1], v[u][1], acc[q]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) acc[q] = butterfly_sum(acc[q]);
+        const int64_t gi = r * a.idx_mul + a.idx_add;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) wave_topk_offer(acc[q], gi, K, lane, my_s[q], my_i[q], thr_s[q], thr_i[q]);
+    }
+    block_merge_store<NQ>(a, smem, my_s, my_i, K, lane, wave, wpb);
+}
+
 // ------------------------------------------------------------------------------------------------ K1, row-batched form
 // The same scan with R rows per wave in flight at once and the loads issued as ONE continuous stream (round 3): a wave walks
 // the (pass, 4 KiB batch, load slot u) sequence of its rows and re-issues slot u for the NEXT batch as soon as the fmas that
@@ -777,10 +841,18 @@ static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, siz
 // 2 workgroups x 512 threads per CU while two copies fit in the 160 KiB (D = 4096 fp32: 48 KiB each), else 1 x 1024 threads
 // (D = 8192 fp32, the reference's default model, or D = 4096 fp64: 96 KiB) -- the same 16 waves per CU either way
 // (measured: 6.7 TB/s vs 5.5 with 512 x 1).  CHIP_SCAN_BLOCK / CHIP_SCAN_BPC override (tuning only).
+// Double rows: how many of the nq queries are NOT staged in LDS but read in place (db_scan_topk_wide); 0 = all of them fit.
+int scan_wide_ng(const Ctx *c, int nq)
+{
+    if (c->elem != 8 || (size_t)nq * c->D * 8 <= 160 * 1024) return 0;
+    const int fit = (int)((160 * 1024) / ((size_t)c->D * 8));
+    return nq - (fit < 1 ? 1 : fit);
+}
+
 static size_t scan_lds_bytes(const Ctx *c, int nq, int K, int block, bool q64, bool rows_form = false)
 {
     if (rows_form) return (size_t)nq * c->D * c->elem + (size_t)(block / 64) * nq * CHIP_MAX_TOPK * sizeof(chip_topk_entry);   // queries + running lists
-    const size_t lds_q = (size_t)nq * c->D * (q64 ? 8 : c->elem);
+    const size_t lds_q = (size_t)(q64 ? nq : nq - scan_wide_ng(c, nq)) * c->D * (q64 ? 8 : c->elem);   // the staged queries
     const size_t lds_m = (size_t)(block / 64) * nq * K * sizeof(chip_topk_entry);
     return lds_q > lds_m ? lds_q : lds_m;
 }
@@ -865,12 +937,32 @@ static int launch_scan_T(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int g
     return CHIP_ERR_UNSUPPORTED;
 }
 
+template <int NQ, int NG>
+static int launch_scan_wide(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds, int block)
+{
+    if (a.D % 512 == 0) {
+        CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_scan_topk_wide<NQ, NG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((db_scan_topk_wide<NQ, NG, true>), dim3(grid), dim3(block), lds, s, a);
+    } else {
+        CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_scan_topk_wide<NQ, NG, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((db_scan_topk_wide<NQ, NG, false>), dim3(grid), dim3(block), lds, s, a);
+    }
+    CHIP_HIP(c, hipGetLastError());
+    return CHIP_OK;
+}
+
 int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid)
 {
     int block, bpc;
     scan_shape(c, nq, a.q64 != 0, &block, &bpc);
     const size_t lds = scan_lds_bytes(c, nq, a.K, block, a.q64 != 0, a.rows_form > 0);
     if (lds > 160 * 1024 || grid > 512) return CHIP_ERR_UNSUPPORTED;  // K2 holds one partial list per thread
+    if (const int ng = scan_wide_ng(c, nq); ng > 0 && !a.q64 && a.rows_form == 0) {   // double rows wider than the LDS holds nq queries of
+        if (nq == 3 && ng == 1) return launch_scan_wide<3, 1>(c, s, a, grid, lds, block);
+        if (nq == 4 && ng == 1) return launch_scan_wide<4, 1>(c, s, a, grid, lds, block);
+        if (nq == 4 && ng == 2) return launch_scan_wide<4, 2>(c, s, a, grid, lds, block);
+        return CHIP_ERR_UNSUPPORTED;   // chip_create bounds D so that two double queries always fit
+    }
     return c->elem == 8 ? launch_scan_T<double>(c, s, a, nq, grid, lds, block) : launch_scan_T<float>(c, s, a, nq, grid, lds, block);
 }
 

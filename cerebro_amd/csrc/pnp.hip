@@ -2158,6 +2158,12 @@ int pnp_create(Ctx *c)
     CHIP_HIP(c, hipMalloc(&st->tab_dev, sizeof(PnpTables)));
     CHIP_HIP(c, hipMemcpy(st->tab_dev, &t, sizeof t, hipMemcpyHostToDevice));
     CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(pnp_build_solve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 102 * 1024));
+    if (const char *e = std::getenv("CHIP_PNP_OCCUPANCY"); e && e[0] == '1') {   // tuning only: resident workgroups per CU of the kernel pair
+        int nb = -1, ne = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(pnp_build_solve<false>), kSolveThreads, kSolveLds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&ne, reinterpret_cast<const void *>(pnp_eig_score<false>), 64, 0);
+        std::fprintf(stderr, "pnp occupancy: pnp_build_solve %d workgroups per CU, pnp_eig_score %d waves per CU\n", nb, ne);
+    }
     CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(pnp_build_solve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 102 * 1024));
     return CHIP_OK;
 }

@@ -93,7 +93,9 @@ void chip_destroy(chip_ctx *ctx);
  *                           succeeds unrounded.  Later non-representable values in a float DB fail (CHIP_ERR_NOT_F32).
  *   CHIP_CREATE_STORE_F32 : float rows, never switches.        CHIP_CREATE_STORE_F64 : double rows from the start.
  * Double rows: scores are fp64 FMA chains (one rounding per term) in the fixed order of DESIGN.md 3 with 2 elements per lane
- * per 128-element chunk; needs 3*D*8 B <= 160 KiB (D <= 6824); the MFMA many-query mode is float-only.                  */
+ * per 128-element chunk; D <= 10 240 as for float rows (two double queries fit the 160 KiB of LDS; where the three of a
+ * tick do not -- D > 6824, e.g. the reference's default 8192 -- the rest is read in place, same bits); the MFMA many-query
+ * mode is float-only.                                                                                                   */
 #define CHIP_CREATE_STORE_F32 1u
 #define CHIP_CREATE_STORE_F64 2u
 int  chip_create_ex(chip_ctx **out, int32_t D, int64_t capacity_hint, int32_t device, int32_t shard_rank, int32_t shard_count,

@@ -39,7 +39,7 @@ def relja_like(seed, N, D, plants=()):
     return db
 
 
-@pytest.mark.parametrize("D,N", [(4, 300), (250 * 4, 700), (1024, 900), (4096, 1200), (6824, 400)])
+@pytest.mark.parametrize("D,N", [(4, 300), (250 * 4, 700), (1024, 900), (4096, 1200), (6824, 400), (8192, 400), (8200, 200), (10240, 300)])
 def test_f64_topk_parity_shapes(D, N):
     plants, loops, ties = scenarios.loop_plants(N, 3, seed=D)
     db = relja_like(D, N, D, plants)
@@ -47,7 +47,9 @@ def test_f64_topk_parity_shapes(D, N):
         assert chip.info()["storage_bytes"] == 8
         chip.append_f64(db)
         rows = [N - 1, N - 2, N - 3, loops[0][1]]
-        for nq in ((1, 2, 3, 4) if D * 8 * 4 <= 160 * 1024 else (1, 2, 3)):
+        # 3 x 8192 x 8 B = 192 KiB of queries do not fit the 160 KiB of LDS: the queries beyond what fits are read in place
+        # (db_scan_topk_wide) -- D = 8192 is the reference's default descriptor size (src/Cerebro.cpp:1021)
+        for nq in (1, 2, 3, 4):
             for K in (1, 8, 16):
                 for k in (0, 1, 7, N - 50, N):
                     want = oracle_lib.scan_topk_f64(db, k, db[rows[:nq]], K)
@@ -114,10 +116,33 @@ def test_f64_tick_sequence_and_auto_switch():
         with pytest.raises(capi.ChipError) as e:
             chip.append_f64(db[:1])
         assert e.value.status == capi.CHIP_ERR_NOT_F32 and chip.size() == 0 and chip.info()["storage_bytes"] == 4
-    # D too large for three double queries in LDS: explicit request refused, automatic switch keeps the float contract
+    # D too large for two double queries in LDS (D > 10 240, the float limit as well): explicit request refused
     with pytest.raises(capi.ChipError) as e:
-        capi.Chip(8192, storage="f64")
+        capi.Chip(10244, storage="f64")
     assert e.value.status == capi.CHIP_ERR_UNSUPPORTED
+
+
+def test_f64_8192d_tick_sequence():
+    """The reference's default descriptor size (8192, src/Cerebro.cpp:1021) as genuine float64 rows: the automatic switch to double rows
+    works there too and every tick is bit-exact vs the f64 oracle (two queries staged in LDS, the third read in place)."""
+    D, N = 8192, 900
+    plants, loops, ties = scenarios.loop_plants(N, 4, seed=8192)
+    db = relja_like(11, N, D, plants)
+    orc = oracle_lib.LoopOracle64(db)
+    with capi.Chip(D) as chip:
+        chip.append_f64(db[:100])
+        assert chip.info()["storage_bytes"] == 8 and chip.info()["lossy_rows"] == 0
+        chip.append_f64(db[100:])
+        ls = set([1, 30, 55, 57, 58, 61] + list(range(64, N + 1, 3)))
+        for l, _, _ in loops:
+            ls -= {l - 1, l - 2}
+            ls.add(l)
+        n_found = 0
+        for l in sorted(ls):
+            o = orc.tick(l)
+            same_tick(chip.loop_tick(l), o)
+            n_found += o["found"]
+        assert n_found >= len(loops)
 
 
 def test_f64_4096d_100k_full_oracle_parity():
