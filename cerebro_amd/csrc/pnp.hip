@@ -439,34 +439,50 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
 #define LS(c, c2) er[16 + ((c) * ((c) - 1)) / 2 + (c2)]
 #define B0(c) er[22 + (c)]
 #define B1(c) er[26 + (c)]
-    int lp0 = lane, lp1 = lane + 64;   // logical position of physical rows lane, lane + 64
+    // Which physical rows are still candidates is wave-uniform state: two lane masks in SGPRs (rows lane / lane + 64), used directly as
+    // select conditions (inverse ballot) and updated by scalar bit instructions.  The reference's row swaps are not tracked per column any
+    // more: where a row WOULD sit logically only matters when two candidates tie exactly (smallest logical index wins), which generic
+    // data never does (0 of 93 000 columns of config 3's 1000 hypotheses) -- that path replays the swaps from the pivot history instead.
+    // The factor wave is bound by the issue rate of a lone wave (~9 cycles per instruction, dependent or not: ~150 instructions and
+    // ~1350 cycles per column before this), so what counts is the number of instructions on the per-column path.
     const bool has1 = lane + 64 < kNR;
+    // (the branch on the wave's role is divergent as far as the compiler knows, so what the factor wave carries around the LU loop lives
+    //  in VGPRs: the masks are moved to SGPRs once per panel -- declaring the role uniform instead costs the matrix waves 129 spills)
+    unsigned long long alive0_v = ~0ull, alive1_v = (1ull << (kNR - 64)) - 1ull;
+    int hist0 = 0, hist1 = 0;   // lane j: physical pivot row of elimination step j / j + 64 (read by the tie path only)
+    auto uniform_u64 = [](unsigned long long v) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    };
 
     // tuning only (CHIP_PNP_STAMPS): sub-phase shader-clock totals of the factor wave
     // (compiled in with -DCHIP_PNP_FSTAMPS only: eight 64-bit accumulators push the kernel past 128 VGPRs = one workgroup per CU,
     // and every stamp costs ~60 cycles on the chain it measures)
 #ifdef CHIP_PNP_FSTAMPS
-    unsigned long long f_t = 0, f_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long f_t = __builtin_readcyclecounter(), f_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool f_stamp = STAMP && wave == 6;
 #define F_STAMP(i) do { if (f_stamp) { const unsigned long long t_ = __builtin_readcyclecounter(); f_acc[i] += t_ - f_t; f_t = t_; } } while (0)
 #else
 #define F_STAMP(i) do { } while (0)
 #endif
-    // factorise the panel held in a0/a1 (columns k .. k+bw-1), publish into parity set `par`
-    auto factor_panel = [&](int k, int bw, int par) {
+    // factorise the panel held in a0/a1 (columns k .. k+BW-1), publish into parity set `par`.  BW is a compile-time constant (4, or 1
+    // for the last panel: 93 = 23 x 4 + 1): no per-column guards.  A zero / non-finite pivot column marks the block singular and the
+    // panel is finished with whatever row was picked -- garbage, but in-range garbage: the workgroup leaves at the top of the next
+    // panel (flag[0]) exactly as before, and nothing of a rejected block is looked at.
+    auto factor_panel = [&](auto bw_tag, int k, int par) {
+        constexpr int BW = decltype(bw_tag)::value;
         F_STAMP(0);   // whatever preceded (the update of the panel by the previous one)
-        int pr_c[kPanel];
+        int pr_c[kPanel] = {0, 0, 0, 0};
         bool sing = false;
+        unsigned long long alive0 = uniform_u64(alive0_v), alive1 = uniform_u64(alive1_v);
 #pragma unroll
         for (int c = 0; c < kPanel; c++) { L0(c) = 0.0; L1(c) = 0.0; }
         // one pivot column.  The column index is a compile-time constant (generic lambda over integral_constant), so that every
         // A0(c) / LS(c, c2) / urow[c2] below is a fixed register whatever the unroller decides.
         auto factor_column = [&](auto c_tag) {
             constexpr int c = decltype(c_tag)::value;
-            pr_c[c] = 0;
-            if (c < bw && !sing) {
-                const int kk = k + c;
-                const bool al0 = lp0 >= kk, al1 = has1 && lp1 >= kk;   // pivots sit at logical positions < kk
+            if constexpr (c < BW) {
+                const bool al0 = __builtin_amdgcn_inverse_ballot_w64(alive0), al1 = __builtin_amdgcn_inverse_ballot_w64(alive1);
                 // Finite non-negative doubles order like their bit patterns, so the HIGH words (sign cleared) decide unless two
                 // candidates agree in exponent and 20 mantissa bits.  Usual case: one lane attains the max high word and its two rows
                 // differ there -> that row is the pivot, found with 32-bit integer work and ONE DPP reduction.  Everything else -- ties on
@@ -474,96 +490,125 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                 // (64-bit compares, second reduction over the low words, smallest-logical-index rule).  Same pivot either way.
                 const unsigned h0 = al0 ? ((unsigned)((unsigned long long)__double_as_longlong(A0(c)) >> 32) & 0x7fffffffu) : 0u;
                 const unsigned h1 = al1 ? ((unsigned)((unsigned long long)__double_as_longlong(A1(c)) >> 32) & 0x7fffffffu) : 0u;
-                const unsigned vhi_i = h0 > h1 ? h0 : h1;
+                const bool up = h1 > h0;                               // per lane: its second row is the larger one
+                const unsigned vhi_i = up ? h1 : h0;
                 const unsigned mhi_i = wave_umax(vhi_i);
                 const unsigned long long cand = __builtin_amdgcn_ballot_w64(vhi_i == mhi_i);
-                const unsigned long long upm = __builtin_amdgcn_ballot_w64(h1 > h0), eqm = __builtin_amdgcn_ballot_w64(h1 == h0);
+                const unsigned long long eqm = __builtin_amdgcn_ballot_w64(h1 == h0);
                 F_STAMP(1);   // candidates + wave max
-                int olane, plog;
-                bool ohalf;
-                double best;
+                // olane / ohalf / pivot_ok are wave-uniform and are KEPT in SGPRs: the tie path computes them with vector instructions,
+                // and merged with the usual path's scalar values they all lived in VGPRs (every later use went through
+                // v_readfirstlane / 64-bit vector mask arithmetic)
+                int olane, ohalf;
+                bool pivot_ok;
+                bool sel;                                              // per lane: its second row is the one to read -- at lane olane: ohalf
                 const int cl = __builtin_ctzll(cand);                  // cand != 0: the lane holding the max is in it
-                if (__popcll(cand) == 1 && mhi_i != 0u && mhi_i < 0x7ff00000u && !((eqm >> cl) & 1ull)) {
+                if (__popcll(cand) == 1 && mhi_i - 1u < 0x7fefffffu && (eqm & cand) == 0ull) {
                     olane = cl;
-                    ohalf = (upm >> cl) & 1ull;
-                    plog = __builtin_amdgcn_readlane(ohalf ? lp1 : lp0, olane);
-                    best = 1.0;                                        // only its sign is looked at below
+                    ohalf = __builtin_amdgcn_readlane(up ? 1 : 0, cl);
+                    pivot_ok = true;
+                    sel = up;                                          // known before the reduction: the row selects below do not wait for ohalf
                 } else {
                     const double v0 = al0 ? fabs(A0(c)) : -1.0, v1 = al1 ? fabs(A1(c)) : -1.0;
                     double vm = v0 > 0.0 ? v0 : 0.0;                   // NaN never wins, as in the reference scan
                     if (v1 > vm) vm = v1;
-                    best = wave_max_nonneg_2x32(vm);
+                    const double best = wave_max_nonneg_2x32(vm);
                     const bool w0 = al0 && v0 == best, w1 = al1 && v1 == best;
                     const unsigned long long t0 = __builtin_amdgcn_ballot_w64(w0), t1 = __builtin_amdgcn_ballot_w64(w1);
+                    int ol, oh;
+                    bool found = true;
                     if (__popcll(t0) + __popcll(t1) == 1) {           // one row attains the max
-                        ohalf = t0 == 0ull;
-                        olane = __builtin_ctzll(ohalf ? t1 : t0);
-                        plog = __builtin_amdgcn_readlane(ohalf ? lp1 : lp0, olane);
-                    } else {                                           // exact ties: smallest logical index among them
-                        plog = w0 ? lp0 : 0x7fffffff;
-                        if (w1 && lp1 < plog) plog = lp1;
+                        oh = t0 == 0ull;
+                        ol = __builtin_ctzll(oh ? t1 : t0);
+                    } else {
+                        // exact ties: the reference's scan keeps the FIRST row of the maximum, i.e. the smallest LOGICAL index -- where
+                        // its row swaps have put the rows by now: step j exchanges the row at logical position j with its pivot row
+                        int lp0 = lane, lp1 = lane + 64;
+                        auto displace = [&](int j, int prow) {         // both wave-uniform
+                            const int a0 = __builtin_amdgcn_readlane(lp0, prow & 63), a1 = __builtin_amdgcn_readlane(lp1, prow & 63);
+                            const int was = prow < 64 ? a0 : a1;
+                            lp0 = lane == prow ? j : (lp0 == j ? was : lp0);
+                            lp1 = lane + 64 == prow ? j : (lp1 == j ? was : lp1);
+                        };
+                        for (int j = 0; j < k; j++) {
+                            const int h = __builtin_amdgcn_readlane(j < 64 ? hist0 : hist1, j & 63);
+                            displace(j, h);
+                        }
 #pragma unroll
-                        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(plog, m, 64); plog = o < plog ? o : plog; }
-                        const unsigned long long o0 = __builtin_amdgcn_ballot_w64(al0 && lp0 == plog), o1 = __builtin_amdgcn_ballot_w64(al1 && lp1 == plog);
-                        ohalf = o0 == 0ull;
-                        olane = __builtin_ctzll(ohalf ? (o1 ? o1 : 1ull) : o0);
+                        for (int c2 = 0; c2 < c; c2++) displace(k + c2, pr_c[c2]);
+                        int pl = w0 ? lp0 : 0x7fffffff;
+                        if (w1 && lp1 < pl) pl = lp1;
+#pragma unroll
+                        for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(pl, m, 64); pl = o < pl ? o : pl; }
+                        found = pl != 0x7fffffff;
+                        const unsigned long long o0 = __builtin_amdgcn_ballot_w64(al0 && lp0 == pl), o1 = __builtin_amdgcn_ballot_w64(al1 && lp1 == pl);
+                        oh = o0 == 0ull;
+                        ol = __builtin_ctzll(oh ? (o1 ? o1 : 1ull) : o0);
                     }
+                    olane = __builtin_amdgcn_readfirstlane(ol);
+                    ohalf = __builtin_amdgcn_readfirstlane(oh);
+                    pivot_ok = __builtin_amdgcn_readfirstlane((best > 0.0 && found) ? 1 : 0) != 0;
+                    sel = ohalf != 0;
                 }
                 F_STAMP(2);   // who attains it: compares, ballots, logical position
-                if (!(best > 0.0) || plog == 0x7fffffff) { sing = true; }
-                else {
-                    pr_c[c] = olane + (ohalf ? 64 : 0);
-                    // the owners publish that row at once.  A relaxed workgroup-scope atomic, NOT a volatile store: the volatile form
-                    // compiled to flat_store_dword + s_waitcnt vmcnt(0) (address-space inference skips volatile accesses), a
-                    // several-hundred-cycle stall on the critical chain of every column; this is one ds_write_b32, no wait
-                    if (lane == 0) __hip_atomic_store(&prow_s[par * kPanel + c], pr_c[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    double urow[kPanel];
+                if (!pivot_ok) sing = true;
+                pr_c[c] = olane + (ohalf ? 64 : 0);
+                // the owners publish that row at once.  A relaxed workgroup-scope atomic, NOT a volatile store: the volatile form
+                // compiled to flat_store_dword + s_waitcnt vmcnt(0) (address-space inference skips volatile accesses), a
+                // several-hundred-cycle stall on the critical chain of every column; this is one ds_write_b32, no wait
+                if (lane == 0) __hip_atomic_store(&prow_s[par * kPanel + c], pr_c[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                double urow[kPanel];
 #pragma unroll
-                    for (int c2 = 0; c2 < kPanel; c2++) {
-                        urow[c2] = lane_value_f64(ohalf ? A1(c2) : A0(c2), olane);
-                        if (c2 < c) LS(c, c2) = lane_value_f64(ohalf ? L1(c2) : L0(c2), olane);
-                    }
-                    F_STAMP(3);   // pivot row entries / earlier multipliers by readlane
-                    const double piv = urow[c];
-                    const bool is0 = !ohalf && lane == olane, is1 = ohalf && lane == olane;
-                    const double m0 = (al0 && !is0) ? A0(c) / piv : 0.0;
-                    const double m1 = (al1 && !is1) ? A1(c) / piv : 0.0;
-                    L0(c) = m0; L1(c) = m1;
-                    F_STAMP(4);   // the two IEEE divisions
-#pragma unroll
-                    for (int c2 = 0; c2 < kPanel; c2++)
-                        if (c2 > c) {
-                            // the reference skips l == 0; e - 0 * u == e for the finite u of a block that is not rejected anyway
-                            // (same argument as in P4), so no compare / select on the chain to the next pivot search
-                            A0(c2) = A0(c2) - m0 * urow[c2];
-                            A1(c2) = A1(c2) - m1 * urow[c2];
-                        }
-                    // the reference swaps logical rows kk and plog
-                    lp0 = is0 ? kk : (lp0 == kk ? plog : lp0);
-                    lp1 = is1 ? kk : (lp1 == kk ? plog : lp1);
-                    F_STAMP(5);   // panel update + logical positions
+                for (int c2 = 0; c2 < kPanel; c2++) {
+                    urow[c2] = lane_value_f64(sel ? A1(c2) : A0(c2), olane);
+                    if (c2 < c) LS(c, c2) = lane_value_f64(sel ? L1(c2) : L0(c2), olane);
                 }
+                F_STAMP(3);   // pivot row entries / earlier multipliers by readlane
+                const double piv = urow[c];
+                // the pivot row leaves the candidates: what is left are exactly the rows that get a multiplier
+                if (ohalf) alive1 &= ~(1ull << olane); else alive0 &= ~(1ull << olane);
+                const bool n0 = __builtin_amdgcn_inverse_ballot_w64(alive0), n1 = __builtin_amdgcn_inverse_ballot_w64(alive1);
+                const double m0 = n0 ? A0(c) / piv : 0.0;
+                const double m1 = n1 ? A1(c) / piv : 0.0;
+                L0(c) = m0; L1(c) = m1;
+                F_STAMP(4);   // the two IEEE divisions
+#pragma unroll
+                for (int c2 = 0; c2 < kPanel; c2++)
+                    if (c2 > c) {
+                        // the reference skips l == 0; e - 0 * u == e for the finite u of a block that is not rejected anyway
+                        // (same argument as in P4), so no compare / select on the chain to the next pivot search
+                        A0(c2) = A0(c2) - m0 * urow[c2];
+                        A1(c2) = A1(c2) - m1 * urow[c2];
+                    }
+                F_STAMP(5);   // panel update
             }
         };
-        static_assert(kPanel == 4, "factor_panel names its four columns");
+        static_assert(kPanel == 4 && kNR % kPanel == 1, "factor_panel names its four columns; the last panel has one");
         factor_column(std::integral_constant<int, 0>{});
         factor_column(std::integral_constant<int, 1>{});
         factor_column(std::integral_constant<int, 2>{});
         factor_column(std::integral_constant<int, 3>{});
+        alive0_v = alive0; alive1_v = alive1;
         double *Lpp = Lp + par * 96 * kPanel;
 #pragma unroll
         for (int c = 0; c < kPanel; c++) {
             Lpp[lane * kPanel + c] = L0(c);
             if (has1) Lpp[(lane + 64) * kPanel + c] = L1(c);
         }
+#pragma unroll
+        for (int c = 0; c < BW; c++) {                               // pivot history (k is a multiple of 4: a panel never straddles step 64)
+            if (k < 64) hist0 = lane == k + c ? pr_c[c] : hist0;
+            else hist1 = lane == k + c - 64 ? pr_c[c] : hist1;
+        }
         if (lane == 0) {
             if (sing) flag[0] = 1;
+            // (every pivot row index went out the moment it was decided.)  Of Lsub only the entries below the diagonal of a full panel are
+            // ever multiplied by something that is not a literal zero: P4's uz[c2] is 0.0 for c2 >= bw, and what it computes for a pivot
+            // row c >= bw is selected away (never used in arithmetic) -- so the last, one-column panel writes nothing here.
 #pragma unroll
-            for (int c = 0; c < kPanel; c++) {
-                prow_s[par * kPanel + c] = pr_c[c];
+            for (int c = 1; c < BW; c++)
 #pragma unroll
-                for (int c2 = 0; c2 < kPanel; c2++) Lsub[par * kPanel * kPanel + c * kPanel + c2] = (c2 < c && c < bw) ? LS(c, c2) : 0.0;
-            }
+                for (int c2 = 0; c2 < c; c2++) Lsub[par * kPanel * kPanel + c * kPanel + c2] = LS(c, c2);
         }
         F_STAMP(6);   // publication of multipliers / pivot rows / sub-multipliers
     };
@@ -580,7 +625,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     // priority it gets one issue slot in ~4 (shader-clock split: ~20 cycles per dependent instruction).  Raised priority lets the
     // arbiter pick it whenever it is ready; the matrix waves fill the slots its latencies leave.  CHIP_PNP_PRIO (tuning knob).
     if (is_factor && a.factor_prio > 0) __builtin_amdgcn_s_setprio(3);
-    if (is_factor) { load_panel(0); factor_panel(0, kPanel, 0); }
+    if (is_factor) { load_panel(0); factor_panel(std::integral_constant<int, kPanel>{}, 0, 0); }
     __syncthreads();
     // tuning only (CHIP_PNP_STAMPS): per-phase shader-clock totals of the LU, wave 0 (a matrix wave) and wave 6 (the factor wave)
     unsigned long long lu_t = 0, lu_acc[4] = {0, 0, 0, 0};
@@ -712,7 +757,8 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
             }
 #pragma unroll
             for (int c2 = 0; c2 < kPanel; c2++) { A0(c2) = B0(c2); A1(c2) = B1(c2); }
-            factor_panel(kn, bwn, par ^ 1);
+            if (bwn == kPanel) factor_panel(std::integral_constant<int, kPanel>{}, kn, par ^ 1);
+            else factor_panel(std::integral_constant<int, 1>{}, kn, par ^ 1);
         }
         LU_STAMP(2);          // P4 (matrix waves) / F (factor wave)
         __syncthreads();
