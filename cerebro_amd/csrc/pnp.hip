@@ -475,6 +475,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         int pr_c[kPanel] = {0, 0, 0, 0};
         bool sing = false;
         unsigned long long alive0 = uniform_u64(alive0_v), alive1 = uniform_u64(alive1_v);
+        int *const prow_par = prow_s + par * kPanel;
 #pragma unroll
         for (int c = 0; c < kPanel; c++) { L0(c) = 0.0; L1(c) = 0.0; }
         // one pivot column.  The column index is a compile-time constant (generic lambda over integral_constant), so that every
@@ -501,13 +502,11 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                 // v_readfirstlane / 64-bit vector mask arithmetic)
                 int olane, ohalf;
                 bool pivot_ok;
-                bool sel;                                              // per lane: its second row is the one to read -- at lane olane: ohalf
                 const int cl = __builtin_ctzll(cand);                  // cand != 0: the lane holding the max is in it
                 if (__popcll(cand) == 1 && mhi_i - 1u < 0x7fefffffu && (eqm & cand) == 0ull) {
                     olane = cl;
-                    ohalf = __builtin_amdgcn_readlane(up ? 1 : 0, cl);
+                    ohalf = (int)((__builtin_amdgcn_ballot_w64(up) >> cl) & 1ull);   // a scalar bit test of the compare's own lane mask
                     pivot_ok = true;
-                    sel = up;                                          // known before the reduction: the row selects below do not wait for ohalf
                 } else {
                     const double v0 = al0 ? fabs(A0(c)) : -1.0, v1 = al1 ? fabs(A1(c)) : -1.0;
                     double vm = v0 > 0.0 ? v0 : 0.0;                   // NaN never wins, as in the reference scan
@@ -548,7 +547,6 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                     olane = __builtin_amdgcn_readfirstlane(ol);
                     ohalf = __builtin_amdgcn_readfirstlane(oh);
                     pivot_ok = __builtin_amdgcn_readfirstlane((best > 0.0 && found) ? 1 : 0) != 0;
-                    sel = ohalf != 0;
                 }
                 F_STAMP(2);   // who attains it: compares, ballots, logical position
                 if (!pivot_ok) sing = true;
@@ -556,17 +554,28 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                 // the owners publish that row at once.  A relaxed workgroup-scope atomic, NOT a volatile store: the volatile form
                 // compiled to flat_store_dword + s_waitcnt vmcnt(0) (address-space inference skips volatile accesses), a
                 // several-hundred-cycle stall on the critical chain of every column; this is one ds_write_b32, no wait
-                if (lane == 0) __hip_atomic_store(&prow_s[par * kPanel + c], pr_c[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // (stored by every lane: same address, same value -- no exec juggling on the chain)
+                __hip_atomic_store(&prow_par[c], pr_c[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // the pivot row's entries / its earlier multipliers by readlane, and the pivot row leaves the candidates (what is left are
+                // exactly the rows that get a multiplier): one wave-uniform branch on the half instead of a vector select per value
                 double urow[kPanel];
+                if (ohalf) {
 #pragma unroll
-                for (int c2 = 0; c2 < kPanel; c2++) {
-                    urow[c2] = lane_value_f64(sel ? A1(c2) : A0(c2), olane);
-                    if (c2 < c) LS(c, c2) = lane_value_f64(sel ? L1(c2) : L0(c2), olane);
+                    for (int c2 = 0; c2 < kPanel; c2++) {
+                        urow[c2] = lane_value_f64(A1(c2), olane);
+                        if (c2 < c) LS(c, c2) = lane_value_f64(L1(c2), olane);
+                    }
+                    alive1 &= ~(1ull << olane);
+                } else {
+#pragma unroll
+                    for (int c2 = 0; c2 < kPanel; c2++) {
+                        urow[c2] = lane_value_f64(A0(c2), olane);
+                        if (c2 < c) LS(c, c2) = lane_value_f64(L0(c2), olane);
+                    }
+                    alive0 &= ~(1ull << olane);
                 }
                 F_STAMP(3);   // pivot row entries / earlier multipliers by readlane
                 const double piv = urow[c];
-                // the pivot row leaves the candidates: what is left are exactly the rows that get a multiplier
-                if (ohalf) alive1 &= ~(1ull << olane); else alive0 &= ~(1ull << olane);
                 const bool n0 = __builtin_amdgcn_inverse_ballot_w64(alive0), n1 = __builtin_amdgcn_inverse_ballot_w64(alive1);
                 const double m0 = n0 ? A0(c) / piv : 0.0;
                 const double m1 = n1 ? A1(c) / piv : 0.0;
