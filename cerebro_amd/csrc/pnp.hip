@@ -751,16 +751,15 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                     double v = prow_raw[(par * kPanel + c) * 128 + kn + c2];
 #pragma unroll
                     for (int c3 = 0; c3 < kPanel; c3++)
-                        if (c3 < c) v = v - LS(c, c3) * un[c3];   // no l != 0 test (v - 0*u == v); un[c >= bw] is not used (uc below)
+                        if (c3 < c) v = v - LS(c, c3) * un[c3];   // no l != 0 test (v - 0*u == v)
                     un[c] = v;
                 }
                 double e0 = pp[lane * kPanel + c2];
                 double e1 = has1 ? pp[(lane + 64) * kPanel + c2] : 0.0;
 #pragma unroll
-                for (int c = 0; c < kPanel; c++) {
-                    const double uc = c < bw ? un[c] : 0.0;
-                    e0 = e0 - L0(c) * uc;
-                    e1 = e1 - L1(c) * uc;
+                for (int c = 0; c < kPanel; c++) {   // (a panel that is applied to a next one is a full panel: only the last has one column)
+                    e0 = e0 - L0(c) * un[c];
+                    e1 = e1 - L1(c) * un[c];
                 }
                 B0(c2) = e0; B1(c2) = e1;
             }
