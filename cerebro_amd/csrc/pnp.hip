@@ -503,7 +503,9 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                 int olane, ohalf;
                 bool pivot_ok;
                 const int cl = __builtin_ctzll(cand);                  // cand != 0: the lane holding the max is in it
-                if (__popcll(cand) == 1 && mhi_i - 1u < 0x7fefffffu && (eqm & cand) == 0ull) {
+                // (one candidate lane, a finite non-zero maximum, its two rows differ in the high word -- as ONE scalar sum: fewer SALU
+                //  instructions than three conditions and-ed as lane masks)
+                if (__popcll(cand) + (mhi_i - 1u < 0x7fefffffu ? 0 : 2) + ((eqm & cand) != 0ull ? 2 : 0) == 1) {
                     olane = cl;
                     ohalf = (int)((__builtin_amdgcn_ballot_w64(up) >> cl) & 1ull);   // a scalar bit test of the compare's own lane mask
                     pivot_ok = true;
