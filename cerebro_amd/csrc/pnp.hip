@@ -1487,6 +1487,7 @@ struct EigArgs {
     int32_t *nsol;          // [H]  number of cheirality-valid real solutions (diagnostics)
     unsigned long long *mask;  // [H][mask_words]
     int32_t debug_stop;     // tuning only (CHIP_PNP_DEBUG_STOP)
+    int32_t backsub_loop;   // CHIP_PNP_BACKSUB=loop: the loop form of the back-substitution only (test knob: the two forms must agree bit for bit)
     unsigned long long *stamps;   // tuning only (CHIP_PNP_STAMPS): [H][8] shader-clock totals per wave, see pnp_eig_score<true>
 };
 
@@ -1614,6 +1615,54 @@ struct HessenbergSteps {
     {
         ortran_step<M>(Hs, Vs, us, ortm, lane);
         if constexpr (M > 1) HessenbergSteps<M - 1>::ortran(Hs, Vs, us, ortm, lane);
+    }
+};
+
+// ---- back-substitution with compile-time row index (round 4) --------------------------------------------------------------------
+// hqr2's real-eigenvector back-substitution, lane n = eigenvector n, as straight-line code over the rows i = 25 .. 0 with the vector x in
+// REGISTERS (x[j], j a compile-time index).  The lane-per-eigenvector loops it replaces ran every lane's own trip counts one after the
+// other (19 us of the reference-mode call; ~5 k instructions per wave, which is what counts when many problems are batched).  What makes
+// the uniform form possible:
+//   * which rows belong to a complex pair depends on wi[] only, so the branch structure is wave-uniform (bit masks of wi < 0 / wi == 0);
+//   * the lower bound of a row's sum is uniform too: j starts at i + 1 unless row i + 1 is the pending second row of a pair (then i + 2);
+//   * the upper bound (j <= n) is per lane -- but x[j] of lane n is 0.0 for j > n (never written), and rr + H(i,j) * 0.0 == rr bit for bit
+//     for finite H (rr starts as +0.0 and a sum that starts there never becomes -0.0), so the terms beyond n are simply added.
+// Same operations in the same order on the same values otherwise.  Two cases are left to the loop form (the caller falls back to it and
+// redoes the whole back-substitution): a non-finite entry anywhere in H or V (0 * inf), and the overflow rescaling of hqr2 (x /= |x_i|
+// when eps * x_i^2 > 1), neither of which a test scene has produced.
+template <int I>
+struct BackSubRow {
+    // returns false when some lane needs the rescaling
+    static __device__ __forceinline__ bool run(const double *Hs, const double *wr, const double *wi, double (&x)[EN], double pe, double &zz, double &ss,
+                                               bool real_root, int lane, unsigned neg_mask, unsigned zero_mask, double eps, double eps_norm)
+    {
+        const double ww = HH(I, I) - pe;
+        double rr = 0.0;
+        if (!((neg_mask >> (I + 1)) & 1u)) rr = rr + HH(I, I + 1) * x[I + 1];   // row I + 1 solved in its own step
+#pragma unroll
+        for (int j = I + 2; j < EN; j++) rr = rr + HH(I, j) * x[j];
+        const bool act = real_root && lane > I;
+        bool big = false;
+        if ((neg_mask >> I) & 1u) { zz = ww; ss = rr; }
+        else if ((zero_mask >> I) & 1u) {
+            const double xi = (ww != 0.0) ? -rr / ww : -rr / eps_norm;
+            x[I] = act ? xi : x[I];
+            const double tt = fabs(xi);
+            big = act && (eps * tt) * tt > 1;
+        } else {  // 2x2 block of a complex pair above a real eigenvalue
+            const double xx = HH(I, I + 1), yy = HH(I + 1, I);
+            const double wri = wr[I], wii = wi[I];
+            const double qq = (wri - pe) * (wri - pe) + wii * wii;
+            const double tt = (xx * ss - zz * rr) / qq;
+            const double x1 = (fabs(xx) > fabs(zz)) ? (-rr - ww * tt) / xx : (-ss - yy * tt) / zz;
+            x[I] = act ? tt : x[I];
+            x[I + 1] = act ? x1 : x[I + 1];
+            const double at = fabs(tt);
+            big = act && (eps * at) * at > 1;
+        }
+        if (__builtin_amdgcn_ballot_w64(big) != 0ull) return false;
+        if constexpr (I > 0) return BackSubRow<I - 1>::run(Hs, wr, wi, x, pe, zz, ss, real_root, lane, neg_mask, zero_mask, eps, eps_norm);
+        else return true;
     }
 };
 
@@ -2045,7 +2094,43 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     // ================= back-substitution (real eigenvalues only), one lane per eigenvector =================
     int my_valid = 0;
     double R[9], t3[3];
-    if (!failed && norm != 0.0 && lane < nn && wi[lane] == 0.0) {
+    const bool real_root = !failed && norm != 0.0 && lane < nn && wi[lane] == 0.0;
+    double v4[4] = {0.0, 0.0, 0.0, 0.0};
+    bool have_v4 = false;
+    if (!a.backsub_loop) {
+        // every entry of H and V finite?  (lane-strided pass; one ballot)
+        unsigned worst = 0;
+        for (int e = lane; e < EN * EN; e += 64) {
+            const unsigned hh = (unsigned)((unsigned long long)__double_as_longlong(Hs[e]) >> 32) & 0x7fffffffu;
+            const unsigned hv = (unsigned)((unsigned long long)__double_as_longlong(Vs[e]) >> 32) & 0x7fffffffu;
+            worst = hh > worst ? hh : worst;
+            worst = hv > worst ? hv : worst;
+        }
+        const bool finite = __builtin_amdgcn_ballot_w64(worst >= 0x7ff00000u) == 0ull;
+        if (finite && __builtin_amdgcn_ballot_w64(real_root) != 0ull) {
+            const double wl = lane < nn ? wi[lane] : 0.0;
+            const unsigned neg_mask = (unsigned)__builtin_amdgcn_ballot_w64(lane < nn && wl < 0.0);
+            const unsigned zero_mask = (unsigned)__builtin_amdgcn_ballot_w64(lane < nn && wl == 0.0);
+            const double pe = lane < nn ? wr[lane] : 0.0;
+            double x[EN];
+#pragma unroll
+            for (int j = 0; j < EN; j++) x[j] = (j == lane) ? 1.0 : 0.0;
+            double zz = 0.0, ss = 0.0;
+            if (BackSubRow<EN - 2>::run(Hs, wr, wi, x, pe, zz, ss, real_root, lane, neg_mask, zero_mask, eps, eps * norm)) {
+                // back-transform only the rows we need: v = V * x, rows {0,1,3,9} = monomials {1, s3, s2, s1}  (x[k] = 0.0 for k > n)
+                constexpr int rows[4] = {0, 1, 3, 9};
+#pragma unroll
+                for (int rrw = 0; rrw < 4; rrw++) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < EN; k++) acc = acc + VV(rows[rrw], k) * x[k];
+                    v4[rrw] = acc;
+                }
+                have_v4 = true;
+            }
+        } else if (finite) have_v4 = true;   // no real root at all: nothing to solve
+    }
+    if (!have_v4 && real_root) {   // the loop form: one lane per eigenvector, each with its own trip counts (see BackSubRow)
         const int nn_ = lane;  // eigenvalue index n
         const double pe = wr[nn_];
         int l = nn_;
@@ -2083,7 +2168,6 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             }
         }
         // back-transform only the rows we need: v = V * x, rows {0,1,3,9} = monomials {1, s3, s2, s1}
-        double v4[4];
         const int rows[4] = {0, 1, 3, 9};
         for (int rrw = 0; rrw < 4; rrw++) {
             const int i = rows[rrw];
@@ -2092,6 +2176,8 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             v4[rrw] = acc;
         }
 #undef XX
+    }
+    if (real_root) {
         const double s1 = v4[3] / v4[0], s2 = v4[2] / v4[0], s3 = v4[1] / v4[0];
         if (fabs(s1) <= DBL_MAX && fabs(s2) <= DBL_MAX && fabs(s3) <= DBL_MAX) {
             const double nq = sqrt(((1.0 + s1 * s1) + s2 * s2) + s3 * s3);
@@ -2350,6 +2436,15 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
     ea.H = H; ea.S = S; ea.thresh = p->error_thresh; ea.use_mle = p->use_mle;
     ea.Sg = st->Sg; ea.Tg = st->Tg; ea.sample = st->sample; ea.ok = st->ok; ea.mask_words = words;
     { const char *dv = std::getenv("CHIP_PNP_DEBUG_STOP"); ea.debug_stop = dv ? std::atoi(dv) : 0; }
+    {
+        static const int loop_form = [] {
+            const char *e = std::getenv("CHIP_PNP_BACKSUB");
+            const int on = e && std::strcmp(e, "loop") == 0;
+            if (on) std::fprintf(stderr, "[cerebro_hip] TEST KNOB ACTIVE: CHIP_PNP_BACKSUB=loop -- pnp_eig_score runs the loop form of the back-substitution\n");
+            return on;
+        }();
+        ea.backsub_loop = loop_form;
+    }
     ea.T_out = st->T_out; ea.cost = st->cost; ea.nin = st->nin; ea.valid = st->valid; ea.nsol = st->nsol; ea.mask = st->mask;
     if (want_stamps) ea.stamps = st->stamps;
     // A batch of several problems may go out as `groups` launch pairs on as many streams (CHIP_PNP_GROUPS, tuning): both kernels are

@@ -139,3 +139,16 @@ def test_batch_equals_individual_calls_and_oracle(H):
         assert chip.pnp_ransac_batch([], gparams()) == []
         with pytest.raises(Exception):
             chip.pnp_ransac_batch([scenes[0], (scenes[0][0][:19], scenes[0][1][:19])], gparams())    # a problem with < 20 points
+
+
+def test_back_substitution_forms_agree():
+    """pnp_eig_score solves the real eigenvectors with straight-line code over compile-time row indices and keeps hqr2's loop form for
+    the two cases that code leaves out (a non-finite entry of H / V, the overflow rescaling).  No scene reaches those, so the loop form is
+    forced by its test knob in a process of its own and must pass the same fuzz (poses, masks, iteration counts bit for bit vs the oracle)."""
+    import os, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, CHIP_PNP_BACKSUB="loop")
+    r = subprocess.run([sys.executable, str(root / "scripts" / "gpu_pnp_fuzz.py"), "36"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert "TEST KNOB ACTIVE: CHIP_PNP_BACKSUB=loop" in r.stderr, r.stderr[-400:]
+    assert "fuzz: 0 mismatches" in r.stdout, (r.stdout[-400:], r.stderr[-400:])
