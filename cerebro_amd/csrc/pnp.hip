@@ -679,7 +679,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
                         default: u = er[30]; break;
                     }
                     prow_raw[(parq * kPanel + c) * 128 + tx] = u;
-                    live &= ~(1u << ps);
+                    live &= ~(1u << (ps & 31));   // (ps <= 30 for a real pivot row; a singular block's leftovers may name rows past 92)
                 }
             }
         }
