@@ -544,6 +544,7 @@ def main():
         chip = capi.Chip(D, capacity_hint=total_rows, device=local_rank, shard_rank=0 if replicated else rank,
                          shard_count=1 if replicated else world, storage=storage)
     det = None
+    det_over_torch_nccl = False
     exchange = "none"
     if (world > 1 and not replicated) or args.force_sharded:
         if args.host_exchange:
@@ -623,6 +624,7 @@ def main():
                     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
                 grp = dist.new_group(backend="nccl") if dist.get_backend() != "nccl" else None
                 det = ShardedLoopDetector(chip, topk=TOPK, group=grp, device=torch.device("cuda", local_rank))
+                det_over_torch_nccl = dist.get_backend() != "nccl"   # a second RCCL bootstrap (torch's): its first collective runs under the warmup deadline too
                 exchange = "host-driven fallback: torch.distributed all_gather_into_tensor (nccl) after chip_comm_init_rank failed"
     elif group_mode:
         exchange = {capi.CHIP_EXCHANGE_RCCL: "in-library RCCL (ncclCommInitAll, one worker thread per device)",
@@ -678,10 +680,11 @@ def main():
     # Warmup.  On a multi-GPU exchange inside the library it is also the FIRST execution of the collective (ncclAllGather over
     # xGMI between real devices): it runs under a deadline, and if it does not come back on some rank every rank rebuilds its
     # context on an exchange that needs no RCCL -- the run still ends with a JSON line, and the line says what happened.
-    guarded = det is None and ((world > 1 and not replicated) or args.force_sharded or group_mode) and info_exchange(chip) != capi.CHIP_EXCHANGE_NONE
+    guarded = (det is None and ((world > 1 and not replicated) or args.force_sharded or group_mode) and info_exchange(chip) != capi.CHIP_EXCHANGE_NONE) \
+        or det_over_torch_nccl
 
     def warm():
-        if os.environ.get("BENCH_HANG_WARMUP") and guarded and info_exchange(chip) == capi.CHIP_EXCHANGE_RCCL:   # test hook
+        if os.environ.get("BENCH_HANG_WARMUP") and guarded and (info_exchange(chip) == capi.CHIP_EXCHANGE_RCCL or det_over_torch_nccl):   # test hook
             time.sleep(1e6)
         return run(ls[:args.warmup])
 
@@ -695,7 +698,7 @@ def main():
             okw = int(flag[0].item())
         if not okw:
             why = "did not finish within its deadline" if not fin else (f"failed: {exc}" if exc is not None else "failed on another rank")
-            sys.stderr.write(f"[bench rank {rank}] warmup over the in-library exchange {why}: rebuilding on a fallback exchange\n")
+            sys.stderr.write(f"[bench rank {rank}] warmup over the {'torch.distributed nccl' if det_over_torch_nccl else 'in-library'} exchange {why}: rebuilding on a fallback exchange\n")
             abandon_process = True            # the old ctx (and whatever is stuck in it) is left alone
             if group_mode:
                 chip = capi.Chip(D, capacity_hint=total_rows, devices=devices, storage=storage, copy_exchange=True)
@@ -708,8 +711,10 @@ def main():
                     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
                     os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
                     dist.init_process_group("gloo")
-                det = ShardedLoopDetector(chip, topk=TOPK, device=torch.device("cuda", local_rank))
-                runtime_fallback = f"host-driven fallback: torch.distributed all_gather_into_tensor ({dist.get_backend()}) -- the warmup over in-library RCCL {why}"
+                det = ShardedLoopDetector(chip, topk=TOPK, device=torch.device("cuda", local_rank))   # default group: the control plane (gloo)
+                runtime_fallback = f"host-driven fallback: torch.distributed all_gather_into_tensor ({dist.get_backend()}) -- the warmup over " \
+                                   f"{'torch.distributed nccl (itself the fallback of a failed chip_comm_init_rank)' if det_over_torch_nccl else 'in-library RCCL'} {why}"
+                det_over_torch_nccl = False
             exchange = runtime_fallback
             t_fill = fill(chip)
             run = make_run(chip, det)

@@ -18,7 +18,11 @@ ROOT = Path(__file__).resolve().parent.parent
 
 @pytest.mark.parametrize("n,extra,hook", [(2, ["--host-exchange"], {}), (3, ["--replicated"], {}),
                                           # the in-library attach "hangs" on every rank: deadline -> exchange over gloo, exit code 0
-                                          (2, [], {"BENCH_HANG_COMM_INIT": "1", "BENCH_COMM_INIT_TIMEOUT": "2"})])
+                                          (2, [], {"BENCH_HANG_COMM_INIT": "1", "BENCH_COMM_INIT_TIMEOUT": "2"}),
+                                          # double fault: the in-library attach FAILS, and the torch.distributed nccl group the run falls back to
+                                          # cannot run its first collective either (here: RCCL refuses two ranks on one device) -- that collective
+                                          # is the warmup, which runs under a deadline; the run ends on the gloo exchange, with its JSON line
+                                          (2, [], {"BENCH_FAIL_COMM_INIT": "1", "BENCH_WARMUP_TIMEOUT": "30"})])
 def test_bench_under_torchrun(n, extra, hook):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -36,8 +40,10 @@ def test_bench_under_torchrun(n, extra, hook):
         assert key in j, key
     assert j["n_gpus"] == n and j["steps"] == 24 and j["value"] > 0
     assert j["scaling"] == ("weak" if "--replicated" in extra else "strong")
-    if hook:
+    if "BENCH_HANG_COMM_INIT" in hook:
         assert "hung" in j["config"]["exchange"]
+    if "BENCH_FAIL_COMM_INIT" in hook:
+        assert "gloo" in j["config"]["exchange"] and "torch.distributed nccl" in j["config"]["exchange"] and j["config"]["exchange_runtime_fallback"]
     assert "cpu_baseline" not in j and "pnp" not in j          # rank 0 at N = 1 only
 
 
