@@ -19,7 +19,7 @@ ORC_SRCS   := $(wildcard oracle/*.c)
 
 all: lib oracle host verify
 lib: $(LIBDIR)/libcerebro_hip.so
-oracle: oracle/_build/liboracle.so oracle/_build/liboracle_eispack.so
+oracle: oracle/_build/liboracle.so oracle/_build/liboracle_eispack.so oracle/_build/liboracle_stats.so
 host: $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay $(LIBDIR)/minimal_loop_detector
 
 $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/chip_internal.h $(CSRC)/ransac_common.h $(CSRC)/topk_merge.h include/cerebro_hip.h
@@ -47,6 +47,12 @@ oracle/_build/liboracle.so: $(ORC_SRCS) oracle/cerebro_oracle.h
 oracle/_build/liboracle_eispack.so: $(ORC_SRCS) oracle/cerebro_oracle.h
 	@mkdir -p oracle/_build
 	$(CC) $(ORCFLAGS) -DORC_EISPACK_DIVIDE -shared $(ORC_SRCS) -o $@ -lm
+
+# The same oracle counting, per pivot column of the DLS elimination, the candidates that tie (test infrastructure for
+# tests/test_fuzz_scenes_reach_tie_paths.py only: which inputs reach the tie paths of the GPU's pivot search).
+oracle/_build/liboracle_stats.so: $(ORC_SRCS) oracle/cerebro_oracle.h
+	@mkdir -p oracle/_build
+	$(CC) $(ORCFLAGS) -DORC_LU_TIE_STATS -shared $(ORC_SRCS) -o $@ -lm
 
 # ---- plain-C-ABI example (the INTEGRATION.md call sequence without ROS / Eigen) ----
 $(LIBDIR)/minimal_loop_detector: examples/minimal_loop_detector.cc include/cerebro_hip.h $(LIBDIR)/libcerebro_hip.so

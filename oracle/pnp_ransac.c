@@ -256,6 +256,9 @@ void orc_dls_cubics(const double *X, const double *uv, int32_t n, double Tfac[27
 /* ================================================================ DLS step 6-7: Macaulay matrix -> action matrix */
 /* S (27x27 row-major) = A - B D^-1 C of the degree-7 Macaulay matrix of {f0; f1, f2, f3}.  Returns 0 on success,
  * -1 if a zero pivot is met (singular D). */
+#ifdef ORC_LU_TIE_STATS
+long orc_lu_tie_stats[4];   /* pivot columns seen, high-word ties, exact ties, largest elimination step with an exact tie */
+#endif
 int orc_dls_action_matrix(const double f[3][20], const double u[4], double S[27 * 27])
 {
     static const int SH[4][3] = { {0,0,0}, {1,0,0}, {0,1,0}, {0,0,1} };  /* terms of f0: 1, s1, s2, s3 */
@@ -286,6 +289,23 @@ int orc_dls_action_matrix(const double f[3][20], const double u[4], double S[27 
             double v = fabs(E[i * NC + k]);
             if (v > best) { best = v; p = i; }
         }
+#ifdef ORC_LU_TIE_STATS
+        {   /* test infrastructure (oracle/_build/liboracle_stats.so only): does this pivot column reach the tie paths of the GPU's pivot
+             * search?  `high` = two candidates agree in the high word of their magnitude (or the maximum is 0 / not finite): the
+             * 64-bit compare path; `exact` = two candidates attain the maximum exactly: the smallest-logical-index rule. */
+            unsigned int mh = 0; int ch = 0, ce = 0; double bb = -1.0;
+            for (int i = k; i < NR; i++) {
+                const double v = fabs(E[i * NC + k]);
+                unsigned long long b; memcpy(&b, &v, 8);
+                const unsigned int h = (unsigned int)(b >> 32);
+                if (h > mh) { mh = h; ch = 1; } else if (h == mh) ch++;
+                if (v > bb) { bb = v; ce = 1; } else if (v == bb) ce++;
+            }
+            __sync_fetch_and_add(&orc_lu_tie_stats[0], 1);
+            if (ch != 1 || mh == 0 || mh >= 0x7ff00000u) __sync_fetch_and_add(&orc_lu_tie_stats[1], 1);
+            if (ce > 1) { __sync_fetch_and_add(&orc_lu_tie_stats[2], 1); if (k > orc_lu_tie_stats[3]) orc_lu_tie_stats[3] = k; }
+        }
+#endif
         if (!(best > 0.0)) { free(E); return -1; }
         if (p != k)
             for (int j = 0; j < NC; j++) { double t = E[k * NC + j]; E[k * NC + j] = E[p * NC + j]; E[p * NC + j] = t; }
