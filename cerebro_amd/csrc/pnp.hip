@@ -2138,7 +2138,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
         // The eigenvector x of the quasi-triangular form (entries 0..nn_) needs no matrix of its own: after the QR iteration only rows
         // {0, 1, 3, 9} of V are still read (the back-transform of the monomials 1, s3, s2, s1 below), so x lives in the other 23
         // rows -- column c <= 12 at the start of free row F[c], column 25 - c behind it (c + 1 + 26 - c = 27 entries fill the row),
-        // column 26 in a row of its own.  6 KiB less LDS per wave: 11 instead of 8 waves per CU when many problems are batched.
+        // column 26 in a row of its own.  6 KiB less LDS per wave (13.25 KiB: 12 waves per CU instead of 8 when many problems are batched).
         double *xcol;
         {
             const int c = nn_ <= 12 ? nn_ : (nn_ <= 25 ? 25 - nn_ : 13);   // index into the free rows
