@@ -6,7 +6,7 @@ HIPCC      ?= $(ROCM)/bin/hipcc
 ARCH       ?= gfx950
 # -ffp-contract=off: the PnP kernels must round exactly like the oracle (no FMA contraction);
 # the scan kernel uses explicit fma() where the product is exact.
-HIPFLAGS   ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -Wall -Wno-unused-function
+HIPFLAGS   ?= -O3 -std=c++17 --offload-arch=$(ARCH) -fPIC -ffp-contract=off -Wall -Wno-unused-function $(EXTRA_HIPFLAGS)
 CC         ?= gcc
 # -mfma only makes __builtin_fmaf a single vfmadd (exact either way); -ffp-contract=off forbids any other fusion
 ORCFLAGS   ?= -O2 -mfma -ffp-contract=off -fopenmp -fPIC -Wall -Wextra
@@ -17,10 +17,21 @@ HIP_SRCS   := $(CSRC)/kernels.hip $(CSRC)/chip_api.hip $(CSRC)/chip_multi.hip $(
 HIP_OBJS   := $(HIP_SRCS:$(CSRC)/%.hip=$(LIBDIR)/%.o)
 ORC_SRCS   := $(wildcard oracle/*.c)
 
-all: lib oracle host verify
+all: lib oracle host testlibs verify
 lib: $(LIBDIR)/libcerebro_hip.so
 oracle: oracle/_build/liboracle.so oracle/_build/liboracle_eispack.so oracle/_build/liboracle_stats.so
 host: $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay $(LIBDIR)/minimal_loop_detector
+# test infrastructure that needs hipcc: the shared-memory stand-in for librccl (N ranks on one device, tests/test_fakerccl_gpu.py)
+testlibs: tests/fakerccl/_build/libfakerccl.so $(LIBDIR)/norows/libcerebro_hip.so
+# the degraded build (-DCHIP_NO_ROWS_FORM: what scripts/verify_codeobj.sh falls back to), kept next to the real one so that the GPU
+# suite proves BOTH builds (tests/test_norows_build_gpu.py): only kernels.hip differs, the other objects are shared
+$(LIBDIR)/norows/libcerebro_hip.so: $(CSRC)/kernels.hip $(HIP_OBJS)
+	@mkdir -p $(LIBDIR)/norows
+	$(HIPCC) $(HIPFLAGS) -DCHIP_NO_ROWS_FORM -c $(CSRC)/kernels.hip -o $(LIBDIR)/norows/kernels.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(LIBDIR)/norows/kernels.o $(filter-out $(LIBDIR)/kernels.o,$(HIP_OBJS)) -o $@ -lpthread -ldl
+tests/fakerccl/_build/libfakerccl.so: tests/fakerccl/fakerccl.cc
+	@mkdir -p tests/fakerccl/_build
+	$(HIPCC) -O2 -std=c++17 -fPIC -shared $< -o $@ -lrt -lpthread
 
 $(LIBDIR)/%.o: $(CSRC)/%.hip $(CSRC)/chip_internal.h $(CSRC)/ransac_common.h $(CSRC)/topk_merge.h include/cerebro_hip.h
 	@mkdir -p $(LIBDIR)
@@ -60,14 +71,15 @@ $(LIBDIR)/minimal_loop_detector: examples/minimal_loop_detector.cc include/cereb
 
 # ---- build-time check of what the inline asm of the scan kernels relies on: the physical-VGPR partition of
 # db_scan_topk_rows (amdgpu_num_vgpr(40) -> 80 ArchVGPRs on this hipcc; v[80:127] written by the asm loads only), no touch of an
-# in-flight load register in the one-row kernel, pnp_build_solve <= 128 VGPRs.  A toolchain that allocates differently fails the
-# BUILD here instead of producing silently wrong scores.  (The same checks are tests/test_codeobj_registers.py.)
+# in-flight load register in the one-row kernel, pnp_build_solve <= 128 VGPRs.  scripts/verify_codeobj.sh DEGRADES instead of
+# failing: a toolchain that allocates differently gets a library rebuilt with -DCHIP_NO_ROWS_FORM (loud line; chip_get_info says
+# so); a machine without pytest / llvm-objdump gets a loud warning and the library as built.  `make lib` never runs it.
 verify: $(LIBDIR)/.codeobj_verified
-$(LIBDIR)/.codeobj_verified: $(LIBDIR)/libcerebro_hip.so tests/test_codeobj_registers.py oracle/_build/liboracle.so $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay $(LIBDIR)/minimal_loop_detector
-	python3 -m pytest tests/test_codeobj_registers.py -q -x -p no:cacheprovider
+$(LIBDIR)/.codeobj_verified: $(LIBDIR)/libcerebro_hip.so tests/test_codeobj_registers.py scripts/verify_codeobj.sh $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay $(LIBDIR)/minimal_loop_detector
+	bash scripts/verify_codeobj.sh
 	@touch $@
 
 clean:
-	rm -rf $(LIBDIR) oracle/_build
+	rm -rf $(LIBDIR) oracle/_build tests/fakerccl/_build
 
-.PHONY: all lib oracle host verify clean
+.PHONY: all lib oracle host testlibs verify clean

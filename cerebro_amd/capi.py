@@ -41,6 +41,7 @@ CHIP_CREATE_STORE_F64 = 2
 CHIP_MULTI_EXCHANGE_COPY = 4
 CHIP_COMM_ID_BYTES = 128
 CHIP_EXCHANGE_NONE, CHIP_EXCHANGE_RCCL, CHIP_EXCHANGE_COPY = 0, 1, 2
+CHIP_SCAN_FORM_ONE_ROW, CHIP_SCAN_FORM_ROWS = 1, 2
 
 CHIP_TICK_SKIPPED, CHIP_TICK_TOO_SHORT, CHIP_TICK_SCANNED = 0, 1, 2
 
@@ -86,7 +87,7 @@ class Info(C.Structure):
                 ("shard_count", C.c_int32), ("n_cus", C.c_int32), ("rows_global", C.c_int64),
                 ("rows_local", C.c_int64), ("capacity_local", C.c_int64), ("lossy_rows", C.c_int64),
                 ("arch", C.c_char * 32), ("storage_bytes", C.c_int32), ("n_devices", C.c_int32), ("exchange", C.c_int32),
-                ("comm_ranks", C.c_int32), ("comm_init_abandoned", C.c_int32)]
+                ("comm_ranks", C.c_int32), ("comm_init_abandoned", C.c_int32), ("scan_forms", C.c_int32)]
 
 
 # every symbol include/cerebro_hip.h declares: name -> (restype, argtypes)
@@ -94,6 +95,7 @@ _P = C.c_void_p
 _SIGS = {
     "chip_strerror": (C.c_char_p, [C.c_int]),
     "chip_abi_version": (C.c_int, []),
+    "chip_build_scan_forms": (C.c_int, []),
     "chip_last_hip_error": (C.c_int, [_P, C.POINTER(C.c_char_p)]),
     "chip_last_comm_error": (C.c_int, [_P, C.POINTER(C.c_char_p)]),
     "chip_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),

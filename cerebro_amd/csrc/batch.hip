@@ -415,6 +415,8 @@ void batch_destroy(Ctx *c)
     c->batch_state = nullptr;
 }
 
+int32_t batch_qpad(int32_t Q) { return (Q + BM - 1) / BM * BM; }
+
 // This ctx's share of a many-query call, enqueued on its scan stream: Q queries (host, Q x D fp32) against its LOCAL rows of the global
 // prefix [0, k) -- the whole prefix on a plain ctx, rows i % G == rank of it on a shard -- leaving one sorted [Qpad][topk] list of
 // (score, GLOBAL index) entries in device memory (*out_dev).  No host synchronisation.  Caller: query lock held, device current.
@@ -426,7 +428,7 @@ int batch_local_enqueue(Ctx *c, int64_t k, const float *queries, int32_t Q, int3
     }
     BatchState *st = static_cast<BatchState *>(c->batch_state);
     const int D = c->D;
-    const int Qpad = (Q + BM - 1) / BM * BM;
+    const int Qpad = batch_qpad(Q);
     const int64_t n_rows = local_count(c, k);
     // Tile shape: 256 x 256 with 8 waves (one workgroup per CU: 16 MFMAs per 6 fragment reads, one barrier per 128 MFMAs, the DB
     // streamed once per 256 queries) when the padded query count is a multiple of 256, else 128 x 128 with 4 waves.

@@ -37,6 +37,7 @@ const char *chip_strerror(int status)
 }
 
 int chip_abi_version(void) { return CHIP_ABI_VERSION; }
+int chip_build_scan_forms(void) { return scan_forms_built(); }
 
 int chip_last_hip_error(const chip_ctx *ctx, const char **text)
 {
@@ -1132,6 +1133,7 @@ int chip_get_info(const chip_ctx *c, chip_info *info)
     info->exchange = c->group ? c->group_transport : (c->xchg ? CHIP_EXCHANGE_RCCL : CHIP_EXCHANGE_NONE);
     info->comm_ranks = exchange_comm_ranks(c->group ? r : c);
     info->comm_init_abandoned = c->comm_init_abandoned;
+    info->scan_forms = scan_forms_built();
     return CHIP_OK;
 }
 

@@ -57,6 +57,7 @@ int launch_merge(Ctx *c, hipStream_t s, const MergeArgs &a, int nq);
 int scan_grid_for(const Ctx *c, int64_t n_rows, int nq, bool q64);
 bool scan_q64(const Ctx *c, int nq, bool long_scan);
 int scan_rows_form(const Ctx *c, int64_t n_rows, int nq, int grid, bool q64);
+int scan_forms_built();              // CHIP_SCAN_FORM_* bits of this build (-DCHIP_NO_ROWS_FORM leaves the row-batched kernel out)
 int launch_scores(Ctx *c, hipStream_t s, const ScanArgs &a, double *out_dev);   // K1s: all scores of one query, out[local row]
 int launch_store_rows(Ctx *c, hipStream_t s, const void *src, int src_elem, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring,
                       int64_t row_stride = 1);
@@ -268,6 +269,7 @@ Ctx *group_root(Ctx *gc);
 int group_size(const Ctx *gc);
 
 // batch.hip: the many-query (MFMA) mode in pieces, so that chip_multi.hip can run it over the shards of a DB
+int32_t batch_qpad(int32_t Q);            // Q rounded up to the query-tile granularity (BM) of db_gemm_topk
 int batch_local_enqueue(Ctx *c, int64_t k, const float *queries, int32_t Q, int32_t topk, chip_topk_entry **out_dev, int32_t *Qpad_out);
 int batch_deliver(Ctx *c, const chip_topk_entry *list_dev, int32_t Q, int32_t topk, float *scores, int64_t *idx);
 int batch_exchange_buffers(Ctx *c, int n_lists, int32_t Qpad, int32_t topk, chip_topk_entry **gathered, chip_topk_entry **merged, hipEvent_t *ev_done);

@@ -24,6 +24,7 @@
 #include <functional>
 #include <memory>
 #include <new>
+#include <system_error>
 #include <thread>
 
 namespace chip {
@@ -123,6 +124,7 @@ static int comm_init_timeout_ms()
 // returns true when the helper finished in time (job->result / job->comms are final), false when it was abandoned
 static bool comm_init_run(const std::shared_ptr<CommInitJob> &job)
 {
+    try {
     std::thread([job] {
         ncclResult_t r;
         const int hook = comm_init_test_hook();
@@ -142,6 +144,11 @@ static bool comm_init_run(const std::shared_ptr<CommInitJob> &job)
         // exchange could block again); the job, and with it this record of them, is released with the last reference
         job->cv.notify_all();
     }).detach();
+    } catch (const std::system_error &) {   // no thread to be had: an extern "C" entry point must not throw -- report it as a failed bootstrap
+        job->result = ncclSystemError;
+        job->done = true;
+        return true;
+    }
     std::unique_lock<std::mutex> lk(job->m);
     if (job->cv.wait_for(lk, std::chrono::milliseconds(comm_init_timeout_ms()), [&] { return job->done; })) return true;
     job->abandoned = true;
@@ -160,6 +167,8 @@ struct Exchange {
     chip_topk_entry *gathered_ring = nullptr;   // [kXRing][world][kListEntries]   all shards' lists ([world][nq][K] packed)
     hipEvent_t ev_local[kXRing] = {};           // copy exchange: this shard's list of tick b is written
     chip_topk_entry *failed_list = nullptr;     // [kListEntries] of (-inf, kFailedShardIdx): what a shard that cannot take part sends
+    int32_t *agree_dev = nullptr;               // [1 + world]: this rank's "I can take part" word, then every rank's (xchg_agree)
+    int32_t *agree_host = nullptr;              // pinned, [1 + world]
     uint64_t n = 0;                             // ticks / queries exchanged so far (one-process-per-GPU layout)
     uint64_t n_calls = 0;                       // collective calls seen by this shard (test hook below)
     int test_fail_every = 0;                    // CHIP_TEST_FAIL_SHARD="rank:every": this shard fails its validation on every
@@ -183,6 +192,8 @@ static int exchange_create(Ctx *c, int world, bool need_gathered)
         CHIP_HIP(c, hipMalloc(&x->failed_list, sizeof(chip_topk_entry) * kListEntries));
         CHIP_HIP(c, hipMemcpy(x->failed_list, mark.data(), sizeof(chip_topk_entry) * kListEntries, hipMemcpyHostToDevice));
     }
+    CHIP_HIP(c, hipMalloc(&x->agree_dev, sizeof(int32_t) * (size_t)(1 + world)));
+    CHIP_HIP(c, hipHostMalloc(&x->agree_host, sizeof(int32_t) * (size_t)(1 + world), hipHostMallocDefault));
     if (const char *t = std::getenv("CHIP_TEST_FAIL_SHARD")) {
         int r = -1, every = 0;
         if (std::sscanf(t, "%d:%d", &r, &every) == 2 && r == c->rank && every > 0) {
@@ -200,6 +211,18 @@ static bool test_fail_now(Exchange *x)
     return x->test_fail_every > 0 && x->n_calls % (uint64_t)x->test_fail_every == 0;
 }
 
+// test hook: CHIP_TEST_BATCH_OOM="rank": this rank's many-query call pretends its per-call allocations failed (announced on stderr)
+static int test_oom_rank()
+{
+    static const int r = [] {
+        const char *t = std::getenv("CHIP_TEST_BATCH_OOM");
+        if (!t || !*t) return -1;
+        std::fprintf(stderr, "[cerebro_hip] TEST HOOK ACTIVE: CHIP_TEST_BATCH_OOM=%s -- that rank's many-query allocations fail\n", t);
+        return std::atoi(t);
+    }();
+    return r;
+}
+
 void exchange_destroy(Ctx *c)
 {
     Exchange *x = c->xchg;
@@ -209,6 +232,8 @@ void exchange_destroy(Ctx *c)
     if (x->local_ring) (void)hipFree(x->local_ring);
     if (x->gathered_ring) (void)hipFree(x->gathered_ring);
     if (x->failed_list) (void)hipFree(x->failed_list);
+    if (x->agree_dev) (void)hipFree(x->agree_dev);
+    if (x->agree_host) (void)hipHostFree(x->agree_host);
     for (hipEvent_t e : x->ev_local)
         if (e) (void)hipEventDestroy(e);
     delete x;
@@ -244,12 +269,15 @@ int xchg_tick_enqueue(Ctx *c, int64_t l, int64_t k, const chip_dot_params *p, Sl
     }
     const int b = (int)(x->n++ % kXRing);
     const chip_topk_entry *mine = x->failed_list;
+    int rc_local = CHIP_OK;
     if (!fail_local) {
-        const int rc = enqueue_scan_merge(c, k, q, 3, K, l, nullptr, x->local(b), nullptr, true, nullptr);   // scan streams -> local merge on the ctx stream
-        if (rc != CHIP_OK) return rc;
-        mine = x->local(b);
+        rc_local = enqueue_scan_merge(c, k, q, 3, K, l, nullptr, x->local(b), nullptr, true, nullptr);   // scan streams -> local merge on the ctx stream
+        if (rc_local == CHIP_OK) mine = x->local(b);
+        // a HIP error / OOM of THIS rank's enqueue: the peers have posted their all-gather -- take part with the mark (they
+        // get CHIP_ERR_SHARD_FAILED for this tick, the communicator stays in step), report the local error afterwards
     }
     CHIP_NCCL(c, rccl().AllGather(mine, x->gathered(b), sizeof(chip_topk_entry) * 3 * K, ncclChar, x->comm, c->s_query));
+    if (rc_local != CHIP_OK) return rc_local;
     return merge_enqueue_slot(c, l, p, x->gathered(b), x->world, K, s);               // merge + decision (:1035-1056), every rank
 }
 
@@ -284,12 +312,13 @@ int xchg_query(Ctx *c, int64_t k, const void *const *q, int nq, int K, double *s
     if (test_fail_now(x)) fail_local = true;
     const int b = (int)(x->n++ % kXRing);
     const chip_topk_entry *mine = x->failed_list;
+    int rc_local = CHIP_OK;
     if (!fail_local) {
-        const int rc = enqueue_scan_merge(c, k, q, nq, K, 0, nullptr, x->local(b), nullptr, false, nullptr);
-        if (rc != CHIP_OK) return rc;
-        mine = x->local(b);
+        rc_local = enqueue_scan_merge(c, k, q, nq, K, 0, nullptr, x->local(b), nullptr, false, nullptr);
+        if (rc_local == CHIP_OK) mine = x->local(b);   // else: take part with the mark, report the local error afterwards (see xchg_tick_enqueue)
     }
     CHIP_NCCL(c, rccl().AllGather(mine, x->gathered(b), sizeof(chip_topk_entry) * nq * K, ncclChar, x->comm, c->s_query));
+    if (rc_local != CHIP_OK) return rc_local;
     const int rc = merge_enqueue_out(c, x->gathered(b), x->world, nq, K, c->topk_dev);
     if (rc != CHIP_OK) return rc;
     return sync_topk_out(c, nq, K, scores, idx);
@@ -795,35 +824,55 @@ int group_query_batch(Ctx *gc, int64_t k, const float *queries, int32_t Q, int32
     return rc;
 }
 
-// The same on a sharded ctx of the one-process-per-GPU layout with its exchange inside the library: local pass -> ncclAllGather of
-// the [Qpad][topk] lists -> merge on every rank (collective: every rank makes the same call; a rank whose own arguments are out of
-// range takes part with the failure mark, like xchg_query).
+// One small collective in which every rank says whether it can take part in the LARGE one that follows (4 bytes per rank, on the
+// ctx stream, host-synchronised).  The many-query call allocates per-call buffers (queries, partial lists, the gathered lists:
+// Q x topk x 16 B x world) and launches a GEMM before its all-gather: a rank that runs out of memory there has nothing to send and
+// nothing to receive into, so it cannot "take part with the mark" the way a tick does -- instead all ranks agree first and, unless
+// every rank is ready, ALL of them skip the large collective.  Costs one latency-bound collective per many-query call
+// (milliseconds of GEMM).  Only an RCCL / HIP error of the agreement itself is hard.
+static int xchg_agree(Ctx *c, bool ok_local, bool *all_ok)
+{
+    Exchange *x = c->xchg;
+    x->agree_host[0] = ok_local ? 1 : 0;
+    CHIP_HIP(c, hipMemcpyAsync(x->agree_dev, x->agree_host, sizeof(int32_t), hipMemcpyHostToDevice, c->s_query));
+    CHIP_NCCL(c, rccl().AllGather(x->agree_dev, x->agree_dev + 1, sizeof(int32_t), ncclChar, x->comm, c->s_query));
+    CHIP_HIP(c, hipMemcpyAsync(x->agree_host + 1, x->agree_dev + 1, sizeof(int32_t) * (size_t)x->world, hipMemcpyDeviceToHost, c->s_query));
+    CHIP_HIP(c, hipStreamSynchronize(c->s_query));
+    bool all = true;
+    for (int r = 0; r < x->world; r++) all = all && x->agree_host[1 + r] == 1;
+    *all_ok = all;
+    return CHIP_OK;
+}
+
+// The same on a sharded ctx of the one-process-per-GPU layout with its exchange inside the library: local pass -> agreement ->
+// ncclAllGather of the [Qpad][topk] lists -> merge on every rank (collective: every rank makes the same call).  A rank whose own
+// arguments are out of range, whose allocations fail or whose enqueue fails says so in the agreement round: then NO rank posts the
+// large all-gather, the failing rank returns its own status and the others CHIP_ERR_SHARD_FAILED -- the communicator stays in step.
 int xchg_query_batch(Ctx *c, int64_t k, const float *queries, int32_t Q, int32_t topk, float *scores, int64_t *idx, bool fail_local)
 {
     Exchange *x = c->xchg;
     if (c->elem != 4) return CHIP_ERR_UNSUPPORTED;      // the storage type is the same on every rank (same append stream)
     if (test_fail_now(x)) fail_local = true;
     chip_topk_entry *mine = nullptr, *gathered = nullptr, *merged = nullptr;
-    int32_t Qpad = (Q + 127) / 128 * 128;
-    int rc = batch_exchange_buffers(c, x->world, Qpad, topk, &gathered, &merged, nullptr);
-    if (rc != CHIP_OK) return rc;
-    const size_t list_entries = (size_t)Qpad * topk;
+    int32_t Qpad = batch_qpad(Q);
+    int rc_local = CHIP_OK;
     if (!fail_local) {
-        rc = batch_local_enqueue(c, k, queries, Q, topk, &mine, &Qpad);
-        if (rc != CHIP_OK) return rc;
-    } else {   // the marked neutral list, built on the host (rare path): merged + 0 is free until the merge below
-        std::vector<chip_topk_entry> mark(list_entries);
-        for (chip_topk_entry &e : mark) { e.score = -INFINITY; e.idx = kFailedShardIdx; }
-        CHIP_HIP(c, hipMemcpyAsync(merged, mark.data(), sizeof(chip_topk_entry) * list_entries, hipMemcpyHostToDevice, c->s_scan));
-        CHIP_HIP(c, hipStreamSynchronize(c->s_scan));
-        mine = merged;
+        rc_local = test_oom_rank() == c->rank ? CHIP_ERR_OOM : batch_exchange_buffers(c, x->world, Qpad, topk, &gathered, &merged, nullptr);
+        if (rc_local == CHIP_OK) rc_local = batch_local_enqueue(c, k, queries, Q, topk, &mine, &Qpad);
+        if (rc_local != CHIP_OK) fail_local = true;
     }
+    bool all_ok = false;
+    const int arc = xchg_agree(c, !fail_local, &all_ok);
+    if (arc != CHIP_OK) return arc;
+    if (!all_ok) {
+        (void)hipStreamSynchronize(c->s_scan);          // whatever this rank's local pass enqueued has drained before the buffers are reused
+        return rc_local != CHIP_OK ? rc_local : CHIP_ERR_SHARD_FAILED;
+    }
+    const size_t list_entries = (size_t)Qpad * topk;
     CHIP_NCCL(c, rccl().AllGather(mine, gathered, sizeof(chip_topk_entry) * list_entries, ncclChar, x->comm, c->s_scan));
-    chip_topk_entry *out = fail_local ? gathered : merged;   // (a failed rank's `merged` is its send buffer; its result is an error anyway)
-    if (fail_local) { CHIP_HIP(c, hipStreamSynchronize(c->s_scan)); return CHIP_ERR_SHARD_FAILED; }
-    rc = batch_merge_lists(c, c->s_scan, gathered, x->world, Qpad, Q, topk, out);
+    const int rc = batch_merge_lists(c, c->s_scan, gathered, x->world, Qpad, Q, topk, merged);
     if (rc != CHIP_OK) return rc;
-    return batch_deliver(c, out, Q, topk, scores, idx);
+    return batch_deliver(c, merged, Q, topk, scores, idx);
 }
 
 int group_synchronize(Ctx *gc)

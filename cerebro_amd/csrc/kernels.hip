@@ -617,6 +617,11 @@ __device__ __forceinline__ void fused_tick_finish(const ScanArgs &a, char *smem,
     }
 }
 
+// -DCHIP_NO_ROWS_FORM leaves the row-batched kernel out of the build: it rests on how THIS hipcc maps amdgpu_num_vgpr to an ArchVGPR
+// budget (above), which `make verify` checks on the built code object -- a toolchain that allocates differently gets a library without
+// the rows form (every scan takes the one-row kernel, same bits, short prefixes ~10-25 % slower) instead of no library at all;
+// chip_get_info().scan_forms says which build this is.
+#ifndef CHIP_NO_ROWS_FORM
 template <typename T, int NQ, int R, bool NTL>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase / 2))) void db_scan_topk_rows(ScanArgs a)
 {
@@ -778,6 +783,7 @@ static int launch_scan_rows(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, 
     CHIP_HIP(c, hipGetLastError());
     return CHIP_OK;
 }
+#endif  // CHIP_NO_ROWS_FORM
 
 template <typename T, int NQ, int U, bool FULL, int NT, int R>
 static int launch_scan_k(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, size_t lds, int block)
@@ -821,6 +827,7 @@ static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, siz
     if constexpr (sizeof(T) == 4) {
         if (a.q64) return launch_scan_k<T, NQ, 4, true, 8, 1>(c, s, a, grid, lds, block);   // scan_q64() said so (float rows only)
     }
+#ifndef CHIP_NO_ROWS_FORM
     if (a.rows_form > 0) {   // scan_rows_form() said so: whole 4 KiB batches, R rows per wave in one continuous load stream
         const bool ntl = a.plain_loads == 0;
         if constexpr (NQ <= 3) {   // (four queries x R > 1 rows of accumulators do not fit the compiler's 80 registers: R = 1 only)
@@ -829,6 +836,7 @@ static int launch_scan_q(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, siz
         }
         return ntl ? launch_scan_rows<T, NQ, 1, true>(c, s, a, grid, lds, block) : launch_scan_rows<T, NQ, 1, false>(c, s, a, grid, lds, block);
     }
+#endif
     if (c->scan_variant != 1) {   // rows of whole 4 KiB / 2 KiB batches (one load per batch measured slower than the builtin path)
         const int64_t row_bytes = (int64_t)a.D * sizeof(T);
         if (row_bytes % 4096 == 0) return launch_scan_k<T, NQ, 4, true, 6, 1>(c, s, a, grid, lds, block);
@@ -877,8 +885,21 @@ bool scan_q64(const Ctx *c, int nq, bool long_scan)
 
 // Row-batched form of K1 (db_scan_topk_rows): R rows per wave in flight.  Returns R (1..3), or 0 for the one-row kernel.
 // CHIP_SCAN_ROWS forces R for every scan (1..3) or disables the form (-1).
+int scan_forms_built()
+{
+#ifdef CHIP_NO_ROWS_FORM
+    return CHIP_SCAN_FORM_ONE_ROW;
+#else
+    return CHIP_SCAN_FORM_ONE_ROW | CHIP_SCAN_FORM_ROWS;
+#endif
+}
+
 int scan_rows_form(const Ctx *c, int64_t n_rows, int nq, int grid, bool q64)
 {
+#ifdef CHIP_NO_ROWS_FORM
+    (void)c; (void)n_rows; (void)nq; (void)grid; (void)q64;
+    return 0;
+#endif
     if (q64 || c->scan_rows < 0 || c->scan_variant == 1 || (int64_t)c->D * c->elem % 4096 != 0) return 0;
     int block, bpc;
     scan_shape(c, nq, false, &block, &bpc);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CHIP_ABI_VERSION 4
+#define CHIP_ABI_VERSION 5
 
 /* ------------------------------------------------------------------------------------------ status codes */
 enum {
@@ -350,7 +350,14 @@ typedef struct {
                                    chip_comm_init_rank) did not return within CHIP_COMM_INIT_TIMEOUT_MS (default 120 s) and was
                                    abandoned on its helper thread; the ctx works (a group: over the copy exchange), but process
                                    teardown may block inside RCCL -- leave through _exit() once the work is done (ABI 4)      */
+    int32_t scan_forms;         /* CHIP_SCAN_FORM_* bits: which forms of the scan kernel this build of the library contains (ABI 5).
+                                   The row-batched form (short prefixes) depends on how the building hipcc allocates registers; a
+                                   build whose code-object check failed is made with -DCHIP_NO_ROWS_FORM and serves every scan with
+                                   the one-row kernel -- same results, short prefixes slower                                    */
 } chip_info;
+enum { CHIP_SCAN_FORM_ONE_ROW = 1, CHIP_SCAN_FORM_ROWS = 2 };
+/* the same bits without a ctx (what `make verify` and the build log ask) */
+int chip_build_scan_forms(void);
 enum { CHIP_EXCHANGE_NONE = 0, CHIP_EXCHANGE_RCCL = 1, CHIP_EXCHANGE_COPY = 2 };
 int chip_get_info(const chip_ctx *ctx, chip_info *info);
 
