@@ -19,7 +19,7 @@ ORC_SRCS   := $(wildcard oracle/*.c)
 
 all: lib oracle host testlibs verify
 lib: $(LIBDIR)/libcerebro_hip.so
-oracle: oracle/_build/liboracle.so oracle/_build/liboracle_eispack.so oracle/_build/liboracle_stats.so
+oracle: oracle/_build/liboracle.so oracle/_build/liboracle_eispack.so oracle/_build/liboracle_stats.so oracle/_build/liboracle_flops.so
 host: $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay $(LIBDIR)/minimal_loop_detector
 # test infrastructure that needs hipcc: the shared-memory stand-in for librccl (N ranks on one device, tests/test_fakerccl_gpu.py)
 testlibs: tests/fakerccl/_build/libfakerccl.so $(LIBDIR)/norows/libcerebro_hip.so
@@ -64,6 +64,12 @@ oracle/_build/liboracle_eispack.so: $(ORC_SRCS) oracle/cerebro_oracle.h
 oracle/_build/liboracle_stats.so: $(ORC_SRCS) oracle/cerebro_oracle.h
 	@mkdir -p oracle/_build
 	$(CC) $(ORCFLAGS) -DORC_LU_TIE_STATS -shared $(ORC_SRCS) -o $@ -lm
+
+# The same oracle counting the fp64 operations the PnP solver executes, per stage (test infrastructure: tests/test_oracle_flops.py pins
+# the count, bench.py prices the PnP kernels' fp64-vector roofline from it -- VERDICT r4 next 1a).
+oracle/_build/liboracle_flops.so: $(ORC_SRCS) oracle/cerebro_oracle.h
+	@mkdir -p oracle/_build
+	$(CC) $(ORCFLAGS) -DORC_FLOP_COUNT -shared $(ORC_SRCS) -o $@ -lm
 
 # ---- plain-C-ABI example (the INTEGRATION.md call sequence without ROS / Eigen) ----
 $(LIBDIR)/minimal_loop_detector: examples/minimal_loop_detector.cc include/cerebro_hip.h $(LIBDIR)/libcerebro_hip.so

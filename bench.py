@@ -167,6 +167,87 @@ def cpu_baseline_all_cores(sample_cols: int, budget_s: float):
     return n * sample_cols / dt, n, dt, nthreads
 
 
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: 256 CUs x 64 lanes x 2 flop x 2.4 GHz (v_fma_f64 at full rate)
+
+
+def pnp_roofline(hyp_per_s: float, batch8_hyp_per_s: float):
+    """SURVEY 8d prices the PnP kernels against the fp64 VECTOR peak.  Numerator: fp64 operations per hypothesis COUNTED from the
+    solver (profiles/pnp_flops.json: an oracle build with -DORC_FLOP_COUNT over this leg's scene, scripts/count_pnp_flops.py) x
+    hypotheses/s of the whole call (both kernels + host selection).  Context, from committed measurements: the peak this part
+    sustains (profiles/r05_fp64_peak.txt: dense v_fma_f64 / the mul + add form a -ffp-contract=off build issues) and how busy the
+    vector pipe is while the kernels run (profiles/pnp_pmc.json: SQ_INSTS_VALU x 4 cycles / (SIMDs x kernel cycles))."""
+    fl = pm = pk = None
+    try:
+        fl = json.loads((ROOT / "profiles" / "pnp_flops.json").read_text())
+    except Exception:
+        pass
+    try:
+        pm = json.loads((ROOT / "profiles" / "pnp_pmc.json").read_text())
+    except Exception:
+        pass
+    try:
+        pk = json.loads([l for l in (ROOT / "profiles" / "r05_fp64_peak.txt").read_text().splitlines() if l.startswith("{")][-1])
+    except Exception:
+        pass
+    fph = fl["flops_per_hypothesis"] if fl else None
+    r = {"bound": "fp64-vector", "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+         "achieved": hyp_per_s * fph / 1e12 if fph else None, "frac": hyp_per_s * fph / 1e12 / FP64_VECTOR_PEAK_TFLOPS if fph else None,
+         "achieved_batch8": batch8_hyp_per_s * fph / 1e12 if fph else None,
+         "frac_batch8": batch8_hyp_per_s * fph / 1e12 / FP64_VECTOR_PEAK_TFLOPS if fph else None,
+         "flops_per_hypothesis": fph,
+         "flops_per_hypothesis_dense_elimination": fl["flops_per_hypothesis_dense_elimination"] if fl else None,
+         "flops_source": "profiles/pnp_flops.json: counted from the solver (oracle build -DORC_FLOP_COUNT over this scene), zero-multiplier rows of the "
+                         "elimination skipped as the algorithm runs; _dense_elimination = without the skip (what the register-resident LU executes)",
+         "traffic": None,
+         "why_far_below_peak": "dependent fp64 chains (LU pivot column, Householder / Francis QR steps on a 27 x 27 matrix): one wave per hypothesis "
+                               "in the eigen kernel, a lone wave issues one VALU instruction per ~8 cycles; <= 27 of 64 lanes active in the QR "
+                               "phases; mul + add instead of fma (-ffp-contract=off, bit parity with the CPU path) halves the usable peak"}
+    if pk:
+        r["peak_measured_fma"] = pk.get("fp64_fma_tflops")
+        r["peak_measured_mul_add"] = pk.get("fp64_mul_add_tflops")
+        r["peak_measured_source"] = "profiles/r05_fp64_peak.txt (scripts/ubench/fp64_peak.hip: 8 independent chains per lane, 8 waves per SIMD)"
+    if pm:
+        r["valu_busy"] = pm.get("valu_busy")
+        r["valu_busy_source"] = pm.get("source")
+        r["kernels"] = pm.get("kernels")
+    return r
+
+
+def icp_leg(chip):
+    """Row N2: Umeyama-ICP-RANSAC (StaticTheiaPoseCompute::P3P_ICP's RANSAC branch, DlsPnpWithRansac.cpp:65-121) on 512 3-D/3-D
+    correspondences: reference mode (<= 50 iterations), 1000 and 8000 fixed hypotheses, and the three-way pose of one loop candidate
+    (PNP a->b + PNP b->a as one batched call with the ICP running underneath, Cerebro.cpp:1518,1572,1629)."""
+    from cerebro_amd import capi
+    from cerebro_amd.synth import make_scene, make_icp_scene
+    A, B = make_icp_scene(N=512, outlier_frac=0.3, noise=0.01, seed=7)[:2]
+    out = {"metric": "Umeyama-ICP-RANSAC hypotheses/sec (512 correspondences, 10-point samples, L2 error 0.1)", "unit": "hypotheses/s", "dtype": "f64"}
+    for H, key in ((0, "reference_mode_ms_per_call"), (1000, "ms_per_call_1000_hyp"), (8000, "ms_per_call_8000_hyp")):
+        p = capi.default_icp_params(); p.n_hypotheses = H; p.seed = 3
+        for _ in range(3):
+            chip.icp_ransac(A, B, p)
+        n = 50
+        t0 = time.perf_counter()
+        for i in range(n):
+            p.seed = 3 + i
+            chip.icp_ransac(A, B, p)
+        out[key] = 1e3 * (time.perf_counter() - t0) / n
+    out["value"] = 8000 / (out["ms_per_call_8000_hyp"] / 1e3)
+    # three-way pose of one loop candidate: the ICP is enqueued first and runs underneath the batched PnP pair
+    scenes = [make_scene(N=512, outlier_frac=0.3, noise_px=0.5, seed=4242 + i)[:2] for i in range(2)]
+    pp = capi.default_ransac_params(); pp.n_hypotheses = 0
+    pi = capi.default_icp_params(); pi.n_hypotheses = 0
+    ts = []
+    for i in range(53):
+        t = time.perf_counter()
+        chip.icp_ransac_enqueue(A, B, pi)
+        chip.pnp_ransac_batch(scenes, pp, seeds=[300 + 2 * i, 301 + 2 * i])
+        chip.icp_ransac_collect(A.shape[0])
+        ts.append(time.perf_counter() - t)
+    out["three_way_pose_ms"] = 1e3 * float(np.mean(ts[3:]))
+    out["three_way_pose"] = "PNP(a->b) + PNP(b->a) (one batched call, <= 50 iterations each) with P3P_ICP's RANSAC underneath (enqueue / collect)"
+    return out
+
+
 def pnp_leg(chip, cpu_budget_s: float):
     """BASELINE config 3: 512 correspondences x 1000 hypotheses of 15 samples (DlsPnpWithRansac), whole call through
     chip_pnp_ransac (includes the 20 KB H2D of the correspondences and the host-side K7 selection)."""
@@ -220,9 +301,8 @@ def pnp_leg(chip, cpu_budget_s: float):
            "reference_mode_pair_ms_per_call": 1e3 * float(np.mean(pair_times)), "reference_mode_pair_ms_per_call_median": 1e3 * float(np.median(pair_times)),
            "reference_mode_pair": "the two role-swapped estimations of one loop candidate (Cerebro.cpp:1518,1572) as ONE batched call, <= 50 iterations each",
            "batch8_hypotheses_per_s": breps * 8 * 1000 / dt_b, "batch8_ms_per_call": 1e3 * dt_b / breps,
-           "dtype": "f64", "n_models_last": r["summary"]["n_models"],
-           "roofline": {"bound": "latency (fp64 VALU + LDS); neither HBM nor MFMA", "flops_per_hypothesis_est": 1.3e6,
-                        "achieved_gflops_est": reps * 1000 * 1.3e6 / dt / 1e9, "note": "see DESIGN.md 5"}}
+           "dtype": "f64", "n_models_last": r["summary"]["n_models"]}
+    out["roofline"] = pnp_roofline(out["value"], out["batch8_hypotheses_per_s"])
     if cpu_budget_s > 0:
         sys.path.insert(0, str(ROOT / "tests"))
         import oracle_lib   # cpu_baseline leg only
@@ -826,8 +906,33 @@ def main():
                                                  "roofline": out["roofline"]}
         if n_gpus == 1 and world == 1 and not args.no_pnp:
             out["pnp"] = pnp_leg(chip, min(args.cpu_budget, 5.0))
+        if n_gpus == 1 and world == 1 and not args.no_pnp:
+            out["icp"] = icp_leg(chip)
         if n_gpus == 1 and world == 1 and not args.no_batch and args.storage == "f32":
             out["batch"] = batch_leg(chip, args.rows)
+        # The driver's record keeps the top-level contract keys plus the SCALAR entries of `config` and `roofline`; the other legs
+        # (second half of BASELINE's metric, BASELINE configs 2 / 3) are repeated there as flat scalars so that they survive.
+        def flat(dst, prefix, src, keys):
+            for k in keys:
+                v = src
+                for part in k.split("."):
+                    v = v.get(part) if isinstance(v, dict) else None
+                if isinstance(v, (int, float)) and not isinstance(v, bool):
+                    dst[prefix + k.replace(".", "_")] = v
+        if "pnp" in out:
+            flat(out["config"], "pnp_", out["pnp"], ["value", "ms_per_call_1000_hyp", "batch8_hypotheses_per_s", "reference_mode_ms_per_call",
+                                                     "reference_mode_pair_ms_per_call", "roofline.flops_per_hypothesis", "roofline.achieved",
+                                                     "roofline.frac", "roofline.frac_batch8", "roofline.peak", "roofline.peak_measured_mul_add",
+                                                     "roofline.valu_busy.pnp_build_solve", "roofline.valu_busy.pnp_eig_score", "cpu_baseline.value"])
+            out["config"]["pnp_hyp_per_s"] = out["config"].pop("pnp_value")
+        if "icp" in out:
+            flat(out["config"], "icp_", out["icp"], ["value", "reference_mode_ms_per_call", "ms_per_call_1000_hyp", "three_way_pose_ms"])
+        if "batch" in out:
+            flat(out["config"], "batch256_", out["batch"], ["value", "roofline.frac", "roofline.achieved"])
+        for name, leg in (out.get("sizes") or {}).items():
+            if name != fmt_rows(args.rows):
+                flat(out["config"], f"size_{name}_", leg, ["value", "ms_per_step", "sync_tick_us", "roofline.frac_kernel", "roofline.frac_step",
+                                                           "roofline.isolated_kernel_ms"])
         if n_gpus == 1 and world == 1 and args.cpu_budget > 0:
             eig = eigen_baseline(args.cpu_sample, min(args.cpu_budget, 10.0))
             cols_per_s, n, dt = cpu_baseline(args.cpu_sample, args.cpu_budget * 2 / 3, "eigen")

@@ -2,11 +2,17 @@
 // StaticTheiaPoseCompute::P3P_ICP (/root/reference/src/DlsPnpWithRansac.cpp:65-121), i.e. theia::Ransac over the
 // AlignPointCloudsUmeyamaWithRansac estimator (src/DlsPnpWithRansac.h:104-166).
 //
-//   icp_hyp_score : one wave per hypothesis.  Lane 0 draws the 10-point sample (same counter-based sampler as PnP);
-//                   the 3x3 Umeyama solve (means, covariance, fixed-sweep Jacobi SVD, S22 sign, scale) is ~600 flops
-//                   and is computed redundantly by every lane (wave-uniform registers, no LDS traffic, no divergence);
-//                   accept iff min(s, 1/s) > 0.9 (:137); then the L2 error of all N correspondences, MLE cost in the
-//                   fixed lane-strided + butterfly order, inlier words by __ballot.
+//   icp_models    : ONE LANE per hypothesis (64 hypotheses per wave; round 5 -- rounds 1-4 ran one wave per hypothesis with all 64
+//                   lanes computing the same 3x3 solve).  The lane draws its 10-point sample (the same counter-based partial
+//                   Fisher-Yates as PnP, here with the sparse permutation map in the lane's own registers: step i's entry is
+//                   (j_i, value), a lookup takes the LAST earlier entry with that key), gathers the sample points, and runs
+//                   the Umeyama solve (means, covariance, fixed-sweep Jacobi SVD, S22 sign, scale: ~600 flops + 24 rotations
+//                   with a division and two square roots each); accept iff min(s, 1/s) > 0.9 (:137); writes b_T_a + valid.
+//   icp_score     : one wave per hypothesis: the L2 error of all N correspondences under that hypothesis's model, MLE cost in
+//                   the fixed lane-strided + butterfly order, inlier words by __ballot.
+//                   Both kernels keep the operation order of oracle/icp_ransac.c, so poses, costs and masks are the bits of
+//                   rounds 1-4 (tests/test_icp_gpu.py); the model work per call drops 64-fold (8000 hypotheses: 168 -> see
+//                   profiles/r05_icp.txt), the reference-mode call (<= 50 hypotheses = one wave of icp_models) keeps its latency.
 //   K7 on the host: ransac_common.h (shared with PnP).
 // fp64, -ffp-contract=off, same operation order as oracle/icp_ransac.c => bit-identical poses and masks.
 #include "ransac_common.h"
@@ -28,6 +34,10 @@ struct IcpArgs {
     int32_t *nin;      // [H]
     int32_t *valid;    // [H]
     unsigned long long *mask;  // [H][mask_words]
+    int32_t H;
+    uint64_t magic[kSampleMax];   // floor(2^64 / (N - i)): the sampler's 64-bit modulo as a multiply-high (the divisors depend on i only)
+    double *T_dev;     // [H][16] device copy of the models: icp_score reads it (T_out is pinned HOST memory)
+    int32_t *valid_dev;// [H]
 };
 
 constexpr int kJacobiSweeps = 8;
@@ -63,37 +73,69 @@ constexpr int kJacobiSweeps = 8;
         for (int r = 0; r < 3; r++) { const double tv = V[r][i]; V[r][i] = V[r][j]; V[r][j] = tv; } \
     } while (0)
 
-__global__ __launch_bounds__(64) void icp_hyp_score(IcpArgs a)
+// Sample of hypothesis `hyp` by ONE lane: theia::RandomSampler's partial Fisher-Yates over a virtual identity permutation
+// (oracle/pnp_ransac.c orc_ransac_sample; ransac_common.h has the wave-cooperative form).  Step i swaps positions i and
+// j_i = i + draw_i % (N - i).  Position i is final after step i and never read again, so only the j-targets need remembering:
+// entry e = (key j_e, the value step e wrote there); the current value of a position is that of the LAST earlier entry with
+// that key, else the position itself.  Fully unrolled, so keys / values stay in registers.
+// x % d by Barrett reduction with the host's m = floor(2^64 / d): q = mulhi(x, m) underestimates x / d by at most 2, so the
+// remainder needs at most two corrections -- the exact x % d of the oracle (hipcc's generic 64-bit division is ~150 instructions
+// per draw and lane; the divisors N - i are the same for every hypothesis).
+__device__ __forceinline__ uint64_t mod_magic(uint64_t x, uint64_t d, uint64_t m)
 {
-    __shared__ int smp[kSampleMax];
-    __shared__ double sa[kSampleMax * 3], sb[kSampleMax * 3];
-    const int lane = threadIdx.x;
-    const int hyp = blockIdx.x;
-    const int n = a.S;
-    {
-        const int sv = ransac_sample_wave(a.seed, hyp, a.N, n, lane);
-        if (lane < n) smp[lane] = sv;
-    }
-    __syncthreads();
-    if (lane < n) {
-        const int s = smp[lane];
-        for (int k = 0; k < 3; k++) { sa[3 * lane + k] = a.A[3 * s + k]; sb[3 * lane + k] = a.B[3 * s + k]; }
-    }
-    __syncthreads();
+    uint64_t r = x - __umul64hi(x, m) * d;
+    if (r >= d) r -= d;
+    if (r >= d) r -= d;
+    return r;
+}
 
-    // ---- Umeyama on the sample (every lane computes the same thing) ----
+__device__ __forceinline__ void ransac_sample_lane(uint64_t seed, int hyp, int N, int S, const uint64_t *magic, int smp[kSampleMax])
+{
+    int key[kSampleMax], val[kSampleMax];
+#pragma unroll
+    for (int i = 0; i < kSampleMax; i++) {
+        key[i] = -1; val[i] = 0; smp[i] = 0;
+        if (i < S) {
+            const uint64_t x = rng_draw(seed, (uint32_t)hyp, (uint32_t)i);
+            const int j = i + (int)mod_magic(x, (uint64_t)(N - i), magic[i]);
+            int vi = i, vj = j;
+#pragma unroll
+            for (int e = 0; e < i; e++) {
+                if (key[e] == i) vi = val[e];
+                if (key[e] == j) vj = val[e];
+            }
+            smp[i] = vj;          // idx[i] <- old idx[j]
+            key[i] = j;           // idx[j] <- old idx[i]   (j == i: vj == vi, a no-op as in the reference)
+            val[i] = vi;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void icp_models(IcpArgs a)
+{
+    const int hyp = blockIdx.x * 64 + threadIdx.x;
+    if (hyp >= a.H) return;
+    const int n = a.S;
+    int smp[kSampleMax];
+    ransac_sample_lane(a.seed, hyp, a.N, n, a.magic, smp);
+
+    // ---- Umeyama on the sample ----
     double ma[3] = {0.0, 0.0, 0.0}, mb[3] = {0.0, 0.0, 0.0};
-    for (int i = 0; i < n; i++)
-        for (int k = 0; k < 3; k++) { ma[k] = ma[k] + sa[3 * i + k]; mb[k] = mb[k] + sb[3 * i + k]; }
+#pragma unroll
+    for (int i = 0; i < kSampleMax; i++)
+        if (i < n)
+            for (int k = 0; k < 3; k++) { ma[k] = ma[k] + a.A[3 * smp[i] + k]; mb[k] = mb[k] + a.B[3 * smp[i] + k]; }
     for (int k = 0; k < 3; k++) { ma[k] = ma[k] / (double)n; mb[k] = mb[k] / (double)n; }
     double Sg[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}}, var_a = 0.0;
-    for (int i = 0; i < n; i++) {
-        double da[3], db[3];
-        for (int k = 0; k < 3; k++) { da[k] = sa[3 * i + k] - ma[k]; db[k] = sb[3 * i + k] - mb[k]; }
-        var_a = var_a + ((da[0] * da[0] + da[1] * da[1]) + da[2] * da[2]);
-        for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 3; c++) Sg[r][c] = Sg[r][c] + db[r] * da[c];
-    }
+#pragma unroll
+    for (int i = 0; i < kSampleMax; i++)
+        if (i < n) {
+            double da[3], db[3];
+            for (int k = 0; k < 3; k++) { da[k] = a.A[3 * smp[i] + k] - ma[k]; db[k] = a.B[3 * smp[i] + k] - mb[k]; }
+            var_a = var_a + ((da[0] * da[0] + da[1] * da[1]) + da[2] * da[2]);
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) Sg[r][c] = Sg[r][c] + db[r] * da[c];
+        }
     var_a = var_a / (double)n;
     for (int r = 0; r < 3; r++)
         for (int c = 0; c < 3; c++) Sg[r][c] = Sg[r][c] / (double)n;
@@ -118,6 +160,8 @@ __global__ __launch_bounds__(64) void icp_hyp_score(IcpArgs a)
     for (int k = 0; k < 3; k++) sig[k] = sqrt(w[k] > 0.0 ? w[k] : 0.0);
     bool ok = (sig[1] > 1e-6 * sig[0]) && (sig[0] > 0.0);
     double R[9], t[3], scale = 0.0;
+    for (int e = 0; e < 9; e++) R[e] = 0.0;
+    t[0] = t[1] = t[2] = 0.0;
     if (ok) {
         for (int k = 0; k < 2; k++)
             for (int r = 0; r < 3; r++) U[r][k] = ((Sg[r][0] * V[0][k] + Sg[r][1] * V[1][k]) + Sg[r][2] * V[2][k]) / sig[k];
@@ -139,17 +183,23 @@ __global__ __launch_bounds__(64) void icp_hyp_score(IcpArgs a)
         const double inv = 1.0 / scale;
         ok = (scale < inv ? scale : inv) > 0.9;   // DlsPnpWithRansac.h:137
     }
-    if (!ok) {
-        if (lane == 0) { a.valid[hyp] = 0; a.nin[hyp] = 0; a.cost[hyp] = INFINITY; }
-        return;
-    }
+    a.valid_dev[hyp] = ok ? 1 : 0;
+    if (!ok) { a.valid[hyp] = 0; a.nin[hyp] = 0; a.cost[hyp] = INFINITY; return; }
     double T[16];
     T[0] = R[0]; T[1] = R[3]; T[2] = R[6]; T[3] = 0.0;
     T[4] = R[1]; T[5] = R[4]; T[6] = R[7]; T[7] = 0.0;
     T[8] = R[2]; T[9] = R[5]; T[10] = R[8]; T[11] = 0.0;
     T[12] = t[0]; T[13] = t[1]; T[14] = t[2]; T[15] = 1.0;
-    if (lane == 0)
-        for (int e = 0; e < 16; e++) a.T_out[hyp * 16 + e] = T[e];
+    for (int e = 0; e < 16; e++) { a.T_dev[(size_t)hyp * 16 + e] = T[e]; a.T_out[(size_t)hyp * 16 + e] = T[e]; }
+}
+
+__global__ __launch_bounds__(64) void icp_score(IcpArgs a)
+{
+    const int lane = threadIdx.x;
+    const int hyp = blockIdx.x;
+    if (!a.valid_dev[hyp]) return;       // wave-uniform; icp_models has written valid / nin / cost of a rejected hypothesis
+    double T[16];
+    for (int e = 0; e < 16; e++) T[e] = a.T_dev[(size_t)hyp * 16 + e];
     // ---- Error (L2, DlsPnpWithRansac.h:152-164) over all N + MLE cost ----
     double acc = 0.0;
     int cnt = 0;
@@ -180,8 +230,8 @@ __global__ __launch_bounds__(64) void icp_hyp_score(IcpArgs a)
 }
 
 struct IcpState {
-    double *A = nullptr, *B = nullptr, *T_out = nullptr, *cost = nullptr;
-    int32_t *nin = nullptr, *valid = nullptr;
+    double *A = nullptr, *B = nullptr, *T_out = nullptr, *cost = nullptr, *T_dev = nullptr;
+    int32_t *nin = nullptr, *valid = nullptr, *valid_dev = nullptr;
     unsigned long long *mask = nullptr;
     int32_t cap_N = 0, cap_H = 0, cap_words = 0;
     double *h_cost = nullptr, *h_T = nullptr;
@@ -195,7 +245,7 @@ struct IcpState {
 
 static void icp_free(IcpState *st)
 {
-    (void)hipFree(st->A); (void)hipFree(st->B);   // T_out/cost/nin/valid/mask are device views of the pinned host buffers below
+    (void)hipFree(st->A); (void)hipFree(st->B); (void)hipFree(st->T_dev); (void)hipFree(st->valid_dev);   // T_out/cost/nin/valid/mask are device views of the pinned host buffers below
     (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid); (void)hipHostFree(st->h_mask);
     const hipStream_t keep = st->stream;   // buffers are regrown, the stream lives as long as the ctx
     *st = IcpState();
@@ -220,6 +270,8 @@ static int icp_reserve(Ctx *c, IcpState *st, int N, int H)
     icp_free(st);
     CHIP_HIP(c, hipMalloc(&st->A, sizeof(double) * 3 * (size_t)nN));
     CHIP_HIP(c, hipMalloc(&st->B, sizeof(double) * 3 * (size_t)nN));
+    CHIP_HIP(c, hipMalloc(&st->T_dev, sizeof(double) * 16 * (size_t)nH));
+    CHIP_HIP(c, hipMalloc(&st->valid_dev, sizeof(int32_t) * (size_t)nH));
     // per-hypothesis results go straight to pinned, device-mapped host memory (as in pnp.hip): no D2H copies, one sync per call
     CHIP_HIP(c, hipHostMalloc(&st->h_cost, sizeof(double) * (size_t)nH, hipHostMallocDefault));
     CHIP_HIP(c, hipHostMalloc(&st->h_T, sizeof(double) * 16 * (size_t)nH, hipHostMallocDefault));
@@ -271,7 +323,14 @@ static int icp_enqueue_locked(chip_ctx *c, const double *A, const double *B, int
     IcpArgs a;
     a.A = st->A; a.B = st->B; a.N = N; a.S = S; a.seed = p->seed; a.thresh = p->error_thresh; a.use_mle = p->use_mle;
     a.mask_words = words; a.T_out = st->T_out; a.cost = st->cost; a.nin = st->nin; a.valid = st->valid; a.mask = st->mask;
-    hipLaunchKernelGGL(icp_hyp_score, dim3(H), dim3(64), 0, s, a);
+    a.H = H; a.T_dev = st->T_dev; a.valid_dev = st->valid_dev;
+    for (int i = 0; i < kSampleMax; i++) {   // N - i >= 20 - 16 > 1 (icp_check_args), so the quotient fits 64 bits
+        const uint64_t d = (uint64_t)(N - (i < S ? i : 0));
+        a.magic[i] = (uint64_t)((((unsigned __int128)1) << 64) / d);
+    }
+    hipLaunchKernelGGL(icp_models, dim3((H + 63) / 64), dim3(64), 0, s, a);    // lane = hypothesis
+    CHIP_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(icp_score, dim3(H), dim3(64), 0, s, a);                 // wave = hypothesis
     CHIP_HIP(c, hipGetLastError());
     st->pending = true;
     st->pend_N = N; st->pend_H = H; st->pend_params = *p;

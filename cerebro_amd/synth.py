@@ -27,3 +27,15 @@ def make_scene(N=512, outlier_frac=0.3, noise_px=0.5, seed=4242, focal=458.0):
     uv[out] = np.stack([rng.uniform(-0.8, 0.8, out.sum()), rng.uniform(-0.5, 0.5, out.sum())], axis=1)
     T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
     return Xa, uv, T, ~out
+
+
+def make_icp_scene(N=300, outlier_frac=0.2, noise=0.02, seed=1):
+    """3-D / 3-D correspondences for the Umeyama-ICP-RANSAC row (P3P_ICP, DlsPnpWithRansac.cpp:15-16: uv_X, uvd_Y): the PnP scene's
+    points in frame a, the same points in frame b with Gaussian noise, a fraction displaced by up to 3 m."""
+    X, uv, T, inl = make_scene(N=N, outlier_frac=0.0, noise_px=0.0, seed=seed)
+    rng = np.random.default_rng(seed + 1000)
+    A = X
+    B = X @ T[:3, :3].T + T[:3, 3] + rng.standard_normal((N, 3)) * noise
+    out = rng.random(N) < outlier_frac
+    B[out] += rng.uniform(-3, 3, (out.sum(), 3))
+    return A, B, T, ~out

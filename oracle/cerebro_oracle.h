@@ -181,6 +181,13 @@ void   orc_icp_params_default(orc_ransac_params *p);
 int    orc_icp_ransac(const double *A, const double *B, int32_t N, const orc_ransac_params *p,
                       double T[16], float *confidence, uint8_t *mask, orc_ransac_summary *summary);
 
+/* -DORC_FLOP_COUNT builds only (oracle/_build/liboracle_flops.so): fp64 operations executed by the PnP solver on the calling thread
+ * since the last reset, per stage: 0 cost matrix + cubics, 1 Macaulay elimination (zero multipliers skipped, as the algorithm
+ * runs), 2 back-substitution + action matrix, 3 Hessenberg reduction + accumulation, 4 Francis QR, 5 real eigenvectors +
+ * back-transform, 6 pose + cheirality, 7 reprojection scoring.  *dense_lu: stage 1 without the zero-multiplier skip. */
+#define ORC_FLOP_STAGES 8
+void orc_flop_counts(long out[ORC_FLOP_STAGES], long *dense_lu, int reset);
+
 /* ================================================================== top-k candidate policies (policies.c, row N4) */
 typedef struct { int64_t idx_curr, idx_prev; double score; } orc_policy_loop;
 typedef struct { int64_t last_l, l_last_added; } orc_naive_state;                      /* zero-initialise */

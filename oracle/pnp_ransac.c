@@ -35,6 +35,28 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* ================================================================ operation counter (test infrastructure) */
+/* -DORC_FLOP_COUNT (oracle/_build/liboracle_flops.so only): the fp64 operations this solver EXECUTES per stage,
+ * counted where they happen -- every +, -, *, / and sqrt is one operation; compares, fabs, sign flips, frexp/ldexp scalings,
+ * integer work and data movement are not counted.  bench.py prices the PnP kernels' fp64-vector roofline from this count
+ * (tests/test_oracle_flops.py pins it) instead of an estimate.  Stage 1 counts the elimination as the reference algorithm runs
+ * it (rows with a zero multiplier skipped); orc_flop_dense_lu is the same elimination without the skip (what a dense update does). */
+#ifdef ORC_FLOP_COUNT
+static __thread long orc_flops[ORC_FLOP_STAGES];
+static __thread long orc_flop_dense_lu;
+long orc_panel_rows_total, orc_panel_rows_allzero;   /* (remaining row, 4-column panel) pairs of the elimination / those whose 4 multipliers are all 0 */
+#define FL(stage, n) (orc_flops[stage] += (long)(n))
+void orc_flop_counts(long out[ORC_FLOP_STAGES], long *dense_lu, int reset)
+{
+    for (int i = 0; i < ORC_FLOP_STAGES; i++) { if (out) out[i] = orc_flops[i]; if (reset) orc_flops[i] = 0; }
+    if (dense_lu) *dense_lu = orc_flop_dense_lu;
+    if (reset) orc_flop_dense_lu = 0;
+}
+#else
+#define FL(stage, n) ((void)0)
+#endif
+enum { FS_CUBICS = 0, FS_LU = 1, FS_ACTION = 2, FS_HESS = 3, FS_QR = 4, FS_EIGVEC = 5, FS_POSE = 6, FS_SCORE = 7 };
+
 /* ================================================================ counter-based RNG + sampler */
 uint64_t orc_rng_draw(uint64_t seed, uint32_t hyp, uint32_t draw)
 {
@@ -77,6 +99,7 @@ double orc_reproj_error(const double *T, const double *X, const double *uv)
     double y = ((T[1] * X[0] + T[5] * X[1]) + T[9] * X[2]) + T[13];
     double z = ((T[2] * X[0] + T[6] * X[1]) + T[10] * X[2]) + T[14];
     double xn = x / z, yn = y / z;
+    FL(FS_SCORE, 18 + 2 + 3);
     return fabs(xn - uv[0]) + fabs(yn - uv[1]);
 }
 
@@ -97,10 +120,12 @@ void orc_score_model(const double *T, const double *X, const double *uv, int32_t
             if (mask) mask[i] = (uint8_t)in;
             cnt += in;
             acc[L] = acc[L] + (in ? r : thresh);
+            FL(FS_SCORE, 1);
         }
     for (int m = 32; m >= 1; m >>= 1) {
         double nxt[64];
         for (int L = 0; L < 64; L++) nxt[L] = acc[L] + acc[L ^ m];
+        FL(FS_SCORE, 1);     /* one wave-wide add per butterfly level (64 lanes, one useful result) */
         memcpy(acc, nxt, sizeof acc);
     }
     *n_inliers = cnt;
@@ -176,11 +201,13 @@ void orc_dls_cubics(const double *X, const double *uv, int32_t n, double Tfac[27
         double u = uv[2 * i], v = uv[2 * i + 1];
         double nrm = sqrt((u * u + v * v) + 1.0);
         zb[i][0] = u / nrm; zb[i][1] = v / nrm; zb[i][2] = 1.0 / nrm;
+        FL(FS_CUBICS, 4 + 1 + 3);
     }
     /* H = (n I - sum z z^T)^-1 */
     for (int i = 0; i < n; i++)
         for (int a = 0; a < 3; a++)
             for (int b = 0; b < 3; b++) Szz[a][b] = Szz[a][b] + zb[i][a] * zb[i][b];
+    FL(FS_CUBICS, 18L * n + 9 /* n I - Szz */ + 27 /* cofactors */ + 5 /* det */ + 9 /* H */);
     double m[3][3], H[3][3];
     for (int a = 0; a < 3; a++)
         for (int b = 0; b < 3; b++) m[a][b] = (a == b ? (double)n : 0.0) - Szz[a][b];
@@ -205,9 +232,10 @@ void orc_dls_cubics(const double *X, const double *uv, int32_t n, double Tfac[27
             for (int b = 0; b < 3; b++) {
                 double e = zb[i][a] * zb[i][b] - (a == b ? 1.0 : 0.0);
                 for (int c = 0; c < 3; c++) W[a][3 * b + c] = W[a][3 * b + c] + e * X[3 * i + c];
+                FL(FS_CUBICS, 2 + 6);
             }
     for (int a = 0; a < 3; a++)
-        for (int j = 0; j < 9; j++) Tfac[9 * a + j] = (H[a][0] * W[0][j] + H[a][1] * W[1][j]) + H[a][2] * W[2][j];
+        for (int j = 0; j < 9; j++) { Tfac[9 * a + j] = (H[a][0] * W[0][j] + H[a][1] * W[1][j]) + H[a][2] * W[2][j]; FL(FS_CUBICS, 5); }
     /* M9 = sum (L+T)^T (I - z z^T) (L+T) */
     for (int i = 0; i < n; i++) {
         double A[3][9], B[3][9], P[3][3];
@@ -220,6 +248,7 @@ void orc_dls_cubics(const double *X, const double *uv, int32_t n, double Tfac[27
             for (int j = 0; j < 9; j++) B[a][j] = (P[a][0] * A[0][j] + P[a][1] * A[1][j]) + P[a][2] * A[2][j];
         for (int j = 0; j < 9; j++)
             for (int k = 0; k < 9; k++) M9[j][k] = M9[j][k] + ((A[0][j] * B[0][k] + A[1][j] * B[1][k]) + A[2][j] * B[2][k]);
+        FL(FS_CUBICS, 9 * 2 /* P */ + 27 /* A */ + 27 * 5 /* B */ + 81 * 6 /* M9 */);
     }
     /* G = Q^T M9 Q;  J'(s) = m10^T G m10 (quartic) */
     double MQ[9][10], G[10][10];
@@ -227,12 +256,14 @@ void orc_dls_cubics(const double *X, const double *uv, int32_t n, double Tfac[27
         for (int q = 0; q < 10; q++) {
             double s = 0.0;
             for (int k = 0; k < 9; k++) s = s + M9[j][k] * QMAT[k][q];
+            FL(FS_CUBICS, 18);
             MQ[j][q] = s;
         }
     for (int l = 0; l < 10; l++)
         for (int q = 0; q < 10; q++) {
             double s = 0.0;
             for (int j = 0; j < 9; j++) s = s + QMAT[j][l] * MQ[j][q];
+            FL(FS_CUBICS, 18);
             G[l][q] = s;
         }
     double c4[35];
@@ -241,6 +272,7 @@ void orc_dls_cubics(const double *X, const double *uv, int32_t n, double Tfac[27
         for (int q = 0; q < 10; q++) {
             int k = idx_le(M10[l][0] + M10[q][0], M10[l][1] + M10[q][1], M10[l][2] + M10[q][2], 4);
             c4[k] = c4[k] + G[l][q];
+            FL(FS_CUBICS, 1);
         }
     /* f_k = dJ'/ds_k */
     for (int a = 0; a <= 3; a++)
@@ -250,6 +282,7 @@ void orc_dls_cubics(const double *X, const double *uv, int32_t n, double Tfac[27
                 f[0][k] = (double)(a + 1) * c4[idx_le(a + 1, b, c, 4)];
                 f[1][k] = (double)(b + 1) * c4[idx_le(a, b + 1, c, 4)];
                 f[2][k] = (double)(c + 1) * c4[idx_le(a, b, c + 1, 4)];
+                FL(FS_CUBICS, 3);
             }
 }
 
@@ -281,8 +314,14 @@ int orc_dls_action_matrix(const double f[3][20], const double u[4], double S[27 
                             if (col >= 27) E[row * NC + (col - 27)] = v; else E[row * NC + (93 + col)] = v;
                         }
             }
+#ifdef ORC_FLOP_COUNT
+    unsigned char allz[93];
+#endif
     /* forward elimination with partial (row) pivoting; ties -> smallest row index */
     for (int k = 0; k < NR; k++) {
+#ifdef ORC_FLOP_COUNT
+        if (k % 4 == 0) memset(allz, 1, sizeof allz);
+#endif
         int p = k;
         double best = fabs(E[k * NC + k]);
         for (int i = k + 1; i < NR; i++) {
@@ -309,12 +348,23 @@ int orc_dls_action_matrix(const double f[3][20], const double u[4], double S[27 
         if (!(best > 0.0)) { free(E); return -1; }
         if (p != k)
             for (int j = 0; j < NC; j++) { double t = E[k * NC + j]; E[k * NC + j] = E[p * NC + j]; E[p * NC + j] = t; }
+#ifdef ORC_FLOP_COUNT
+        if (p != k) { unsigned char t = allz[k]; allz[k] = allz[p]; allz[p] = t; }
+#endif
         double piv = E[k * NC + k];
         for (int i = k + 1; i < NR; i++) {
             double l = E[i * NC + k] / piv;
             E[i * NC + k] = l;
-            if (l != 0.0)
+            FL(FS_LU, 1);
+#ifdef ORC_FLOP_COUNT
+            orc_flop_dense_lu += 1 + 2L * (NC - k - 1);
+            if (l != 0.0) allz[i] = 0;
+            if (k % 4 == 3 || k == NR - 1) { orc_panel_rows_total++; orc_panel_rows_allzero += allz[i]; }
+#endif
+            if (l != 0.0) {
                 for (int j = k + 1; j < NC; j++) E[i * NC + j] = E[i * NC + j] - l * E[k * NC + j];
+                FL(FS_LU, 2L * (NC - k - 1));
+            }
         }
     }
     /* back-substitution for the last 27 unknowns only (boundary monomials), all 27 right-hand sides */
@@ -324,6 +374,7 @@ int orc_dls_action_matrix(const double f[3][20], const double u[4], double S[27 
             double s = E[i * NC + 93 + c];
             for (int j = i + 1; j < NR; j++) s = s - E[i * NC + j] * Xb[j - 66][c];
             Xb[i - 66][c] = s / E[i * NC + i];
+            FL(FS_ACTION, 2L * (NR - 1 - i) + 1);
         }
     free(E);
     /* S = A - B X : row m (reduced monomial) is m * f0 = u0 m + u1 m s1 + u2 m s2 + u3 m s3 */
@@ -335,12 +386,15 @@ int orc_dls_action_matrix(const double f[3][20], const double u[4], double S[27 
                 for (int j = 0; j < 27; j++) Sr[j] = 0.0;
                 for (int t = 0; t < 4; t++) {
                     int col = pos[a + SH[t][0]][b + SH[t][1]][c + SH[t][2]];
-                    if (col < 27) Sr[col] = Sr[col] + u[t];
+                    if (col < 27) { Sr[col] = Sr[col] + u[t]; FL(FS_ACTION, 1); }
                 }
                 for (int t = 1; t < 4; t++) {
                     int col = pos[a + SH[t][0]][b + SH[t][1]][c + SH[t][2]];
                     if (col >= 27) /* boundary monomial: position 93.. -> Xb row col-93 */
+                    {
                         for (int j = 0; j < 27; j++) Sr[j] = Sr[j] - u[t] * Xb[col - 93][j];
+                        FL(FS_ACTION, 54);
+                    }
                 }
             }
     return 0;
@@ -359,10 +413,12 @@ static void hessenberg(double H[EN][EN], double V[EN][EN])
     for (int m = low + 1; m <= high - 1; m++) {
         double scale = 0.0;
         for (int i = m; i <= high; i++) scale = scale + fabs(H[i][m - 1]);
+        FL(FS_HESS, high - m + 1);
         ort[m] = 0.0;
         if (scale != 0.0) {
             double h = 0.0;
             for (int i = high; i >= m; i--) { ort[i] = H[i][m - 1] / scale; h = h + ort[i] * ort[i]; }
+            FL(FS_HESS, 3L * (high - m + 1) + 1 /* sqrt */ + 3 /* h, ort[m] */ + 2 /* rescale */);
             double g = sqrt(h);
             if (ort[m] > 0) g = -g;
             h = h - ort[m] * g;
@@ -372,12 +428,14 @@ static void hessenberg(double H[EN][EN], double V[EN][EN])
                 for (int i = high; i >= m; i--) f = f + ort[i] * H[i][j];
                 f = f / h;
                 for (int i = m; i <= high; i++) H[i][j] = H[i][j] - f * ort[i];
+                FL(FS_HESS, 4L * (high - m + 1) + 1);
             }
             for (int i = 0; i <= high; i++) { /* H = H (I - u u^T/h) */
                 double f = 0.0;
                 for (int j = high; j >= m; j--) f = f + ort[j] * H[i][j];
                 f = f / h;
                 for (int j = m; j <= high; j++) H[i][j] = H[i][j] - f * ort[j];
+                FL(FS_HESS, 4L * (high - m + 1) + 1);
             }
             ort[m] = scale * ort[m];
             H[m][m - 1] = scale * g;
@@ -397,6 +455,7 @@ static void hessenberg(double H[EN][EN], double V[EN][EN])
                 for (int i = m; i <= high; i++) g = g + o[i] * V[i][j];
                 g = (g / o[m]) / H[m][m - 1]; /* double division avoids underflow */
                 for (int i = m; i <= high; i++) V[i][j] = V[i][j] + g * o[i];
+                FL(FS_HESS, 4L * (high - m + 1) + 2);
             }
         }
     }
@@ -415,18 +474,20 @@ static int francis_qr(double H[EN][EN], double V[EN][EN], double wr[EN], double 
     double exshift = 0.0, p = 0, q = 0, r = 0, s = 0, z = 0, t, w, x, y;
     double norm = 0.0;
     for (int i = 0; i < nn; i++)
-        for (int j = (i - 1 > 0 ? i - 1 : 0); j < nn; j++) norm = norm + fabs(H[i][j]);
+        for (int j = (i - 1 > 0 ? i - 1 : 0); j < nn; j++) { norm = norm + fabs(H[i][j]); FL(FS_QR, 1); }
     int iter = 0;
     while (n >= low) {
         int l = n;
         while (l > low) {
             s = fabs(H[l - 1][l - 1]) + fabs(H[l][l]);
             if (s == 0.0) s = norm;
+            FL(FS_QR, 2);
             if (fabs(H[l][l - 1]) < eps * s) break;
             l--;
         }
         if (l == n) { /* one root */
             H[n][n] = H[n][n] + exshift;
+            FL(FS_QR, 1);
             wr[n] = H[n][n]; wi[n] = 0.0;
             n--; iter = 0;
         } else if (l == n - 1) { /* two roots */
@@ -437,6 +498,7 @@ static int francis_qr(double H[EN][EN], double V[EN][EN], double wr[EN], double 
             H[n][n] = H[n][n] + exshift;
             H[n - 1][n - 1] = H[n - 1][n - 1] + exshift;
             x = H[n][n];
+            FL(FS_QR, 1 + 2 + 2 + 1 + 2);
             if (q >= 0) { /* real pair */
                 z = (p >= 0) ? p + z : p - z;
                 wr[n - 1] = x + z;
@@ -451,25 +513,30 @@ static int francis_qr(double H[EN][EN], double V[EN][EN], double wr[EN], double 
                 for (int j = n - 1; j < nn; j++) { z = H[n - 1][j]; H[n - 1][j] = q * z + p * H[n][j]; H[n][j] = q * H[n][j] - p * z; }
                 for (int i = 0; i <= n; i++) { z = H[i][n - 1]; H[i][n - 1] = q * z + p * H[i][n]; H[i][n] = q * H[i][n] - p * z; }
                 for (int i = low; i <= high; i++) { z = V[i][n - 1]; V[i][n - 1] = q * z + p * V[i][n]; V[i][n] = q * V[i][n] - p * z; }
+                FL(FS_QR, 1 + 1 + 2 + 1 + 2 + 4 + 2 + 6L * (nn - (n - 1)) + 6L * (n + 1) + 6L * (high - low + 1));
             } else { /* complex pair */
+                FL(FS_QR, 2);
                 wr[n - 1] = x + p; wr[n] = x + p;
                 wi[n - 1] = z; wi[n] = -z;
             }
             n -= 2; iter = 0;
         } else {
             x = H[n][n]; y = 0.0; w = 0.0;
-            if (l < n) { y = H[n - 1][n - 1]; w = H[n][n - 1] * H[n - 1][n]; }
+            if (l < n) { y = H[n - 1][n - 1]; w = H[n][n - 1] * H[n - 1][n]; FL(FS_QR, 1); }
             if (iter == 10) { /* Wilkinson's exceptional shift */
                 exshift = exshift + x;
                 for (int i = low; i <= n; i++) H[i][i] = H[i][i] - x;
                 s = fabs(H[n][n - 1]) + fabs(H[n - 1][n - 2]);
                 x = y = 0.75 * s;
                 w = -0.4375 * s * s;
+                FL(FS_QR, 1 + (n - low + 1) + 1 + 1 + 2);
             }
             if (iter == 30) { /* second exceptional shift */
                 s = (y - x) / 2.0;
                 s = s * s + w;
+                FL(FS_QR, 4);
                 if (s > 0) {
+                    FL(FS_QR, 1 + 5 + (n - low + 1) + 1);
                     s = sqrt(s);
                     if (y < x) s = -s;
                     s = x - w / ((y - x) / 2.0 + s);
@@ -488,6 +555,7 @@ static int francis_qr(double H[EN][EN], double V[EN][EN], double wr[EN], double 
                 p = (r * s - w) / H[m + 1][m] + H[m][m + 1];
                 q = H[m + 1][m + 1] - z - r - s;
                 r = H[m + 2][m + 1];
+                FL(FS_QR, 2 + 4 + 3 + 2 /* |p|+|q|+|r| */);
                 /* EISPACK divides (p,q,r) by |p|+|q|+|r| purely as overflow protection; here the scale is the power of two
                  * 2^e with |p|+|q|+|r| = f * 2^e, f in [0.5,1): the scaling is then exact (no rounding) and costs three
                  * exponent adjustments instead of three divisions on the critical path of every step. */
@@ -498,6 +566,7 @@ static int francis_qr(double H[EN][EN], double V[EN][EN], double wr[EN], double 
                 { int e2; (void)frexp(s, &e2); p = ldexp(p, -e2); q = ldexp(q, -e2); r = ldexp(r, -e2); }
 #endif
                 if (m == l) break;
+                FL(FS_QR, 2 + 4);
                 if (fabs(H[m][m - 1]) * (fabs(q) + fabs(r)) <
                     eps * (fabs(p) * (fabs(H[m - 1][m - 1]) + fabs(z) + fabs(H[m + 1][m + 1])))) break;
                 m--;
@@ -511,6 +580,7 @@ static int francis_qr(double H[EN][EN], double V[EN][EN], double wr[EN], double 
                 if (k != m) {
                     p = H[k][k - 1]; q = H[k + 1][k - 1]; r = notlast ? H[k + 2][k - 1] : 0.0;
                     x = fabs(p) + fabs(q) + fabs(r);
+                    FL(FS_QR, 2);
                     if (x == 0.0) continue;
 #ifdef ORC_EISPACK_DIVIDE
                     p = p / x; q = q / x; r = r / x;
@@ -520,8 +590,11 @@ static int francis_qr(double H[EN][EN], double V[EN][EN], double wr[EN], double 
 #endif
                 }
                 s = sqrt(p * p + q * q + r * r);
+                FL(FS_QR, 6);
                 if (p < 0) s = -s;
                 if (s != 0.0) {
+                    FL(FS_QR, 1 + 3 + 2);
+                    FL(FS_QR, (notlast ? 10L : 6L) * (nn - k) + (notlast ? 10L : 6L) * (((n < k + 3) ? n : k + 3) + 1) + (notlast ? 10L : 6L) * (high - low + 1));
 #ifdef ORC_EISPACK_DIVIDE
                     if (k != m) H[k][k - 1] = -s * x;
 #else
@@ -565,20 +638,24 @@ static int francis_qr(double H[EN][EN], double V[EN][EN], double wr[EN], double 
             w = H[i][i] - p;
             r = 0.0;
             for (int j = l; j <= n; j++) r = r + H[i][j] * H[j][n];
+            FL(FS_EIGVEC, 1 + 2L * (n - l + 1));
             if (wi[i] < 0.0) { z = w; s = r; }
             else {
                 l = i;
                 if (wi[i] == 0.0) {
                     if (w != 0.0) H[i][n] = -r / w; else H[i][n] = -r / (eps * norm);
+                    FL(FS_EIGVEC, 1);
                 } else { /* 2x2 block of a complex pair above a real eigenvalue */
                     x = H[i][i + 1]; y = H[i + 1][i];
                     q = (wr[i] - p) * (wr[i] - p) + wi[i] * wi[i];
                     t = (x * s - z * r) / q;
                     H[i][n] = t;
                     if (fabs(x) > fabs(z)) H[i + 1][n] = (-r - w * t) / x; else H[i + 1][n] = (-s - y * t) / z;
+                    FL(FS_EIGVEC, 5 + 4 + 3);
                 }
                 t = fabs(H[i][n]);
-                if ((eps * t) * t > 1) for (int j = i; j <= n; j++) H[j][n] = H[j][n] / t;
+                FL(FS_EIGVEC, 2);
+                if ((eps * t) * t > 1) { for (int j = i; j <= n; j++) H[j][n] = H[j][n] / t; FL(FS_EIGVEC, n - i + 1); }
             }
         }
     }
@@ -606,6 +683,7 @@ int orc_eig27_real(const double S[27 * 27], double lambda[27], double v4[27][4])
             int i = ROWS[rr];
             double zz = 0.0;
             for (int k = 0; k <= n; k++) zz = zz + V[i][k] * H[k][n];
+            FL(FS_EIGVEC, 2L * (n + 1));
             v4[cnt][rr] = zz;
         }
         cnt++;
@@ -640,6 +718,7 @@ int orc_dls_pnp(const double *X, const double *uv, int32_t n, const double u[4],
     for (int e = 0; e < nreal; e++) {
         double s1 = v4[e][3] / v4[e][0], s2 = v4[e][2] / v4[e][0], s3 = v4[e][1] / v4[e][0];
         if (!(fabs(s1) <= DBL_MAX && fabs(s2) <= DBL_MAX && fabs(s3) <= DBL_MAX)) continue; /* inf / NaN root */
+        FL(FS_POSE, 3 + 7 + 4 + 25 /* quat_to_rot: 3 + 9 + 13 */ + 3 * 18);
         double nq = sqrt(((1.0 + s1 * s1) + s2 * s2) + s3 * s3);
         double R[9], t[3];
         quat_to_rot(1.0 / nq, s1 / nq, s2 / nq, s3 / nq, R);
@@ -651,6 +730,7 @@ int orc_dls_pnp(const double *X, const double *uv, int32_t n, const double u[4],
         int front = 1;
         for (int i = 0; i < n; i++) { /* all sample points in front of the camera */
             double zc = ((R[6] * X[3 * i] + R[7] * X[3 * i + 1]) + R[8] * X[3 * i + 2]) + t[2];
+            FL(FS_POSE, 6);
             if (zc < 0) { front = 0; break; }
         }
         if (!front) continue;

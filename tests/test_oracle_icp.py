@@ -21,14 +21,7 @@ def np_umeyama(a, b):
     return R, mb - s * R @ ma, s
 
 
-def make_icp_scene(N=300, outlier_frac=0.2, noise=0.02, seed=1):
-    X, uv, T, inl = M.make_scene(N=N, outlier_frac=0.0, noise_px=0.0, seed=seed)
-    rng = np.random.default_rng(seed + 1000)
-    A = X
-    B = X @ T[:3, :3].T + T[:3, 3] + rng.standard_normal((N, 3)) * noise
-    out = rng.random(N) < outlier_frac
-    B[out] += rng.uniform(-3, 3, (out.sum(), 3))
-    return A, B, T, ~out
+from cerebro_amd.synth import make_icp_scene  # noqa: E402,F401  (one definition, shared with bench.py's icp leg)
 
 
 @pytest.mark.parametrize("seed", range(8))
