@@ -42,6 +42,7 @@ CHIP_MULTI_EXCHANGE_COPY = 4
 CHIP_COMM_ID_BYTES = 128
 CHIP_EXCHANGE_NONE, CHIP_EXCHANGE_RCCL, CHIP_EXCHANGE_COPY = 0, 1, 2
 CHIP_SCAN_FORM_ONE_ROW, CHIP_SCAN_FORM_ROWS = 1, 2
+CHIP_SAMPLER_FRESH, CHIP_SAMPLER_THEIA_PERSISTENT = 0, 1
 
 CHIP_TICK_SKIPPED, CHIP_TICK_TOO_SHORT, CHIP_TICK_SCANNED = 0, 1, 2
 
@@ -74,7 +75,7 @@ class RansacParams(C.Structure):
     _fields_ = [("error_thresh", C.c_double), ("min_inlier_ratio", C.c_double), ("max_iterations", C.c_int32),
                 ("min_iterations", C.c_int32), ("use_mle", C.c_int32), ("sample_size", C.c_int32),
                 ("failure_probability", C.c_double), ("seed", C.c_uint64), ("n_hypotheses", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("sampler", C.c_int32)]
 
 
 class RansacSummary(C.Structure):

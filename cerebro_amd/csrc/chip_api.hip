@@ -69,7 +69,7 @@ void chip_ransac_params_default(chip_ransac_params *p)
     p->failure_probability = 0.01; // theia::RansacParameters default
     p->seed = 0x5EEDCE7EB80ULL;
     p->n_hypotheses = 0;
-    p->reserved = 0;
+    p->sampler = CHIP_SAMPLER_FRESH;
 }
 
 }  // extern "C"

@@ -18,6 +18,7 @@
 #include "ransac_common.h"
 #include <cstring>
 #include <new>
+#include <vector>
 
 namespace chip {
 
@@ -36,6 +37,7 @@ struct IcpArgs {
     unsigned long long *mask;  // [H][mask_words]
     int32_t H;
     uint64_t magic[kSampleMax];   // floor(2^64 / (N - i)): the sampler's 64-bit modulo as a multiply-high (the divisors depend on i only)
+    const int32_t *sample_in;   // CHIP_SAMPLER_THEIA_PERSISTENT: [H][kSampleMax] sequenced by the host (pinned, device-mapped); else nullptr
     double *T_dev;     // [H][16] device copy of the models: icp_score reads it (T_out is pinned HOST memory)
     int32_t *valid_dev;// [H]
 };
@@ -117,7 +119,12 @@ __global__ __launch_bounds__(64) void icp_models(IcpArgs a)
     if (hyp >= a.H) return;
     const int n = a.S;
     int smp[kSampleMax];
-    ransac_sample_lane(a.seed, hyp, a.N, n, a.magic, smp);
+    if (a.sample_in) {
+#pragma unroll
+        for (int i = 0; i < kSampleMax; i++) smp[i] = i < n ? a.sample_in[(size_t)hyp * kSampleMax + i] : 0;
+    } else {
+        ransac_sample_lane(a.seed, hyp, a.N, n, a.magic, smp);
+    }
 
     // ---- Umeyama on the sample ----
     double ma[3] = {0.0, 0.0, 0.0}, mb[3] = {0.0, 0.0, 0.0};
@@ -232,6 +239,8 @@ __global__ __launch_bounds__(64) void icp_score(IcpArgs a)
 struct IcpState {
     double *A = nullptr, *B = nullptr, *T_out = nullptr, *cost = nullptr, *T_dev = nullptr;
     int32_t *nin = nullptr, *valid = nullptr, *valid_dev = nullptr;
+    int32_t *h_sample_in = nullptr, *d_sample_in = nullptr;   // persistent-sampler table (pinned host + device view)
+    std::vector<int32_t> perm;
     unsigned long long *mask = nullptr;
     int32_t cap_N = 0, cap_H = 0, cap_words = 0;
     double *h_cost = nullptr, *h_T = nullptr;
@@ -246,7 +255,7 @@ struct IcpState {
 static void icp_free(IcpState *st)
 {
     (void)hipFree(st->A); (void)hipFree(st->B); (void)hipFree(st->T_dev); (void)hipFree(st->valid_dev);   // T_out/cost/nin/valid/mask are device views of the pinned host buffers below
-    (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid); (void)hipHostFree(st->h_mask);
+    (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid); (void)hipHostFree(st->h_mask); (void)hipHostFree(st->h_sample_in);
     const hipStream_t keep = st->stream;   // buffers are regrown, the stream lives as long as the ctx
     *st = IcpState();
     st->stream = keep;
@@ -278,6 +287,8 @@ static int icp_reserve(Ctx *c, IcpState *st, int N, int H)
     CHIP_HIP(c, hipHostMalloc(&st->h_nin, sizeof(int32_t) * (size_t)nH, hipHostMallocDefault));
     CHIP_HIP(c, hipHostMalloc(&st->h_valid, sizeof(int32_t) * (size_t)nH, hipHostMallocDefault));
     CHIP_HIP(c, hipHostMalloc(&st->h_mask, sizeof(unsigned long long) * (size_t)nH * nW, hipHostMallocDefault));
+    CHIP_HIP(c, hipHostMalloc(&st->h_sample_in, sizeof(int32_t) * kSampleMax * (size_t)nH, hipHostMallocDefault));
+    CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->d_sample_in, st->h_sample_in, 0));
     CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->cost, st->h_cost, 0));
     CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->T_out, st->h_T, 0));
     CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->nin, st->h_nin, 0));
@@ -324,6 +335,12 @@ static int icp_enqueue_locked(chip_ctx *c, const double *A, const double *B, int
     a.A = st->A; a.B = st->B; a.N = N; a.S = S; a.seed = p->seed; a.thresh = p->error_thresh; a.use_mle = p->use_mle;
     a.mask_words = words; a.T_out = st->T_out; a.cost = st->cost; a.nin = st->nin; a.valid = st->valid; a.mask = st->mask;
     a.H = H; a.T_dev = st->T_dev; a.valid_dev = st->valid_dev;
+    a.sample_in = nullptr;
+    if (p->sampler == CHIP_SAMPLER_THEIA_PERSISTENT) {
+        st->perm.resize((size_t)N);
+        ransac_sample_table_persistent(p->seed, H, N, S, kSampleMax, st->perm.data(), st->h_sample_in);
+        a.sample_in = st->d_sample_in;
+    }
     for (int i = 0; i < kSampleMax; i++) {   // N - i >= 20 - 16 > 1 (icp_check_args), so the quotient fits 64 bits
         const uint64_t d = (uint64_t)(N - (i < S ? i : 0));
         a.magic[i] = (uint64_t)((((unsigned __int128)1) << 64) / d);
@@ -380,6 +397,7 @@ static int icp_check_args(const double *A, const double *B, int32_t N, const chi
     if (N < 20) return CHIP_ERR_TOO_FEW_POINTS;  // DlsPnpWithRansac.cpp:19-22
     const int32_t S = p->sample_size;
     if (S < 3 || S > kSampleMax || S > N || p->n_hypotheses < 0 || p->max_iterations < 1) return CHIP_ERR_UNSUPPORTED;
+    if (p->sampler != CHIP_SAMPLER_FRESH && p->sampler != CHIP_SAMPLER_THEIA_PERSISTENT) return CHIP_ERR_UNSUPPORTED;
     return CHIP_OK;
 }
 

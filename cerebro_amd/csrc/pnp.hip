@@ -204,6 +204,7 @@ struct SolveArgs {
     double *Sg;         // [H][729]  action matrices
     double *Tg;         // [H][27]   translation factor (t = Tfac * vec(R))
     int32_t *sample;    // [H][kSampleMax]
+    const int32_t *sample_in;   // CHIP_SAMPLER_THEIA_PERSISTENT: [P * H][kSampleMax] made by the host (pinned, device-mapped); else nullptr
     int32_t *ok;        // [H] 1 = S valid, 0 = singular D
     unsigned long long *stamps;   // tuning only (CHIP_PNP_STAMPS): [H][8] s_memtime at the phase boundaries of pnp_build_solve
     // The correspondences arrive in pinned, device-mapped HOST memory (no H2D copy in front of the launch: 6 us of copy + ~10 us of
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
         for (int64_t e = (int64_t)blockIdx.x * kSolveThreads + tid; e < a.n_in; e += (int64_t)gridDim.x * kSolveThreads) a.in_dev[e] = a.in_host[e];
     // ---- sampler: partial Fisher-Yates over a virtual identity permutation (theia::RandomSampler restated) ----
     if (wave == 0) {
-        const int sv = ransac_sample_wave(pr.seed, hyp, pr.N, n, lane);
+        // (sample_in: the persistent-permutation mode -- the host sequenced the swaps, this hypothesis reads its row of the table)
+        const int sv = a.sample_in ? (lane < n ? a.sample_in[(size_t)slot * kSampleMax + lane] : 0) : ransac_sample_wave(pr.seed, hyp, pr.N, n, lane);
         if (lane < n) smp[lane] = sv;
         if (lane < 4) {   // random linear form f0 (Theia: 100 * Vector4d::Random())
             const uint64_t x = rng_draw(pr.seed, (uint32_t)hyp, (uint32_t)(64 + lane));
@@ -2274,6 +2276,8 @@ struct PnpState {
     int32_t cap_N = 0;
     double *Sg = nullptr, *Tg = nullptr;
     int32_t *sample = nullptr, *ok = nullptr;
+    int32_t *h_sample_in = nullptr, *d_sample_in = nullptr;   // CHIP_SAMPLER_THEIA_PERSISTENT: the host-sequenced sample table (pinned) + its device view
+    std::vector<int32_t> perm;                                // ... and the permutation it is sequenced on
     int32_t cap_H = 0, cap_words = 0;
     // Per-hypothesis results live in pinned, device-mapped HOST memory: pnp_eig_score stores them straight across PCIe (a few
     // hundred KB per call, posted while the kernel runs), so a call needs no D2H copy and a single stream synchronisation.
@@ -2316,7 +2320,7 @@ static void pnp_free_dev(PnpState *st)
     (void)hipFree(st->Sg); (void)hipFree(st->Tg);
     (void)hipFree(st->sample); (void)hipFree(st->ok);
     (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid);
-    (void)hipHostFree(st->h_nsol); (void)hipHostFree(st->h_mask);
+    (void)hipHostFree(st->h_nsol); (void)hipHostFree(st->h_mask); (void)hipHostFree(st->h_sample_in);
     (void)hipFree(st->stamps);
     if (st->s2) (void)hipStreamDestroy(st->s2);
     if (st->ev_in) (void)hipEventDestroy(st->ev_in);
@@ -2347,7 +2351,8 @@ static int pnp_reserve(Ctx *c, PnpState *st, int N, int H, int words, int P)
         const int nh = H > st->cap_H ? H : st->cap_H, nw = words > st->cap_words ? words : st->cap_words;
         (void)hipFree(st->Sg); (void)hipFree(st->Tg); (void)hipFree(st->sample); (void)hipFree(st->ok);
         (void)hipHostFree(st->h_cost); (void)hipHostFree(st->h_T); (void)hipHostFree(st->h_nin); (void)hipHostFree(st->h_valid);
-        (void)hipHostFree(st->h_nsol); (void)hipHostFree(st->h_mask);
+        (void)hipHostFree(st->h_nsol); (void)hipHostFree(st->h_mask); (void)hipHostFree(st->h_sample_in);
+        st->h_sample_in = nullptr;
         st->Sg = st->Tg = nullptr; st->sample = st->ok = nullptr;
         st->h_cost = st->h_T = nullptr; st->h_nin = st->h_valid = st->h_nsol = nullptr; st->h_mask = nullptr;
         st->cap_H = st->cap_words = 0;
@@ -2361,6 +2366,8 @@ static int pnp_reserve(Ctx *c, PnpState *st, int N, int H, int words, int P)
         CHIP_HIP(c, hipHostMalloc(&st->h_valid, sizeof(int32_t) * (size_t)nh, hipHostMallocDefault));
         CHIP_HIP(c, hipHostMalloc(&st->h_nsol, sizeof(int32_t) * (size_t)nh, hipHostMallocDefault));
         CHIP_HIP(c, hipHostMalloc(&st->h_mask, sizeof(unsigned long long) * (size_t)nh * nw, hipHostMallocDefault));
+        CHIP_HIP(c, hipHostMalloc(&st->h_sample_in, sizeof(int32_t) * kSampleMax * (size_t)nh, hipHostMallocDefault));
+        CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->d_sample_in, st->h_sample_in, 0));
         CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->cost, st->h_cost, 0));
         CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->T_out, st->h_T, 0));
         CHIP_HIP(c, hipHostGetDevicePointer((void **)&st->nin, st->h_nin, 0));
@@ -2418,6 +2425,13 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
         for (int i = 0; i < P; i++) sa.prob[i] = ea.prob[i];
     }
     if (ht.on) ht1 = ht_now();
+    if (p->sampler == CHIP_SAMPLER_THEIA_PERSISTENT) {   // one persistent permutation per problem, hypotheses 0..H-1 in order
+        for (int i = 0; i < P; i++) {
+            st->perm.resize((size_t)N[i]);
+            ransac_sample_table_persistent(seeds ? seeds[i] : p->seed, H, N[i], S, kSampleMax, st->perm.data(), st->h_sample_in + (size_t)i * H * kSampleMax);
+        }
+        sa.sample_in = st->d_sample_in;
+    }
     sa.H = H; sa.S = S; sa.tab = st->tab_dev;
     sa.Sg = st->Sg; sa.Tg = st->Tg; sa.sample = st->sample; sa.ok = st->ok;
     sa.in_host = want_h2d ? nullptr : st->d_hin; sa.in_dev = st->X; sa.n_in = 5 * (int64_t)Ntot;
@@ -2559,6 +2573,7 @@ extern "C" int chip_pnp_ransac_batch(chip_ctx *c, int32_t P, const double *const
         if (S > N[i]) return CHIP_ERR_UNSUPPORTED;
     }
     if (S < 3 || S > kSampleMax || p->n_hypotheses < 0 || p->max_iterations < 1) return CHIP_ERR_UNSUPPORTED;
+    if (p->sampler != CHIP_SAMPLER_FRESH && p->sampler != CHIP_SAMPLER_THEIA_PERSISTENT) return CHIP_ERR_UNSUPPORTED;
     std::lock_guard<std::mutex> lk(c->pnp_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
     PnpState *st = static_cast<PnpState *>(c->pnp_state);

@@ -51,6 +51,30 @@ __device__ __forceinline__ int ransac_sample_wave(uint64_t seed, int hyp, int N,
     return mine;
 }
 
+inline uint64_t splitmix64_h(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// CHIP_SAMPLER_THEIA_PERSISTENT: theia::RandomSampler as written -- Initialize() once (0..N-1), every Sample() continues on the
+// permutation the previous one left (oracle/pnp_ransac.c orc_ransac_sample_persistent).  Inherently sequential over the
+// hypotheses, S swaps each: done on the host, the kernels read the table (out[h * stride + i]).  `perm` is scratch (>= N).
+inline void ransac_sample_table_persistent(uint64_t seed, int32_t H, int32_t N, int32_t S, int32_t stride, int32_t *perm, int32_t *out)
+{
+    for (int32_t i = 0; i < N; i++) perm[i] = i;
+    for (int32_t h = 0; h < H; h++)
+        for (int32_t i = 0; i < S; i++) {
+            const uint64_t x = splitmix64_h(seed ^ ((uint64_t)(uint32_t)h << 32) ^ (uint64_t)(uint32_t)i);
+            const int32_t j = i + (int32_t)(x % (uint64_t)(N - i));
+            const int32_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+            out[(size_t)h * stride + i] = perm[i];
+        }
+}
+
 // theia::SampleConsensusEstimator::ComputeMaxIterations
 inline int32_t ransac_max_iterations(int32_t S, double ratio, double log_fail, int32_t min_it, int32_t max_it)
 {

@@ -2,6 +2,7 @@
 #include "cerebro_host.h"
 #include "state_json.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -65,6 +66,12 @@ int64_t Cerebro::loadStateFromDisk(const std::string &path)
     }
     status_ = chip_db_append_f64(ctx_, sd.desc.data(), (int64_t)sd.stampNSec.size(), float32_text ? CHIP_APPEND_ALLOW_ROUNDING : 0u, &first);
     if (status_ != CHIP_OK) { error_ = chip_strerror(status_); return -1; }
+    for (uint64_t ns : sd.all_stampNSec) {        // every DataNode of the checkpoint is a data_map entry (DataManager.cpp:1230-1290 rebuilds it)
+        Time t;
+        t.sec = (uint32_t)(ns / 1000000000ull);
+        t.nsec = (uint32_t)(ns % 1000000000ull);
+        data_map_insert(t);
+    }
     std::lock_guard<std::mutex> lk(m_wholeImageComputedList);
     for (uint64_t ns : sd.stampNSec) {
         Time t;
@@ -73,6 +80,31 @@ int64_t Cerebro::loadStateFromDisk(const std::string &path)
         wholeImageComputedList.push_back(t);
     }
     return (int64_t)sd.stampNSec.size();
+}
+
+void Cerebro::data_map_insert(const Time &stamp)
+{
+    std::lock_guard<std::mutex> lk(m_data_map);
+    const uint64_t k = ((uint64_t)stamp.sec << 32) | stamp.nsec;
+    if (!data_map_.empty() && k <= data_map_.back()) data_map_sorted_ = false;   // frames normally arrive in time order
+    data_map_.push_back(k);
+}
+
+void Cerebro::set_frame_index_map(const std::vector<int64_t> &row_to_frame)
+{
+    std::lock_guard<std::mutex> lk(m_data_map);
+    row_to_frame_ = row_to_frame;
+}
+
+int64_t Cerebro::data_map_size() const
+{
+    std::lock_guard<std::mutex> lk(m_data_map);
+    if (!data_map_sorted_) {
+        std::sort(data_map_.begin(), data_map_.end());
+        data_map_.erase(std::unique(data_map_.begin(), data_map_.end()), data_map_.end());
+        data_map_sorted_ = true;
+    }
+    return (int64_t)data_map_.size();
 }
 
 int Cerebro::wholeImageComputedList_size() const
@@ -240,9 +272,25 @@ std::string Cerebro::foundLoops_as_JSON() const
     std::unordered_map<uint64_t, long> first_row;
     first_row.reserve(stamps.size());
     for (size_t i = 0; i < stamps.size(); i++) first_row.emplace(((uint64_t)stamps[i].sec << 32) | stamps[i].nsec, (long)i);
+    // global_a / global_b (Cerebro.cpp:1142-1143): the frame's rank in data_map when the frames are known, else the DB row
+    (void)data_map_size();   // sorts + dedups the registered frame stamps
+    std::vector<uint64_t> frames;
+    std::vector<int64_t> r2f;
+    {
+        std::lock_guard<std::mutex> lk(m_data_map);
+        frames = data_map_;
+        r2f = row_to_frame_;
+    }
     auto index_of = [&](const Time &t) {
-        auto it = first_row.find(((uint64_t)t.sec << 32) | t.nsec);
-        return it == first_row.end() ? -1L : it->second;
+        const uint64_t k = ((uint64_t)t.sec << 32) | t.nsec;
+        auto it = first_row.find(k);
+        const long row = it == first_row.end() ? -1L : it->second;
+        if (row >= 0 && (size_t)row < r2f.size()) return (long)r2f[(size_t)row];
+        if (!frames.empty()) {
+            auto f = std::lower_bound(frames.begin(), frames.end(), k);
+            if (f != frames.end() && *f == k) return (long)(f - frames.begin());   // std::distance(begin, find(t))
+        }
+        return row;
     };
     std::ostringstream o;
     o.precision(17);

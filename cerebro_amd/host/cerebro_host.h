@@ -65,6 +65,17 @@ public:
     int64_t loadStateFromDisk(const std::string &state_json_path);
     const std::string &last_error() const { return error_; }
 
+    // ---- what foundLoops_as_JSON's global_a / global_b refer to.  The reference reports std::distance(data_map->begin(),
+    // data_map->find(t)) (Cerebro.cpp:1142-1143): the rank of the time stamp among ALL camera frames DataManager holds (every frame
+    // gets a node, DataManager.cpp image callbacks; only keyframes get descriptors), not the row of the descriptor DB.  Two ways
+    // to give this mirror the same information, both optional:
+    //   data_map_insert(stamp)        call it for every frame, as DataManager does (any order; duplicates ignored);
+    //   set_frame_index_map(r2f)      r2f[row] = index of that row's frame in data_map (e.g. from a recorded run).
+    // With neither, global_a / global_b fall back to the DB row (= wholeImageComputedList index).
+    void data_map_insert(const Time &stamp);
+    void set_frame_index_map(const std::vector<int64_t> &row_to_frame);
+    int64_t data_map_size() const;
+
     // ---- thread-safe accessors (Cerebro.h:105-106)
     int wholeImageComputedList_size() const;
     Time wholeImageComputedList_at(int k) const;
@@ -93,8 +104,8 @@ public:
     // ---- foundLoops (Cerebro.h:152-158)
     int foundLoops_count() const;
     std::tuple<Time, Time, double> foundLoops_i(int i) const;
-    // Same keys as Cerebro.cpp:1149-1159; global_a/global_b are indices into wholeImageComputedList here (the
-    // reference reports the index into DataManager's data_map, which is out of scope).
+    // Same keys as Cerebro.cpp:1149-1159.  global_a / global_b: the reference's data_map index when the frames were registered
+    // (data_map_insert / set_frame_index_map / a state.json cold start, which lists every node), else the DB row.
     std::string foundLoops_as_JSON() const;
 
     chip_dot_params params;  // LOCALITY_THRESH / DOT_PROD_THRESH / lag  (Cerebro.cpp:912-914)
@@ -108,6 +119,10 @@ private:
     std::vector<Time> wholeImageComputedList;
     mutable std::mutex m_foundLoops;
     std::vector<std::tuple<Time, Time, double>> foundLoops;
+    mutable std::mutex m_data_map;
+    mutable std::vector<uint64_t> data_map_;          // all frame stamps (sec << 32 | nsec); sorted lazily
+    mutable bool data_map_sorted_ = true;
+    std::vector<int64_t> row_to_frame_;
     std::atomic<bool> b_run_thread{false};
     // state of the two index policies (function-locals of the reference: Cerebro.cpp:393-394 / :535-539)
     bool index_search(int64_t ntotal, const int64_t *rows, int n_rows, float *distances, int64_t *labels);

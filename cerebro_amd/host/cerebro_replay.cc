@@ -4,7 +4,10 @@
 //   cerebro_replay [--devices a,b,..] <stream.bin> <out.json> [device]
 // stream.bin (little endian): "CRBR" u32 version=1, u32 D, u64 N, u64 n_ticks, then N x {u32 sec, u32 nsec},
 // N x D float64 descriptors (the .srv wire type), n_ticks x i64 l (value of wholeImageComputedList_size() at each
-// iteration of the dot-product thread; rows < l are appended before the tick).
+// iteration of the dot-product thread; rows < l are appended before the tick).  Optional trailers, any order, so that the dump's
+// global_a / global_b are the reference's data_map indices (src/Cerebro.cpp:1142-1143) and a genuine loopcandidates_liverun.json
+// compares without field exceptions:  "FRMS" u64 F, F x {u32 sec, u32 nsec} = the stamp of EVERY camera frame (what DataManager's
+// data_map holds);  "FIDX" u64 N, N x i64 = row -> data_map index, given directly.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -69,11 +72,12 @@ static int from_state(const char *in, const char *outp, int device)
 // writes at shutdown (loopcandidates_liverun.json = Cerebro::foundLoops_as_JSON().dump(4), src/cerebro_node.cpp:769-770, keys
 // of src/Cerebro.cpp:1149-1159) -- e.g. a recorded EuRoC run of the reference against `cerebro_replay <stream> <out.json>` fed
 // the same descriptors and tick schedule (BASELINE configs 1 and 5).  Candidates are matched IN ORDER on the four time stamps
-// (sec/nsec of t_curr and t_prev): that is the selection.  global_a / global_b are not compared (the reference reports the
-// index into DataManager's data_map, this harness the DB row); scores are compared numerically and the largest difference is
-// reported (Eigen's summation order differs from the fixed tree in the last bits).  Prints one JSON object; exit status 0 iff
-// the two selections are identical.
-struct LoopRec { uint64_t sa = 0, na = 0, sb = 0, nb = 0; double score = 0.0; int have = 0; };
+// (sec/nsec of t_curr and t_prev): that is the selection.  global_a / global_b (the reference: index into DataManager's data_map,
+// src/Cerebro.cpp:1142-1143) are compared too -- a replay that was given the frames (stream trailers FRMS / FIDX, or a state.json
+// cold start) emits the same indices; `--compare-selection` skips them for a replay that was not.  Scores are compared
+// numerically and the largest difference is reported (Eigen's summation order differs from the fixed tree in the last bits).
+// Prints one JSON object; exit status 0 iff the two dumps agree.
+struct LoopRec { uint64_t sa = 0, na = 0, sb = 0, nb = 0; double score = 0.0; int have = 0; long long ga = -1, gb = -1; };
 
 static bool parse_loop_dump(const char *path, std::vector<LoopRec> &out, std::string &err)
 {
@@ -115,20 +119,22 @@ static bool parse_loop_dump(const char *path, std::vector<LoopRec> &out, std::st
             else if (key == "time_nsec_a") { r.na = std::strtoull(p, &q, 10); r.have |= 2; }
             else if (key == "time_sec_b") { r.sb = std::strtoull(p, &q, 10); r.have |= 4; }
             else if (key == "time_nsec_b") { r.nb = std::strtoull(p, &q, 10); r.have |= 8; }
-            else (void)std::strtod(p, &q);   // time_double_*, global_*: numbers, not part of the comparison
+            else if (key == "global_a") { r.ga = std::strtoll(p, &q, 10); r.have |= 32; }
+            else if (key == "global_b") { r.gb = std::strtoll(p, &q, 10); r.have |= 64; }
+            else (void)std::strtod(p, &q);   // time_double_*: derived from sec / nsec
             if (!q || q == p) { err = "expected a number for key " + key; return false; }
             p = q;
             ws();
             if (p < e && *p == ',') p++;
         }
-        if (r.have != 31) { err = "candidate without time_sec/nsec_a/b + score"; return false; }
+        if ((r.have & 31) != 31) { err = "candidate without time_sec/nsec_a/b + score"; return false; }
         out.push_back(r);
         ws();
         if (p < e && *p == ',') p++;
     }
 }
 
-static int compare_dumps(const char *ref_path, const char *cand_path)
+static int compare_dumps(const char *ref_path, const char *cand_path, bool with_global)
 {
     std::vector<LoopRec> a, b;
     std::string err;
@@ -141,10 +147,19 @@ static int compare_dumps(const char *ref_path, const char *cand_path)
         const double d = a[i].score > b[i].score ? a[i].score - b[i].score : b[i].score - a[i].score;
         if (d > max_d) max_d = d;
     }
-    const bool same = first == n && a.size() == b.size();
-    std::printf("{\"identical_selection\": %s, \"n_reference\": %zu, \"n_candidate\": %zu, \"matched_prefix\": %zu, \"max_abs_score_diff\": %.17g",
-                same ? "true" : "false", a.size(), b.size(), first, max_d);
-    if (!same) {
+    const bool same_sel = first == n && a.size() == b.size();
+    size_t global_mismatch = 0, global_compared = 0;
+    if (with_global)
+        for (size_t i = 0; i < first; i++) {
+            if ((a[i].have & 96) != 96 || (b[i].have & 96) != 96) { global_mismatch++; continue; }   // a dump without the fields does not pass the strict form
+            global_compared++;
+            if (a[i].ga != b[i].ga || a[i].gb != b[i].gb) global_mismatch++;
+        }
+    const bool same = same_sel && global_mismatch == 0;
+    std::printf("{\"identical_selection\": %s, \"identical_dump\": %s, \"global_index_compared\": %zu, \"global_index_mismatches\": %zu, "
+                "\"n_reference\": %zu, \"n_candidate\": %zu, \"matched_prefix\": %zu, \"max_abs_score_diff\": %.17g",
+                same_sel ? "true" : "false", with_global ? (same ? "true" : "false") : "null", global_compared, global_mismatch, a.size(), b.size(), first, max_d);
+    if (!same_sel) {
         std::printf(", \"first_divergence\": {\"index\": %zu", first);
         auto one = [](const char *name, const std::vector<LoopRec> &v, size_t i) {
             if (i < v.size())
@@ -263,7 +278,8 @@ int main(int argc, char **argv)
         argv += 2;
         argc -= 2;
     }
-    if (argc >= 4 && std::strcmp(argv[1], "--compare") == 0) return compare_dumps(argv[2], argv[3]);
+    if (argc >= 4 && std::strcmp(argv[1], "--compare") == 0) return compare_dumps(argv[2], argv[3], true);
+    if (argc >= 4 && std::strcmp(argv[1], "--compare-selection") == 0) return compare_dumps(argv[2], argv[3], false);
     if (argc >= 3 && std::strcmp(argv[1], "--gate") == 0) return gate(argv[2]);
     if (argc >= 3 && std::strcmp(argv[1], "--threeway") == 0) return threeway(argv[2], argc > 3 ? std::atoi(argv[3]) : 0);
     if (argc >= 4 && std::strcmp(argv[1], "--parse-only") == 0) return parse_only(argv[2], argv[3]);
@@ -287,11 +303,26 @@ int main(int argc, char **argv)
         std::fprintf(stderr, "truncated stream\n");
         return 2;
     }
+    std::vector<cerebro_hip::Time> frames;
+    std::vector<int64_t> row_to_frame;
+    for (char tag[4]; std::fread(tag, 1, 4, f) == 4;) {      // optional trailers
+        uint64_t cnt = 0;
+        if (std::fread(&cnt, 8, 1, f) != 1 || cnt > (1ull << 32)) { std::fprintf(stderr, "bad trailer\n"); return 2; }
+        if (std::memcmp(tag, "FRMS", 4) == 0) {
+            frames.resize(cnt);
+            if (std::fread(frames.data(), sizeof(cerebro_hip::Time), cnt, f) != cnt) { std::fprintf(stderr, "truncated FRMS trailer\n"); return 2; }
+        } else if (std::memcmp(tag, "FIDX", 4) == 0) {
+            row_to_frame.resize(cnt);
+            if (std::fread(row_to_frame.data(), sizeof(int64_t), cnt, f) != cnt) { std::fprintf(stderr, "truncated FIDX trailer\n"); return 2; }
+        } else { std::fprintf(stderr, "unknown trailer\n"); return 2; }
+    }
     std::fclose(f);
     std::unique_ptr<cerebro_hip::Cerebro> cer_p(make_cerebro((int)D, argc > 3 ? std::atoi(argv[3]) : 0, (int64_t)N));
     cerebro_hip::Cerebro &cer = *cer_p;
     if (!cer.ok()) { std::fprintf(stderr, "chip_create failed: %s\n", chip_strerror(cer.last_status())); return 3; }
     cer.rand_source = replay_rand;
+    for (const cerebro_hip::Time &t : frames) cer.data_map_insert(t);
+    if (!row_to_frame.empty()) cer.set_frame_index_map(row_to_frame);
     int64_t appended = 0;
     for (uint64_t t = 0; t < T; t++) {
         const int64_t l = ticks[t];

@@ -249,6 +249,7 @@ bool parse_node(Cur &c, StateDescriptors &out, std::vector<DataSpan> &spans)
         if (c.p < c.end && *c.p == ',') c.p++;
     }
     out.n_nodes++;
+    if (have_stamp) out.all_stampNSec.push_back(stamp);
     if (have_desc && available != 0) {   // DataManager::loadStateFromDisk only restores it when the flag is set
         if (!have_stamp) return c.fail("node with descriptor but no stampNSec");
         if (sp.rows > kMaxDescriptor || sp.cols > kMaxDescriptor || sp.rows * sp.cols > kMaxDescriptor)

@@ -19,6 +19,7 @@ struct StateDescriptors {
     std::vector<uint64_t> stampNSec; // one per descriptor, file order
     std::vector<double> desc;        // stampNSec.size() * D values
     int64_t n_nodes = 0;             // DataNodes seen (with or without descriptor)
+    std::vector<uint64_t> all_stampNSec; // stamp of EVERY DataNode that has one, file order: the keys of DataManager's data_map
     std::string error;               // non-empty on failure
 };
 

@@ -282,8 +282,14 @@ typedef struct {
     double  failure_probability; /* 0.01   theia::RansacParameters default */
     uint64_t seed;               /* counter-based sampler seed (Theia's is time-seeded => nondeterministic) */
     int32_t n_hypotheses;        /* 0 = adaptive reference mode */
-    int32_t reserved;
+    int32_t sampler;             /* CHIP_SAMPLER_*: which permutation the 15 / 10 sample indices of a hypothesis are drawn from (ABI 5) */
 } chip_ransac_params;
+/* CHIP_SAMPLER_FRESH (default): a fresh identity permutation per hypothesis -- hypotheses are independent and are generated on the
+ * device.  CHIP_SAMPLER_THEIA_PERSISTENT: theia::RandomSampler as written -- the permutation is initialised ONCE per estimation and
+ * every hypothesis continues on the array the previous one left (one theia::Ransac, hence one sampler, per PNP / P3P_ICP call:
+ * src/DlsPnpWithRansac.cpp:216-221, :95-100); the host sequences the swaps (S per hypothesis) and hands the kernels a sample table.
+ * Both modes use the same counter-based draws (Theia's own generator is time-seeded, i.e. not reproducible).                     */
+enum { CHIP_SAMPLER_FRESH = 0, CHIP_SAMPLER_THEIA_PERSISTENT = 1 };
 void chip_ransac_params_default(chip_ransac_params *p);
 
 typedef struct {

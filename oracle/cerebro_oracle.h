@@ -142,7 +142,9 @@ typedef struct {
     double  failure_probability; /* 0.01   theia default */
     uint64_t seed;
     int32_t n_hypotheses;        /* 0 = adaptive reference mode, >0 = fixed count, all scored */
-    int32_t reserved;
+    int32_t sampler;             /* 0 = fresh identity permutation per hypothesis (hypotheses independent: the default);
+                                    1 = theia::RandomSampler as written: ONE permutation, initialised once per estimation and carried
+                                    from hypothesis to hypothesis (DlsPnpWithRansac.cpp:216-221 constructs one Ransac, hence one sampler) */
 } orc_ransac_params;
 typedef struct {
     int32_t n_iterations, n_inliers, best_hypothesis, n_models;
@@ -151,6 +153,14 @@ typedef struct {
 
 uint64_t orc_rng_draw(uint64_t seed, uint32_t hyp, uint32_t draw);
 void   orc_ransac_sample(uint64_t seed, int32_t hyp, int32_t N, int32_t S, int32_t *out);
+/* theia::RandomSampler with its PERSISTENT permutation (Initialize once: 0..N-1; every Sample(): for i < S swap(idx[i],
+ * idx[RandInt(i, N-1)]), subset[i] = idx[i]), over the same counter-based draws: samples of hypotheses 0..H-1 -> out[H][S]. */
+void   orc_ransac_sample_persistent(uint64_t seed, int32_t H, int32_t N, int32_t S, int32_t *out);
+/* the hypothesis of a GIVEN sample (sample == NULL: orc_ransac_sample(seed, hyp, ...)); the linear form is keyed by (seed, hyp) */
+int    orc_pnp_hypothesis_sampled(const double *X, const double *uv, int32_t N, uint64_t seed, int32_t hyp, int32_t S,
+                                  const int32_t *sample, double T[16]);
+int    orc_icp_hypothesis_sampled(const double *A, const double *B, int32_t N, uint64_t seed, int32_t hyp, int32_t S,
+                                  const int32_t *sample, double T[16], double *scale_out);
 void   orc_dls_linear_form(uint64_t seed, int32_t hyp, double u[4]);
 double orc_reproj_error(const double *T_colmajor, const double *X, const double *uv);
 void   orc_score_model(const double *T_colmajor, const double *X, const double *uv, int32_t N, double thresh, int32_t use_mle,

@@ -16,6 +16,7 @@
 #include "cerebro_oracle.h"
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define JACOBI_SWEEPS 8
@@ -152,10 +153,17 @@ void orc_icp_score_model(const double *T, const double *A, const double *B, int3
 /* EstimateModel (DlsPnpWithRansac.h:121-150) on the hypothesis' sample.  Returns 1 and b_T_a (column-major) iff accepted. */
 int orc_icp_hypothesis(const double *A, const double *B, int32_t N, uint64_t seed, int32_t hyp, int32_t S, double T[16], double *scale_out)
 {
+    return orc_icp_hypothesis_sampled(A, B, N, seed, hyp, S, NULL, T, scale_out);
+}
+
+int orc_icp_hypothesis_sampled(const double *A, const double *B, int32_t N, uint64_t seed, int32_t hyp, int32_t S,
+                               const int32_t *sample_in, double T[16], double *scale_out)
+{
     int32_t sample[64];
     double sa[64 * 3], sb[64 * 3], R[9], t[3], s = 0.0;
     if (S > 64) S = 64;
-    orc_ransac_sample(seed, hyp, N, S, sample);
+    if (sample_in) memcpy(sample, sample_in, sizeof(int32_t) * (size_t)S);
+    else orc_ransac_sample(seed, hyp, N, S, sample);
     for (int i = 0; i < S; i++) {
         memcpy(sa + 3 * i, A + 3 * sample[i], 3 * sizeof(double));
         memcpy(sb + 3 * i, B + 3 * sample[i], 3 * sizeof(double));
@@ -194,10 +202,15 @@ int orc_icp_ransac(const double *A, const double *B, int32_t N, const orc_ransac
         if (p->min_inlier_ratio > 0)
             max_it = orc_ransac_max_iterations(S, p->min_inlier_ratio, log_fail, p->min_iterations, p->max_iterations);
     }
+    int32_t *table = NULL;   /* sampler mode 1: theia's persistent permutation (pnp_ransac.c orc_ransac_sample_persistent) */
+    if (p->sampler == 1) {
+        table = (int32_t *)malloc(sizeof(int32_t) * (size_t)max_it * (size_t)S);
+        orc_ransac_sample_persistent(p->seed, max_it, N, S, table);
+    }
     for (num_it = 0; num_it < max_it; num_it++) {
         double Th[16], cost;
         int32_t nin;
-        if (!orc_icp_hypothesis(A, B, N, p->seed, num_it, S, Th, NULL)) continue;
+        if (!orc_icp_hypothesis_sampled(A, B, N, p->seed, num_it, S, table ? table + (size_t)num_it * S : NULL, Th, NULL)) continue;
         n_models++;
         orc_icp_score_model(Th, A, B, N, p->error_thresh, p->use_mle, &cost, &nin, NULL);
         if (cost < best_cost) {
@@ -211,6 +224,7 @@ int orc_icp_ransac(const double *A, const double *B, int32_t N, const orc_ransac
             }
         }
     }
+    free(table);
     int32_t nin = 0;
     if (best_h >= 0) {
         double c;

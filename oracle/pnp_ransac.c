@@ -79,6 +79,25 @@ void orc_ransac_sample(uint64_t seed, int32_t hyp, int32_t N, int32_t S, int32_t
     free(idx);
 }
 
+/* theia::RandomSampler AS WRITTEN (sampler mode 1): the permutation is initialised once (Initialize: 0..N-1) and every Sample()
+ * continues on the array the previous one left -- which is what the reference runs, since StaticTheiaPoseCompute::PNP builds ONE
+ * theia::Ransac (hence one sampler) per estimation (DlsPnpWithRansac.cpp:216-221).  RandInt(i, N-1) = i + draw(hyp, i) % (N - i),
+ * the same counter-based draws as mode 0 (Theia's mt19937 is time-seeded).  Hypothesis h then depends on all earlier ones, so the
+ * device gets the table from the host; mode 0 stays the default because it lets hypotheses be generated independently. */
+void orc_ransac_sample_persistent(uint64_t seed, int32_t H, int32_t N, int32_t S, int32_t *out)
+{
+    int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)N);
+    for (int32_t i = 0; i < N; i++) idx[i] = i;
+    for (int32_t h = 0; h < H; h++)
+        for (int32_t i = 0; i < S; i++) {
+            uint64_t x = orc_rng_draw(seed, (uint32_t)h, (uint32_t)i);
+            int32_t j = i + (int32_t)(x % (uint64_t)(N - i));
+            int32_t t = idx[i]; idx[i] = idx[j]; idx[j] = t;
+            out[(size_t)h * S + i] = idx[i];
+        }
+    free(idx);
+}
+
 /* random linear form f0 = u0 + u1 s1 + u2 s2 + u3 s3, u_j uniform in (-100, 100) (Theia: 100*Vector4d::Random()) */
 void orc_dls_linear_form(uint64_t seed, int32_t hyp, double u[4])
 {
@@ -744,14 +763,14 @@ int orc_dls_pnp(const double *X, const double *uv, int32_t n, const double u[4],
 /* DlsPnpWithRansac::EstimateModel (DlsPnpWithRansac.h:48-72): accept iff exactly one solution; the accepted model is
  * b_T_a (column-major 4x4).  Returns 1 if a model was produced, else 0.  (The reference's success branch falls off a
  * non-void function, :62-68; its own test copy has `return true`, unittest_theia.cpp:84 -- restated as true.) */
-int orc_pnp_hypothesis(const double *X, const double *uv, int32_t N, uint64_t seed, int32_t hyp, int32_t S,
-                       double T[16], int32_t *sample_out)
+int orc_pnp_hypothesis_sampled(const double *X, const double *uv, int32_t N, uint64_t seed, int32_t hyp, int32_t S,
+                               const int32_t *sample_in, double T[16])
 {
     int32_t sample[64];
     double sx[64 * 3], suv[64 * 2], u[4], R[9], t[3];
     if (S > 64) S = 64;
-    orc_ransac_sample(seed, hyp, N, S, sample);
-    if (sample_out) memcpy(sample_out, sample, sizeof(int32_t) * (size_t)S);
+    if (sample_in) memcpy(sample, sample_in, sizeof(int32_t) * (size_t)S);
+    else orc_ransac_sample(seed, hyp, N, S, sample);
     for (int i = 0; i < S; i++) {
         memcpy(sx + 3 * i, X + 3 * sample[i], 3 * sizeof(double));
         memcpy(suv + 2 * i, uv + 2 * sample[i], 2 * sizeof(double));
@@ -766,6 +785,16 @@ int orc_pnp_hypothesis(const double *X, const double *uv, int32_t N, uint64_t se
     return 1;
 }
 
+int orc_pnp_hypothesis(const double *X, const double *uv, int32_t N, uint64_t seed, int32_t hyp, int32_t S,
+                       double T[16], int32_t *sample_out)
+{
+    int32_t sample[64];
+    if (S > 64) S = 64;
+    orc_ransac_sample(seed, hyp, N, S, sample);
+    if (sample_out) memcpy(sample_out, sample, sizeof(int32_t) * (size_t)S);
+    return orc_pnp_hypothesis_sampled(X, uv, N, seed, hyp, S, sample, T);
+}
+
 /* ================================================================ RANSAC driver (theia::Ransac::Estimate) */
 void orc_ransac_params_default(orc_ransac_params *p)
 {
@@ -778,7 +807,7 @@ void orc_ransac_params_default(orc_ransac_params *p)
     p->failure_probability = 0.01; /* theia::RansacParameters default */
     p->seed = 0x5EEDCE7EB80ULL;
     p->n_hypotheses = 0;
-    p->reserved = 0;
+    p->sampler = 0;
 }
 
 int32_t orc_ransac_max_iterations(int32_t S, double ratio, double log_fail, int32_t min_it, int32_t max_it)
@@ -810,10 +839,15 @@ int orc_pnp_ransac(const double *X, const double *uv, int32_t N, const orc_ransa
         if (p->min_inlier_ratio > 0)
             max_it = orc_ransac_max_iterations(S, p->min_inlier_ratio, log_fail, p->min_iterations, p->max_iterations);
     }
+    int32_t *table = NULL;   /* sampler mode 1: the samples of hypotheses 0..max_it-1 of the ONE persistent permutation */
+    if (p->sampler == 1) {
+        table = (int32_t *)malloc(sizeof(int32_t) * (size_t)max_it * (size_t)S);
+        orc_ransac_sample_persistent(p->seed, max_it, N, S, table);
+    }
     for (num_it = 0; num_it < max_it; num_it++) {
         double Th[16], cost;
         int32_t nin;
-        if (!orc_pnp_hypothesis(X, uv, N, p->seed, num_it, S, Th, NULL)) continue;
+        if (!orc_pnp_hypothesis_sampled(X, uv, N, p->seed, num_it, S, table ? table + (size_t)num_it * S : NULL, Th)) continue;
         n_models++;
         orc_score_model(Th, X, uv, N, p->error_thresh, p->use_mle, &cost, &nin, NULL);
         if (cost < best_cost) { /* strict: first best wins */
@@ -827,6 +861,7 @@ int orc_pnp_ransac(const double *X, const double *uv, int32_t N, const orc_ransa
             }
         }
     }
+    free(table);
     int32_t nin = 0;
     if (best_h >= 0) {
         double c;

@@ -269,7 +269,7 @@ class OrcRansacParams(C.Structure):
     _fields_ = [("error_thresh", C.c_double), ("min_inlier_ratio", C.c_double), ("max_iterations", C.c_int32),
                 ("min_iterations", C.c_int32), ("use_mle", C.c_int32), ("sample_size", C.c_int32),
                 ("failure_probability", C.c_double), ("seed", C.c_uint64), ("n_hypotheses", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("sampler", C.c_int32)]
 
 
 class OrcRansacSummary(C.Structure):
@@ -315,6 +315,16 @@ def ransac_params(**kw) -> OrcRansacParams:
     for k, v in kw.items():
         setattr(p, k, v)
     return p
+
+
+def ransac_sample_persistent(seed, H, N, S=15):
+    """theia::RandomSampler's persistent permutation: the samples of hypotheses 0..H-1 -> [H, S]"""
+    lib = _bind_pnp()
+    lib.orc_ransac_sample_persistent.restype = None
+    lib.orc_ransac_sample_persistent.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    out = np.empty((H, S), dtype=np.int32)
+    lib.orc_ransac_sample_persistent(seed, H, N, S, _p(out))
+    return out
 
 
 def ransac_sample(seed, hyp, N, S=15):

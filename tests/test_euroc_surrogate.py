@@ -76,7 +76,10 @@ def test_merged_fixture_is_consistent():
         assert c["time_sec_a"] > c["time_sec_b"] and c["score"] > 0.85 and c["global_a"] > c["global_b"]
 
 
-def write_stream(path, run):
+def write_stream(path, run, frames="FRMS"):
+    """+ the frames of the run, so that the replay's dump carries the reference's global_a / global_b (index into the map of ALL
+    camera frames, Cerebro.cpp:1142-1143): as the stamp of every frame (FRMS: what DataManager's data_map holds) or as a row -> frame
+    index table (FIDX)."""
     db = run["db"]
     N, D = db.shape
     with open(path, "wb") as f:
@@ -84,6 +87,12 @@ def write_stream(path, run):
         f.write(np.asarray(run["stamps"], dtype=np.uint32).tobytes())
         f.write(db.tobytes())
         f.write(np.asarray(run["ticks"], dtype=np.int64).tobytes())
+        if frames == "FRMS":
+            ns = E.plan(run["variant"], run["seed"])["stamps_ns"]
+            st = np.stack([ns // 10**9, ns % 10**9], axis=1).astype(np.uint32)
+            f.write(b"FRMS" + struct.pack("<Q", len(st)) + st.tobytes())
+        elif frames == "FIDX":
+            f.write(b"FIDX" + struct.pack("<Q", N) + np.asarray(run["frame_idx"], dtype=np.int64).tobytes())
 
 
 @pytest.mark.gpu
@@ -96,7 +105,7 @@ def test_gpu_replay_selects_the_recorded_reference_run(tmp_path, name, devices):
     g = json.loads((GOLD / f"euroc_surrogate_{name}.json").read_text())
     run = get_run(name)
     assert run["sha256"] == g["descriptors_sha256"] and run["ticks_sha256"] == g["ticks_sha256"]
-    write_stream(tmp_path / "s.bin", run)
+    write_stream(tmp_path / "s.bin", run, "FIDX" if devices else "FRMS")
     cmd = [str(LIB / "cerebro_replay")] + (["--devices", devices] if devices else []) + [str(tmp_path / "s.bin"), str(tmp_path / "ours.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -105,6 +114,8 @@ def test_gpu_replay_selects_the_recorded_reference_run(tmp_path, name, devices):
                        capture_output=True, text=True)
     rep = json.loads(r.stdout)
     assert r.returncode == 0 and rep["identical_selection"] and rep["n_reference"] == rep["n_candidate"] == len(g["loopcandidates_liverun"]), rep
+    # the strict form: EVERY field of the recorded dump, global_a / global_b (indices into the map of all frames) included
+    assert rep["identical_dump"] is True and rep["global_index_mismatches"] == 0 and rep["global_index_compared"] == len(g["loopcandidates_liverun"]), rep
     assert rep["max_abs_score_diff"] < 6.4e-14
     ours = json.loads((tmp_path / "ours.json").read_text())
     assert [float(c["score"]).hex() for c in ours] == g["tree_order_scores_hex"]

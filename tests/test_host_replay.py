@@ -79,8 +79,31 @@ def test_replay_matches_oracle(tmp_path, devices):
         assert g["time_double_a"] == pytest.approx(w["time_sec_a"] + 1e-9 * w["time_nsec_a"])
     # the one-command check for whoever holds a recorded run of the reference: its dump vs ours
     (tmp_path / "liverun.json").write_text(json.dumps([dict(w, time_double_a=0.0, time_double_b=0.0, global_a=0, global_b=0) for w in want], indent=4))
-    r = subprocess.run([str(LIB / "cerebro_replay"), "--compare", str(tmp_path / "liverun.json"), str(tmp_path / "o.json")], capture_output=True, text=True)
+    # (this stream carries no frame list: the dump's global_a / global_b are DB rows, so only the SELECTION is compared)
+    r = subprocess.run([str(LIB / "cerebro_replay"), "--compare-selection", str(tmp_path / "liverun.json"), str(tmp_path / "o.json")], capture_output=True, text=True)
     assert r.returncode == 0 and json.loads(r.stdout)["identical_selection"], r.stdout + r.stderr
+    # ... and with the frames known (every 20 Hz keyframe is every 2nd camera frame of a 40 Hz stream: data_map index = 2 x row) the
+    # dump carries the reference's global_a / global_b (Cerebro.cpp:1142-1143) and the strict form passes, by either trailer
+    for trailer in ("FRMS", "FIDX"):
+        with open(tmp_path / "s2.bin", "wb") as f:
+            f.write((tmp_path / "s.bin").read_bytes())
+            if trailer == "FRMS":
+                frames = []
+                for (sec, nsec) in stamps:
+                    frames += [(sec, nsec), (sec, nsec + 25_000_000)]
+                f.write(b"FRMS" + struct.pack("<Q", len(frames)) + np.asarray(frames, dtype=np.uint32).tobytes())
+            else:
+                f.write(b"FIDX" + struct.pack("<Q", N) + (2 * np.arange(N, dtype=np.int64)).tobytes())
+        r = subprocess.run([str(LIB / "cerebro_replay")] + (["--devices", devices] if devices else []) + [str(tmp_path / "s2.bin"), str(tmp_path / "o2.json")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        (tmp_path / "liverun2.json").write_text(json.dumps([dict(w, time_double_a=0.0, time_double_b=0.0, global_a=2 * w["global_a"], global_b=2 * w["global_b"])
+                                                            for w in want], indent=4))
+        r = subprocess.run([str(LIB / "cerebro_replay"), "--compare", str(tmp_path / "liverun2.json"), str(tmp_path / "o2.json")], capture_output=True, text=True)
+        j = json.loads(r.stdout)
+        assert r.returncode == 0 and j["identical_dump"] and j["global_index_mismatches"] == 0 and j["global_index_compared"] == len(want), (trailer, j)
+        r = subprocess.run([str(LIB / "cerebro_replay"), "--compare", str(tmp_path / "liverun2.json"), str(tmp_path / "o.json")], capture_output=True, text=True)
+        assert r.returncode == 1 and json.loads(r.stdout)["global_index_mismatches"] > 0        # rows are not data_map indices
 
 
 def test_compare_recorded_reference_run(tmp_path):
@@ -94,16 +117,25 @@ def test_compare_recorded_reference_run(tmp_path):
         ref.append({"time_sec_a": sa, "time_nsec_a": na, "time_sec_b": sb, "time_nsec_b": nb, "time_double_a": sa + 1e-9 * na,
                     "time_double_b": sb + 1e-9 * nb, "global_a": 4000 + 7 * i, "global_b": 100 + i, "score": float(rng.uniform(0.86, 0.99))})
 
-    def run(a, b):
+    def run(a, b, mode="--compare-selection"):
         (tmp_path / "ref.json").write_text(a if isinstance(a, str) else json.dumps(a, indent=4))
         (tmp_path / "ours.json").write_text(b if isinstance(b, str) else json.dumps(b, separators=(",", ":")))
-        r = subprocess.run([str(LIB / "cerebro_replay"), "--compare", str(tmp_path / "ref.json"), str(tmp_path / "ours.json")], capture_output=True, text=True)
+        r = subprocess.run([str(LIB / "cerebro_replay"), mode, str(tmp_path / "ref.json"), str(tmp_path / "ours.json")], capture_output=True, text=True)
         return r.returncode, (json.loads(r.stdout) if r.stdout.strip() else r.stderr)
 
     ours = [dict(c, global_a=c["global_a"] // 7, global_b=c["global_b"] - 100, score=c["score"] * (1 + 2e-16)) for c in ref]   # other index space, last-bit scores
     rc, j = run(ref, ours)
     assert rc == 0 and j["identical_selection"] and j["n_reference"] == j["n_candidate"] == j["matched_prefix"] == 40
     assert 0 < j["max_abs_score_diff"] < 1e-15
+    # the strict form (every field of a genuine loopcandidates_liverun.json): another index space does not pass, the same one does
+    rc, j = run(ref, ours, "--compare")
+    assert rc == 1 and j["identical_selection"] and not j["identical_dump"] and j["global_index_mismatches"] == 40
+    same_space = [dict(c, score=c["score"] * (1 + 2e-16)) for c in ref]
+    rc, j = run(ref, same_space, "--compare")
+    assert rc == 0 and j["identical_dump"] and j["global_index_compared"] == 40 and j["global_index_mismatches"] == 0
+    same_space[3]["global_b"] += 1
+    rc, j = run(ref, same_space, "--compare")
+    assert rc == 1 and j["global_index_mismatches"] == 1
     bad = [dict(c) for c in ours]
     bad[17]["time_nsec_b"] += 50_000_000                       # a neighbouring keyframe was selected
     rc, j = run(ref, bad)
@@ -233,14 +265,33 @@ def test_state_json_untrusted_input(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("D,N,devices", [(1024, 700, None), (256, 4600, "0,0,0")])
-def test_cold_start_from_state_json_matches_oracle(tmp_path, D, N, devices):
+@pytest.mark.parametrize("D,N,devices,gaps", [(1024, 700, None, False), (256, 4600, "0,0,0", False), (512, 900, None, True)])
+def test_cold_start_from_state_json_matches_oracle(tmp_path, D, N, devices, gaps):
     """--devices + a checkpoint longer than the replicated ring (CHIP_RING_ROWS = 4096): after the cold start the schedule starts at
     l = 56, 4500 rows behind the append head -- those ticks fetch their query rows from the sub-contexts that own them."""
     plants, loops, ties = scenarios.loop_plants(N, 4, seed=8)
     db = scenarios.build_db(19, N, D, plants)
-    stamps = [1403636579_000000000 + i * 50_000_000 for i in range(N)]
-    write_state_json(tmp_path / "state.json", db, stamps)
+    node_of_row = list(range(N))
+    if gaps:
+        # a checkpoint holds a node for EVERY camera frame; only keyframes carry a descriptor (here: two descriptor-less frames after
+        # every third keyframe).  global_a / global_b of the dump are then the NODE index (= the reference's data_map index,
+        # Cerebro.cpp:1142-1143), not the DB row.
+        node_of_row, k = [], 0
+        for i in range(N):
+            node_of_row.append(k)
+            k += 3 if i % 3 == 2 else 1
+        n_nodes = k
+        full = np.zeros((n_nodes, D), dtype=db.dtype)
+        has = [False] * n_nodes
+        for i, nd in enumerate(node_of_row):
+            full[nd] = db[i]
+            has[nd] = True
+        node_stamps = [1403636579_000000000 + i * 50_000_000 for i in range(n_nodes)]
+        write_state_json(tmp_path / "state.json", full, node_stamps, has)
+        stamps = [node_stamps[nd] for nd in node_of_row]
+    else:
+        stamps = [1403636579_000000000 + i * 50_000_000 for i in range(N)]
+        write_state_json(tmp_path / "state.json", db, stamps)
     r = subprocess.run([str(LIB / "cerebro_replay")] + (["--devices", devices] if devices else []) +
                        ["--state", str(tmp_path / "state.json"), str(tmp_path / "o.json")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -250,9 +301,10 @@ def test_cold_start_from_state_json_matches_oracle(tmp_path, D, N, devices):
     for l in range(56, N + 1, 3):
         o = orc.tick(l)
         if o["found"]:
-            want.append((o["idx_curr"], o["idx_prev"], o["score"]))
+            want.append((node_of_row[o["idx_curr"]], node_of_row[o["idx_prev"]], o["score"]))
     assert [(g["global_a"], g["global_b"], g["score"]) for g in got] == want and len(want) >= len(loops)
-    assert got[0]["time_sec_a"] == stamps[want[0][0]] // 10**9 and got[0]["time_nsec_a"] == stamps[want[0][0]] % 10**9
+    row0 = node_of_row.index(want[0][0])
+    assert got[0]["time_sec_a"] == stamps[row0] // 10**9 and got[0]["time_nsec_a"] == stamps[row0] % 10**9
 
 
 # ------------------------------------------------------------------ N4: top-k candidate policies over the C ABI

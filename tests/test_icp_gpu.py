@@ -83,3 +83,14 @@ def test_enqueue_collect_equals_the_blocking_call_and_overlaps_pnp():
         with pytest.raises(capi.ChipError):                      # nothing pending any more
             chip.icp_ransac_collect(n)
         assert chip.icp_ransac(A, B, p)["summary"] == want["summary"]
+
+
+@pytest.mark.parametrize("N,outl,noise,seed", [(20, 0.0, 0.0, 1), (400, 0.25, 0.02, 11), (3001, 0.3, 0.02, 5)])
+def test_theia_persistent_sampler_mode(N, outl, noise, seed):
+    """The ICP estimator under theia::RandomSampler's persistent permutation (P3P_ICP builds one theia::Ransac per call,
+    DlsPnpWithRansac.cpp:95-100): the host-sequenced sample table through icp_models, bit for bit the oracle's sampler mode 1."""
+    A, B, T, inl = make_icp_scene(N=N, outlier_frac=outl, noise=noise, seed=seed)
+    with capi.Chip(64) as chip:
+        check(chip, A, B, seed=seed, sampler=capi.CHIP_SAMPLER_THEIA_PERSISTENT)
+        check(chip, A, B, seed=seed + 3, n_hypotheses=300, sampler=1)
+        check(chip, A, B, seed=seed + 3, n_hypotheses=300)

@@ -277,3 +277,24 @@ def test_dls_solutions_are_stationary_points_of_the_least_squares_cost(seed):
         g = np.array([(Jp(s0 + h * e) - Jp(s0 - h * e)) / (2 * h) for e in np.eye(3)])
         curv = max(abs(Jp(s0 + 1e-2 * e) + Jp(s0 - 1e-2 * e) - 2 * Jp(s0)) / 1e-4 for e in np.eye(3))   # second-derivative scale
         assert np.abs(g).max() <= 1e-6 * max(curv, 1e-12), (g, curv)          # gradient vanishes relative to the curvature
+
+
+def test_persistent_sampler_is_theias_random_sampler():
+    """Sampler mode 1 = theia::RandomSampler as written: Initialize() fills 0..N-1 ONCE; every Sample() does, for i < S,
+    swap(idx[i], idx[RandInt(i, N-1)]) on the array the previous call left and returns idx[:S].  Restated here in plain Python over
+    the same counter-based draws; hypothesis 0 coincides with the fresh-permutation mode, later ones in general do not."""
+    lib = O._bind_pnp()
+    for seed, N, S, H in ((7, 40, 15, 60), (1234567, 512, 15, 50), (3, 20, 10, 30), (99, 16, 15, 8)):
+        idx = list(range(N))
+        want = []
+        for h in range(H):
+            for i in range(S):
+                j = i + int(lib.orc_rng_draw(seed, h, i) % (N - i))
+                idx[i], idx[j] = idx[j], idx[i]
+            want.append(idx[:S])
+        got = O.ransac_sample_persistent(seed, H, N, S)
+        assert got.tolist() == want
+        assert got[0].tolist() == O.ransac_sample(seed, 0, N, S).tolist()
+        assert all(len(set(r)) == S and min(r) >= 0 and max(r) < N for r in want)
+        if N > 2 * S:
+            assert any(got[h].tolist() != O.ransac_sample(seed, h, N, S).tolist() for h in range(1, H))

@@ -95,6 +95,12 @@ def test_persistent_permutation_sampler_departure():
             assert (fresh is None) == (o["summary"]["best_hypothesis"] < 0) and it_f == o["summary"]["n_iterations"]
             if fresh is not None:
                 assert np.array_equal(fresh[2], o["mask"]) and rel_frob(fresh[0], o["T"]) < 1e-12
+            # ... and the persistent-permutation python driver IS the oracle's sampler mode 1 (round 5: theia::RandomSampler as
+            # written is a selectable mode of oracle and kernels, DlsPnpWithRansac.cpp:216-221)
+            o1 = O.pnp_ransac(X, uv, O.ransac_params(seed=seed, sampler=1))
+            assert (pers is None) == (o1["summary"]["best_hypothesis"] < 0) and it_p == o1["summary"]["n_iterations"]
+            if pers is not None:
+                assert np.array_equal(pers[2], o1["mask"]) and rel_frob(pers[0], o1["T"]) < 1e-12
             rows.append((fresh is not None, pers is not None, it_f, it_p,
                          rel_frob(fresh[0], T) if fresh else np.nan, rel_frob(pers[0], T) if pers else np.nan,
                          fresh[1] / X.shape[0] if fresh else 0.0, pers[1] / X.shape[0] if pers else 0.0))

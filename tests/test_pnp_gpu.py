@@ -152,3 +152,32 @@ def test_back_substitution_forms_agree():
     r = subprocess.run([sys.executable, str(root / "scripts" / "gpu_pnp_fuzz.py"), "36"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert "TEST KNOB ACTIVE: CHIP_PNP_BACKSUB=loop" in r.stderr, r.stderr[-400:]
     assert "fuzz: 0 mismatches" in r.stdout, (r.stdout[-400:], r.stderr[-400:])
+
+
+@pytest.mark.parametrize("N,outl,noise,seed", [(20, 0.0, 0.0, 1), (100, 0.3, 0.5, 3), (512, 0.3, 0.5, 4242), (3000, 0.2, 0.5, 6)])
+def test_theia_persistent_sampler_mode(N, outl, noise, seed):
+    """CHIP_SAMPLER_THEIA_PERSISTENT (round 5): theia::RandomSampler as written -- one permutation per estimation, carried from
+    hypothesis to hypothesis (one theia::Ransac per PNP call, DlsPnpWithRansac.cpp:216-221).  The host sequences the swaps, the
+    kernels read the table: same parity bar as the default mode, in every RANSAC mode and through the batched entry point."""
+    X, uv, T, inl = M.make_scene(N=N, outlier_frac=outl, noise_px=noise, seed=seed)
+    with capi.Chip(256) as chip:
+        g1, o1 = check_against_oracle(chip, X, uv, seed=seed, sampler=capi.CHIP_SAMPLER_THEIA_PERSISTENT)
+        check_against_oracle(chip, X, uv, seed=seed + 100, n_hypotheses=200, sampler=1)
+        check_against_oracle(chip, X, uv, seed=seed, use_mle=0, n_hypotheses=64, sampler=1)
+        g0, o0 = check_against_oracle(chip, X, uv, seed=seed + 100, n_hypotheses=200)          # the default mode is untouched by a table left behind
+        if N >= 100:    # different samples from hypothesis 1 on: the two modes are different estimations of the same scene
+            a = O.pnp_ransac(X, uv, O.ransac_params(seed=seed + 100, n_hypotheses=200, sampler=1))
+            assert a["summary"]["best_hypothesis"] != o0["summary"]["best_hypothesis"] or not np.array_equal(a["T"], o0["T"])
+        # batched: two problems of different size, own seeds, own permutations
+        X2, uv2, _, _ = M.make_scene(N=max(20, N // 2), outlier_frac=outl, noise_px=noise, seed=seed + 1)
+        p = gparams(n_hypotheses=96, sampler=1)
+        rs = chip.pnp_ransac_batch([(X, uv), (X2, uv2)], p, seeds=[seed, seed + 7])
+        for (Xi, uvi), sd, r in zip(((X, uv), (X2, uv2)), (seed, seed + 7), rs):
+            o = O.pnp_ransac(Xi, uvi, O.ransac_params(n_hypotheses=96, seed=sd, sampler=1))
+            assert r["summary"]["best_hypothesis"] == o["summary"]["best_hypothesis"] and np.array_equal(r["mask"], o["mask"])
+            if o["summary"]["best_hypothesis"] >= 0:
+                assert np.array_equal(r["T"].view(np.uint64), o["T"].view(np.uint64))
+        p.sampler = 7
+        with pytest.raises(capi.ChipError) as ei:
+            chip.pnp_ransac(X, uv, p)
+        assert ei.value.status == capi.CHIP_ERR_UNSUPPORTED
