@@ -537,6 +537,13 @@ int tick_collect_slot(Ctx *c, Slot &s, chip_tick_result *out)
         // enqueued (and may succeed) meanwhile: its commit of last_l stands, exactly as if the reference's sequential loop had
         // skipped the failed pass and run the next one.
         if (s.last_l_ptr && *s.last_l_ptr == s.tick_l) *s.last_l_ptr = s.prev_last_l;
+        else if (s.last_l_ptr) {
+            // A newer tick was enqueued on top of this failed one.  Should IT fail too, it must not roll back to this tick's l (a pass
+            // that never reached :1098): hand it this tick's predecessor instead, so that a run of failed ticks unwinds to the last_l
+            // of the newest tick that did not fail.  The successor is the in-flight slot whose prev_last_l is this l.
+            for (Slot &o : c->slots)
+                if (&o != &s && o.in_flight && o.last_l_ptr == s.last_l_ptr && o.prev_last_l == s.tick_l) o.prev_last_l = s.prev_last_l;
+        }
         fill_immediate(out, CHIP_TICK_FAILED);
         return CHIP_ERR_SHARD_FAILED;
     }

@@ -1477,7 +1477,7 @@ struct EigArgs {
     int32_t slot0, pad2_;
     double thresh;
     int32_t use_mle;
-    const double *Sg;       // [H][729]
+    double *Sg;             // [H][729]  in: the action matrices; scratch of the loop-form back-substitution afterwards
     const double *Tg;       // [H][27]
     const int32_t *sample;  // [H][kSampleMax]
     const int32_t *ok;      // [H]
@@ -1494,7 +1494,13 @@ struct EigArgs {
 };
 
 #define HH(i, j) Hs[(i) * EN + (j)]
-#define VV(i, j) Vs[(i) * EN + (j)]
+// Of the accumulated transformation V only the rows of the monomials {1, s3, s2, s1} are ever read back (the back-transform of the
+// eigenvectors), the QR iteration updates V row by row (a column operation never mixes rows), and ortran -- which does mix rows --
+// works on one column per lane: so V lives in REGISTERS during ortran (vcol[i] of lane j = V(i, j)) and only those four rows exist
+// in LDS afterwards (round 5: 13.25 -> 8.4 KiB of LDS per wave, 12 -> 16 waves per CU when many problems are batched).
+constexpr int kVRows = 4;
+__device__ constexpr int kVRow[kVRows] = {0, 1, 3, 9};
+#define V4(r, j) Vs4[(r) * EN + (j)]
 
 // pnp_eig_score is ONE wave per workgroup: the LDS unit executes a wave's DS instructions in issue order, so a write by any lane
 // is visible to a later read by any lane of the same wave without waiting for the write to complete.  What the code needs
@@ -1583,7 +1589,7 @@ __device__ __forceinline__ void orthes_step(double *Hs, double *us, double *ortm
     }
 }
 template <int M>
-__device__ __forceinline__ void ortran_step(double *Hs, double *Vs, double *us, const double *ortm, int lane)
+__device__ __forceinline__ void ortran_step(double *Hs, double (&vcol)[EN], double *us, const double *ortm, int lane)
 {
     constexpr int L = EN - M, high = EN - 1;
     const double hmm = HH(M, M - 1);
@@ -1592,16 +1598,17 @@ __device__ __forceinline__ void ortran_step(double *Hs, double *Vs, double *us, 
         // u = (ort[M], H(M+1, M-1), .., H(high, M-1)) staged contiguously for the broadcast reads
         if (lane >= M && lane <= high) us[lane] = (lane == M) ? om : HH(lane, M - 1);
         WAVE_SYNC();
-        if (lane >= M && lane <= high) {
-            double b[L];
+        // column j = lane of V, rows M..26, in the lane's own registers: the arithmetic runs on every lane (lanes outside M..26 hold
+        // columns the reflector does not touch: their result is discarded by the select), no LDS traffic but the broadcast reads of u
+        const bool mine = lane >= M && lane <= high;
+        double g = 0.0;
 #pragma unroll
-            for (int t = 0; t < L; t++) b[t] = VV(M + t, lane);
-            double g = 0.0;
+        for (int t = 0; t < L; t++) g = g + us[M + t] * vcol[M + t];
+        g = (g / om) / hmm;
 #pragma unroll
-            for (int t = 0; t < L; t++) g = g + us[M + t] * b[t];
-            g = (g / om) / hmm;
-#pragma unroll
-            for (int t = 0; t < L; t++) VV(M + t, lane) = b[t] + g * us[M + t];
+        for (int t = 0; t < L; t++) {
+            const double nv = vcol[M + t] + g * us[M + t];
+            vcol[M + t] = mine ? nv : vcol[M + t];
         }
         WAVE_SYNC();
     }
@@ -1613,10 +1620,10 @@ struct HessenbergSteps {
         orthes_step<M>(Hs, us, ortm, lane);
         if constexpr (M < EN - 2) HessenbergSteps<M + 1>::orthes(Hs, us, ortm, lane);
     }
-    static __device__ __forceinline__ void ortran(double *Hs, double *Vs, double *us, const double *ortm, int lane)
+    static __device__ __forceinline__ void ortran(double *Hs, double (&vcol)[EN], double *us, const double *ortm, int lane)
     {
-        ortran_step<M>(Hs, Vs, us, ortm, lane);
-        if constexpr (M > 1) HessenbergSteps<M - 1>::ortran(Hs, Vs, us, ortm, lane);
+        ortran_step<M>(Hs, vcol, us, ortm, lane);
+        if constexpr (M > 1) HessenbergSteps<M - 1>::ortran(Hs, vcol, us, ortm, lane);
     }
 };
 
@@ -1641,8 +1648,29 @@ struct BackSubRow {
         const double ww = HH(I, I) - pe;
         double rr = 0.0;
         if (!((neg_mask >> (I + 1)) & 1u)) rr = rr + HH(I, I + 1) * x[I + 1];   // row I + 1 solved in its own step
+        // terms j = I + 2 .. 26 in the reference's order, the broadcast reads of H(I, j) software-pipelined in groups of kG: group g + 1
+        // is in flight underneath the arithmetic of group g.  (Left to itself hipcc hoists ALL reads of a row in front of its chain --
+        // up to 50 registers next to the 54 of x -- which no longer fits once the kernel is held to 128 VGPRs = 4 waves per SIMD.)
+        {
+            constexpr int kG = 6, J0 = I + 2, NT = EN - J0, NG = (NT + kG - 1) / kG;
+            double hb[2][kG];
+            if constexpr (NT > 0) {
 #pragma unroll
-        for (int j = I + 2; j < EN; j++) rr = rr + HH(I, j) * x[j];
+                for (int t = 0; t < kG; t++) hb[0][t] = (t < NT) ? HH(I, J0 + t) : 0.0;
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    if (g + 1 < NG) {
+#pragma unroll
+                        for (int t = 0; t < kG; t++) hb[(g + 1) & 1][t] = ((g + 1) * kG + t < NT) ? HH(I, J0 + (g + 1) * kG + t) : 0.0;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < kG; t++)
+                        if (g * kG + t < NT) rr = rr + hb[g & 1][t] * x[J0 + g * kG + t];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
         const bool act = real_root && lane > I;
         bool big = false;
         if ((neg_mask >> I) & 1u) { zz = ww; ss = rr; }
@@ -1673,7 +1701,7 @@ struct BackSubRow {
 // read back), 2 row modification, 3 column modification + forwarding, 4 number of double-shift steps, 5 number of sweeps,
 // 6 Hessenberg reduction + accumulation, 7 whole kernel.  The stamps themselves cost ~10 % (s_memtime + lgkmcnt wait each).
 template <bool STAMP>
-__global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void pnp_eig_score(EigArgs a)
 {
     unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = 0, t_start = 0;
@@ -1689,7 +1717,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     // H sits 28 doubles (one row + one element) into its allocation: qr_sweep_head_asm addresses every operand of lane i relative to
     // &H(i-1, i-1), which for lane 0 lies 224 bytes in front of H -- inside this pad, not below LDS address 0 (no address wrap-around;
     // the pad's content is never used: lane 0's H(-1,-1) / H(0,-1) only feed a comparison whose result is overridden)
-    __shared__ double HsPad[28 + EN * EN], Vs[EN * EN];
+    __shared__ double HsPad[28 + EN * EN], Vs4[kVRows * EN];
     double *const Hs = HsPad + 28;
     __shared__ double ortm[EN], wr[EN], wi[EN], Tf[27], sxs[kSampleMax * 3], model[16];
     __shared__ __attribute__((aligned(16))) double us[EN + 5];   // the current Householder vector (orthes / ortran)
@@ -1703,7 +1731,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
         if (lane == 0) { a.valid[hyp] = 0; a.nsol[hyp] = -1; a.nin[hyp] = 0; a.cost[hyp] = INFINITY; }
         return;
     }
-    for (int e = lane; e < EN * EN; e += 64) { Hs[e] = a.Sg[(size_t)hyp * 729 + e]; Vs[e] = ((e / EN) == (e % EN)) ? 1.0 : 0.0; }
+    for (int e = lane; e < EN * EN; e += 64) Hs[e] = a.Sg[(size_t)hyp * 729 + e];
     if (lane < 27) Tf[lane] = a.Tg[hyp * 27 + lane];
     if (lane < a.S) {
         const int s = a.sample[hyp * kSampleMax + lane];
@@ -1717,8 +1745,6 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
     // broadcasts, four terms ahead of the arithmetic (dot_desc / dot_asc / axpy_rows above).  Term order is the reference's.
 #ifndef CHIP_PNP_HESS_LOOPED
     HessenbergSteps<1>::orthes(Hs, us, ortm, lane);
-    // accumulate the reflectors into V (ortran)
-    HessenbergSteps<EN - 2>::ortran(Hs, Vs, us, ortm, lane);
 #else
     for (int m = low + 1; m <= high - 1; m++) {
         // scale = sum_{i = m..high} |H(i, m-1)|, ascending: every lane runs the same chain on broadcast reads of the column
@@ -1762,24 +1788,17 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             WAVE_SYNC();
         }
     }
-    // accumulate the reflectors into V (ortran)
-    for (int m = high - 1; m >= low + 1; m--) {
-        const double hmm = HH(m, m - 1);
-        if (hmm != 0.0) {
-            const double om = ortm[m];
-            // u = (ort[m], H(m+1, m-1), .., H(high, m-1)) staged contiguously for the broadcast reads
-            if (lane >= m && lane <= high) us[lane] = (lane == m) ? om : HH(lane, m - 1);
-            WAVE_SYNC();
-            if (lane >= m && lane <= high) {
-                double *colj = &VV(0, lane);
-                double g = dot_asc<EN>(us, colj, m, high);
-                g = (g / om) / hmm;
-                axpy_rows<EN>(us, colj, g, m, high);
-            }
-            WAVE_SYNC();
+#endif
+    {   // accumulate the reflectors into V (ortran): column `lane` of V in registers, then the four rows that are read back -> LDS
+        double vcol[EN];
+#pragma unroll
+        for (int i = 0; i < EN; i++) vcol[i] = (i == lane) ? 1.0 : 0.0;
+        HessenbergSteps<EN - 2>::ortran(Hs, vcol, us, ortm, lane);
+        if (lane < EN) {
+#pragma unroll
+            for (int rr = 0; rr < kVRows; rr++) V4(rr, lane) = vcol[kVRow[rr]];
         }
     }
-#endif
     for (int e = lane; e < EN * EN; e += 64) {
         const int i = e / EN, j = e % EN;
         if (j < i - 1) Hs[e] = 0.0;
@@ -1854,11 +1873,11 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                     HH(n - 1, j) = q * zz + p * HH(n, j);
                     HH(n, j) = q * HH(n, j) - p * zz;
                 }
-                if (lane >= 32 && lane - 32 <= high) {  // accumulate (independent of H)
+                if (lane >= 32 && lane - 32 < kVRows) {  // accumulate (independent of H): the four rows of V that are kept
                     const int i = lane - 32;
-                    const double zz = VV(i, n - 1);
-                    VV(i, n - 1) = q * zz + p * VV(i, n);
-                    VV(i, n) = q * VV(i, n) - p * zz;
+                    const double zz = V4(i, n - 1);
+                    V4(i, n - 1) = q * zz + p * V4(i, n);
+                    V4(i, n) = q * V4(i, n) - p * zz;
                 }
                 WAVE_SYNC();
                 if (lane <= n) {  // columns n-1, n
@@ -1943,8 +1962,10 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             // through v_readlane instead of an LDS write -> barrier -> read.
             PNP_STAMP(0);
             if constexpr (STAMP) clk[5] += 1;
-            double *const Abase = (lane < 32) ? Hs : Vs;     // lanes 0..26 work on H, lanes 32..58 on V
-            const int arow = (lane < 32) ? lane : lane - 32;
+            double *const Abase = (lane < 32) ? Hs : Vs4;    // lanes 0..26 work on H, lanes 32..35 on the four kept rows of V
+            // (idle lanes -- 27..31, 36..63 -- read a row that exists, EN - 1 resp. 0, and store nothing: with V down to four rows the
+            //  "row 27..31 of their matrix" they used to touch would lie past the workgroup's LDS allocation)
+            const int arow = (lane < 32) ? (lane < EN ? lane : EN - 1) : (lane - 32 < kVRows ? lane - 32 : 0);
             bool fwd = false;
             double fp = 0.0, fq = 0.0, fr = 0.0;
             // One double-shift step.  NOTLAST (k != n-1: the reflector spans three rows) is a compile-time flag: with a run-time one
@@ -1956,7 +1977,7 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             // Per-lane activity limit of the column modification, once per sweep: H lanes (< 32) work on rows arow <= min(n, k + 3), i.e.
             // "arow <= n and arow - 3 <= k"; V lanes 32..58 always; lanes 27..31 / 59..63 never.  One v_cmp per step instead of
             // s_min / v_mov / v_cndmask / v_cmp (round 4: the step is bound by its instruction COUNT, ~8.5 cycles each for a lone wave).
-            const int col_lim = (lane < 32) ? ((lane <= n && lane < EN) ? lane - 3 : 0x7fffffff) : ((lane - 32 <= high) ? -0x7fffffff : 0x7fffffff);
+            const int col_lim = (lane < 32) ? ((lane <= n && lane < EN) ? lane - 3 : 0x7fffffff) : ((lane - 32 < kVRows) ? -0x7fffffff : 0x7fffffff);
             auto qr_step = [&](int k, auto notlast_tag) {
                 constexpr bool NOTLAST = decltype(notlast_tag)::value;
                 double pk = p, qk = q, rk = r;   // (k == m: from the m search)
@@ -2058,11 +2079,11 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
                     const bool first = k == m;
                     if (!first && !fwd) { qr_step(k, std::true_type()); k++; continue; }
                     double ap = uniform_f64(first ? p : fp), aq = uniform_f64(first ? q : fq), ar = uniform_f64(first ? r : fr);
-                    const uint32_t hs0 = lds_addr32(Hs), vs0 = lds_addr32(Vs);
+                    const uint32_t hs0 = lds_addr32(Hs), vs0 = lds_addr32(Vs4);
                     const uint32_t rowaddr = hs0 + (uint32_t)(k * EN + lane) * 8u;
                     const uint32_t coladdr = ((lane < 32) ? hs0 : vs0) + (uint32_t)(arow * EN + k) * 8u;
                     const uint32_t subaddr = hs0 + (uint32_t)(k * EN + k - 1) * 8u;
-                    const uint64_t vmask = ((1ull << EN) - 1) << 32;                                      // V rows 0..26 on lanes 32..58
+                    const uint64_t vmask = ((1ull << kVRows) - 1) << 32;                                  // the kept V rows on lanes 32..35
                     const uint64_t nmask = ((1ull << (n + 1)) - 1) | vmask;                               // H rows 0..n
                     const uint64_t rowmask = ((1ull << EN) - 1) & (~0ull << k);                          // lanes k..26
                     const uint64_t colmask = (((1ull << (k + 4)) - 1) | vmask) & nmask;                   // H rows 0..min(n, k+3) | V rows
@@ -2104,8 +2125,10 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
         unsigned worst = 0;
         for (int e = lane; e < EN * EN; e += 64) {
             const unsigned hh = (unsigned)((unsigned long long)__double_as_longlong(Hs[e]) >> 32) & 0x7fffffffu;
-            const unsigned hv = (unsigned)((unsigned long long)__double_as_longlong(Vs[e]) >> 32) & 0x7fffffffu;
             worst = hh > worst ? hh : worst;
+        }
+        for (int e = lane; e < kVRows * EN; e += 64) {
+            const unsigned hv = (unsigned)((unsigned long long)__double_as_longlong(Vs4[e]) >> 32) & 0x7fffffffu;
             worst = hv > worst ? hv : worst;
         }
         const bool finite = __builtin_amdgcn_ballot_w64(worst >= 0x7ff00000u) == 0ull;
@@ -2115,17 +2138,20 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             const unsigned zero_mask = (unsigned)__builtin_amdgcn_ballot_w64(lane < nn && wl == 0.0);
             const double pe = lane < nn ? wr[lane] : 0.0;
             double x[EN];
+            // (an opaque copy of the lane id: the unit vectors below are the same values ortran's vcol[] started from, and hipcc would
+            //  otherwise keep those 54 registers alive across the whole QR iteration to reuse them here -- 169 instead of 129 VGPRs)
+            int lane_x = lane;
+            asm volatile("" : "+v"(lane_x));
 #pragma unroll
-            for (int j = 0; j < EN; j++) x[j] = (j == lane) ? 1.0 : 0.0;
+            for (int j = 0; j < EN; j++) x[j] = (j == lane_x) ? 1.0 : 0.0;
             double zz = 0.0, ss = 0.0;
             if (BackSubRow<EN - 2>::run(Hs, wr, wi, x, pe, zz, ss, real_root, lane, neg_mask, zero_mask, eps, eps * norm)) {
                 // back-transform only the rows we need: v = V * x, rows {0,1,3,9} = monomials {1, s3, s2, s1}  (x[k] = 0.0 for k > n)
-                constexpr int rows[4] = {0, 1, 3, 9};
 #pragma unroll
-                for (int rrw = 0; rrw < 4; rrw++) {
+                for (int rrw = 0; rrw < kVRows; rrw++) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int k = 0; k < EN; k++) acc = acc + VV(rows[rrw], k) * x[k];
+                    for (int k = 0; k < EN; k++) acc = acc + V4(rrw, k) * x[k];
                     v4[rrw] = acc;
                 }
                 have_v4 = true;
@@ -2137,16 +2163,10 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
         const double pe = wr[nn_];
         int l = nn_;
         double zz = 0.0, ss = 0.0;
-        // The eigenvector x of the quasi-triangular form (entries 0..nn_) needs no matrix of its own: after the QR iteration only rows
-        // {0, 1, 3, 9} of V are still read (the back-transform of the monomials 1, s3, s2, s1 below), so x lives in the other 23
-        // rows -- column c <= 12 at the start of free row F[c], column 25 - c behind it (c + 1 + 26 - c = 27 entries fill the row),
-        // column 26 in a row of its own.  6 KiB less LDS per wave (13.25 KiB: 12 waves per CU instead of 8 when many problems are batched).
-        double *xcol;
-        {
-            const int c = nn_ <= 12 ? nn_ : (nn_ <= 25 ? 25 - nn_ : 13);   // index into the free rows
-            const int row = c < 1 ? 2 : (c < 6 ? c + 3 : c + 4);            // F = {2, 4..8, 10..26}
-            xcol = Vs + row * EN + ((nn_ > 12 && nn_ <= 25) ? 26 - nn_ : 0);
-        }
+        // The eigenvector x of the quasi-triangular form (entries 0..nn_) of this rare path lives in GLOBAL memory: the hypothesis's
+        // slot of the action-matrix buffer (729 doubles, dead since the kernel copied it into LDS) -- the LDS holds no spare matrix
+        // any more (round 5).  Lane nn_ owns entries [27 nn_, 27 nn_ + nn_].
+        double *const xcol = a.Sg + (size_t)hyp * 729 + (size_t)nn_ * EN;
 #define XX(i, j) xcol[(i)]
         XX(nn_, nn_) = 1.0;
         for (int i = nn_ - 1; i >= 0; i--) {
@@ -2170,11 +2190,9 @@ __global__ __launch_bounds__(64) void pnp_eig_score(EigArgs a)
             }
         }
         // back-transform only the rows we need: v = V * x, rows {0,1,3,9} = monomials {1, s3, s2, s1}
-        const int rows[4] = {0, 1, 3, 9};
-        for (int rrw = 0; rrw < 4; rrw++) {
-            const int i = rows[rrw];
+        for (int rrw = 0; rrw < kVRows; rrw++) {
             double acc = 0.0;
-            for (int k = 0; k <= nn_; k++) acc = acc + VV(i, k) * XX(k, nn_);
+            for (int k = 0; k <= nn_; k++) acc = acc + V4(rrw, k) * XX(k, nn_);
             v4[rrw] = acc;
         }
 #undef XX

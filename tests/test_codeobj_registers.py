@@ -205,3 +205,26 @@ def test_pnp_build_solve_fits_two_workgroups_per_cu(tmp_path):
             assert get(r"\.vgpr_spill_count") == 0 and get(r"\.private_segment_fixed_size") == 0, name
             seen += 1
     assert seen == 2          # the product kernel and its stamped (tuning) twin
+
+
+@pytest.mark.skipif(not (LLVM / "llvm-readelf").exists(), reason="llvm-readelf not available")
+def test_pnp_eig_score_fits_four_waves_per_simd(tmp_path):
+    """pnp_eig_score (one wave per hypothesis) is sized for FOUR waves per SIMD = 16 per CU (round 5; 12 before): that needs <= 128
+    VGPRs and <= 10 KiB of LDS per wave.  Both are one careless change away -- the hand-scheduled QR loop already owns v72..v127, and
+    a second copy of the accumulated transformation V in LDS costs 5.7 KiB -- so they are checked from the code object's metadata.
+    The few bytes of scratch are one LDS address the Hessenberg steps reload (measured: no effect on the call time)."""
+    if not SO.exists():
+        pytest.skip("libcerebro_hip.so not built")
+    seen = 0
+    for co in code_objects(tmp_path):
+        notes = subprocess.run([str(LLVM / "llvm-readelf"), "--notes", str(co)], capture_output=True, text=True, check=True).stdout
+        for block in notes.split(".name:")[1:]:
+            name = block.split()[0]
+            if "pnp_eig_score" not in name or name.endswith(".kd"):
+                continue
+            get = lambda key: int(re.search(key + r":\s+(\d+)", block).group(1))   # noqa: E731
+            assert get(r"\.vgpr_count") <= 128, (name, get(r"\.vgpr_count"))
+            assert get(r"\.group_segment_fixed_size") <= 10 * 1024, (name, get(r"\.group_segment_fixed_size"))
+            assert get(r"\.private_segment_fixed_size") <= 32, (name, get(r"\.private_segment_fixed_size"))
+            seen += 1
+    assert seen == 2          # the product kernel and its stamped (tuning) twin

@@ -511,3 +511,24 @@ def test_group_copy_exchange_distinct_devices():
         wsc, wix = scenarios.cached_scan_topk_synth(seed, l - 50, D, [l - 1, l - 2, l - 3], 8, plants, nthreads=min(os.cpu_count() or 1, 128))
         assert r.found == 1 and r.idx_prev == p + 4 and list(r.argmax) == list(wix[:, 0])
         assert [float(x).hex() for x in r.maxv] == [float(x).hex() for x in wsc[:, 0]]
+
+
+def test_two_consecutive_failed_pipelined_ticks_unwind_to_the_last_good_l(monkeypatch):
+    """ticks A and B are both enqueued and both come back CHIP_TICK_FAILED.  A's collect cannot roll back (B was enqueued on
+    top of it); B's collect must not restore A's l (a pass that never reached Cerebro.cpp:1098) but the last_l from before A."""
+    monkeypatch.setenv("CHIP_TEST_FAIL_SHARD", "1:1")           # shard 1 fails EVERY collective call
+    D, N = 256, 900
+    db = scenarios.build_db(5, N, D, [])
+    with capi.Chip(D, devices=[0, 0]) as chip:
+        chip.append_f32(db)
+        assert chip.last_l() == 0
+        for depth in (2, 3):
+            ls = [400 + 10 * i for i in range(depth)]
+            for s_, l in enumerate(ls):
+                chip.loop_tick_enqueue(l, s_)
+            assert chip.last_l() == ls[-1]                       # provisional commits
+            for s_ in range(depth):
+                with pytest.raises(capi.ChipError) as ei:
+                    chip.loop_tick_collect(s_)
+                assert ei.value.status == capi.CHIP_ERR_SHARD_FAILED
+            assert chip.last_l() == 0, depth                     # unwound through every failed predecessor
