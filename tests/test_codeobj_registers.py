@@ -218,9 +218,9 @@ def test_pnp_eig_score_fits_four_waves_per_simd(tmp_path):
     seen = 0
     for co in code_objects(tmp_path):
         notes = subprocess.run([str(LLVM / "llvm-readelf"), "--notes", str(co)], capture_output=True, text=True, check=True).stdout
-        for block in notes.split(".name:")[1:]:
-            name = block.split()[0]
-            if "pnp_eig_score" not in name or name.endswith(".kd"):
+        for block in notes.split("- .agpr_count:")[1:]:      # one metadata entry per kernel (keys in alphabetical order)
+            name = re.search(r"\.name:\s+(\S+)", block).group(1)
+            if "pnp_eig_score" not in name:
                 continue
             get = lambda key: int(re.search(key + r":\s+(\d+)", block).group(1))   # noqa: E731
             assert get(r"\.vgpr_count") <= 128, (name, get(r"\.vgpr_count"))
