@@ -204,6 +204,7 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     if (c->scan_blocks_per_cu < 1) c->scan_blocks_per_cu = 1;
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);
     c->scan_rows = env_int("CHIP_SCAN_ROWS", 0);
+    c->scan_claim = env_int("CHIP_SCAN_CLAIM", -1);   // -1 = auto (full-occupancy launches of the row-batched kernel), 0 = never, 1 = always
     c->tick_same_stream = env_int("CHIP_TICK_SAME_STREAM", 1) != 0;
     c->scan_short_bpc = env_int("CHIP_SCAN_SHORT_BPC", 1);
     c->scan_plain_bytes = (double)env_int("CHIP_SCAN_PLAIN_MIB", 768) * 1024 * 1024;
@@ -331,6 +332,9 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
     a.rows_form = scan_rows_form(c, a.n_rows, nq, grid, a.q64 != 0);
     a.plain_loads = (double)a.n_rows * c->D * c->elem <= c->scan_plain_bytes ? 1 : 0;
     a.stamps = c->stamps_dev;
+    // rows claimed within the workgroup: measured -2 % on the synchronous 29k / 45k tick (two workgroups per CU), neutral at 10k (one
+    // workgroup per CU: the launch is too short for the waves to drift apart) -- profiles/r05_short_scan.md
+    a.dyn_claim = (a.rows_form == 1 && (c->scan_claim == 1 || (c->scan_claim < 0 && grid > c->n_cus))) ? 1 : 0;
     // fused tick: one launch (kernels.hip fused_tick_finish) -- same-stream short ticks through the row-batched kernel, decision wanted,
     // no list output
     const bool fused = same_stream && a.rows_form > 0 && c->tick_fused && res != nullptr && out == nullptr && nq == 3 && p != nullptr;

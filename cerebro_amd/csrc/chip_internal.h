@@ -28,6 +28,7 @@ struct ScanArgs {
     int32_t q64 = 0;                // queries staged in LDS as fp64 (scan_q64)
     int32_t rows_form = 0;          // > 0: row-batched kernel with this many rows per wave in flight (scan_rows_form)
     int32_t plain_loads = 0;        // row-batched kernel: temporal loads (the prefix fits the Infinity Cache and is re-read every tick)
+    int32_t dyn_claim = 0;          // row-batched kernel, R = 1: the waves of a workgroup CLAIM their rows from an LDS counter instead of the static map (CHIP_SCAN_CLAIM=1)
     unsigned long long *stamps = nullptr;   // tuning only (CHIP_SCAN_STAMPS): 4 wall-clock stamps per wave of the row-batched kernel
     // fused tick (row-batched kernel, plain ctx): the LAST workgroup to finish reduces the per-workgroup best entries and writes the
     // decision record itself -- a tick is then ONE launch.  fused_result == nullptr: lists only, K2 follows as a launch of its own.
@@ -166,6 +167,7 @@ struct Ctx {
     int32_t scan_reserve = 0;
     int32_t scan_variant = 0;
     bool tick_same_stream = true;  // short ticks of a plain ctx: merge on the scan's stream (CHIP_TICK_SAME_STREAM=0 disables)
+    int32_t scan_claim = -1;      // CHIP_SCAN_CLAIM: rows claimed within the workgroup (row-batched kernel, R = 1): -1 auto, 0 never (static row -> wave map), 1 always
     int32_t scan_rows = 0;        // CHIP_SCAN_ROWS: 0 = auto (prefixes up to scan_plain_bytes), 1..3 = row-batched kernel with that R for every scan, -1 = never
     double scan_plain_bytes = 768.0 * 1024 * 1024;   // prefixes up to this size: rows form, R = 1, temporal loads (CHIP_SCAN_PLAIN_MIB)
     double scan_half_bytes = 192.0 * 1024 * 1024;    // prefixes up to this size: launches take half of every CU's workgroup slots (CHIP_SCAN_HALF_MIB)

@@ -640,7 +640,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
     const int64_t tw = (int64_t)gridDim.x * wpb;
     const int64_t g = (int64_t)blockIdx.x * wpb + wave;           // this wave's first row (same row -> wave map as db_scan_topk)
     const int nb = D / (CH * U);                                   // 4 KiB batches per row
-    const int npass = g < a.n_rows ? (int)((a.n_rows - 1 - g) / (R * tw)) + 1 : 0;
+    const int64_t rbase = g, rstep = tw, rlim = a.n_rows;        // this wave's rows: rbase + i * rstep < rlim (the same row -> wave map as db_scan_topk)
+    const int npass = rbase < rlim ? (int)((rlim - 1 - rbase) / (R * rstep)) + 1 : 0;
     const int total = npass * nb;                                  // batches this wave consumes (wave-uniform)
 
     unsigned long long *stamp = a.stamps ? a.stamps + (size_t)g * 4 : nullptr;   // tuning only
@@ -658,11 +659,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
     const T *row[R];                                               // bases of the rows the NEXT issue reads (wave-uniform, SGPRs)
     const uint32_t lane_off = (uint32_t)(lane * 16);
     auto set_rows = [&](int pass) {
-        const int64_t r0 = g + (int64_t)pass * R * tw;
+        const int64_t r0 = rbase + (int64_t)pass * R * rstep;
 #pragma unroll
         for (int rr = 0; rr < R; rr++) {
-            const int64_t r = r0 + rr * tw;
-            row[rr] = uniform_ptr(row_base_uniform<T>(a, r < a.n_rows ? r : r0));   // a missing row re-reads the pass's first row; its result is dropped
+            const int64_t r = r0 + rr * rstep;
+            row[rr] = uniform_ptr(row_base_uniform<T>(a, r < rlim ? r : r0));   // a missing row re-reads the pass's first row; its result is dropped
         }
     };
     // load slot u of every row of the batch at byte offset byte_off of the rows
@@ -674,6 +675,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
         if constexpr (R > 2) rows_issue<NTL, rows_slot_reg<R>(u, R > 2 ? 2 : 0), (u) * 1024>(vo_, row[R > 2 ? 2 : 0]);  \
     } while (0)
 
+    if constexpr (R == 1) if (a.dyn_claim && tid == 0)   // the claim counter: units 0 .. wpb-1 are the waves' first rows (set before the barrier below)
+        *reinterpret_cast<uint32_t *>(smem + (size_t)NQ * D * sizeof(T) + (size_t)wpb * NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry)) = (uint32_t)wpb;
     if (total > 0) {
         set_rows(0);
         CHIP_ROWS_ISSUE_SLOT(0, 0u); CHIP_ROWS_ISSUE_SLOT(1, 0u); CHIP_ROWS_ISSUE_SLOT(2, 0u); CHIP_ROWS_ISSUE_SLOT(3, 0u);
@@ -730,6 +733,67 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
     } while (0)
 
     int pass = 0, b = 0;
+    bool dyn = false;
+    if constexpr (R == 1) dyn = a.dyn_claim != 0;
+    if (dyn) {
+      if constexpr (R == 1) {
+        // ---- rows CLAIMED within the workgroup (round 5) -------------------------------------------------------------------------
+        // Which wave scores which row is free: a row's dot products are one wave's fixed per-lane chain whoever that wave is, and the
+        // lists merge under a total order.  The static map (wave g: rows g, g + tw, ...) makes every wave finish its LAST row when
+        // its own speed says so -- and the speeds differ by the wave's age on its SIMD (stamps: 61 / 65 / 70 / 74 us at 29k rows).
+        // Here the workgroup's rows -- unit u = row (u / wpb) * tw + blockIdx * wpb + u % wpb, the same set as before -- are handed
+        // out by an LDS counter: a wave claims its next unit while it starts on the current one (the ds_add_rtn has a whole row,
+        // ~8 us, to come back), so the waves of a workgroup run dry within one row of each other.
+        uint32_t *ctr = reinterpret_cast<uint32_t *>(smem + (size_t)NQ * D * sizeof(T) + (size_t)wpb * NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry));
+        const int64_t wg0 = (int64_t)blockIdx.x * wpb;
+        int n_units = 0;
+        if (a.n_rows > wg0) {
+            const int64_t span = a.n_rows - wg0, pf = span / tw, rem = span - pf * tw;
+            n_units = (int)(pf * wpb + (rem < wpb ? rem : wpb));
+        }
+        auto unit_row = [&](int u) { return (int64_t)(u / wpb) * tw + wg0 + (u % wpb); };
+        // (the counter was set to wpb by wave 0 before the staging barrier; unit `wave` is this wave's first, loaded above)
+        int cur = wave;
+        while (cur < n_units) {
+            uint32_t nxt_v = 0;                                 // next unit, claimed by lane 0 alone: needed at this row's last batch
+            if (lane == 0) nxt_v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int nxt = 0;
+            bool more = false;
+            for (b = 0; b < nb; b++) {
+                const int base = b * (CH * U);
+                bool next_batch = true;
+                int nbase = base + CH * U;
+                if (b + 1 == nb) {
+                    nxt = __builtin_amdgcn_readfirstlane((int)nxt_v);
+                    more = nxt < n_units;
+                    next_batch = more;
+                    nbase = 0;
+                    if (more) row[0] = uniform_ptr(row_base_uniform<T>(a, unit_row(nxt)));
+                }
+                if (next_batch) {
+                    const uint32_t noff = (uint32_t)nbase * (uint32_t)sizeof(T);
+                    CHIP_ROWS_FMA_SLOT(0, base, (U - 1) * R); CHIP_ROWS_ISSUE_SLOT(0, noff);
+                    CHIP_ROWS_FMA_SLOT(1, base, (U - 1) * R); CHIP_ROWS_ISSUE_SLOT(1, noff);
+                    CHIP_ROWS_FMA_SLOT(2, base, (U - 1) * R); CHIP_ROWS_ISSUE_SLOT(2, noff);
+                    CHIP_ROWS_FMA_SLOT(3, base, (U - 1) * R); CHIP_ROWS_ISSUE_SLOT(3, noff);
+                } else {
+                    CHIP_ROWS_FMA_SLOT(0, base, 3 * R);
+                    CHIP_ROWS_FMA_SLOT(1, base, 2 * R);
+                    CHIP_ROWS_FMA_SLOT(2, base, 1 * R);
+                    CHIP_ROWS_FMA_SLOT(3, base, 0);
+                }
+            }
+            const int64_t r = unit_row(cur);
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const double s = butterfly_sum(acc[0][q]);
+                acc[0][q] = 0.0;
+                wave_topk_offer_lds(s, r * a.idx_mul + a.idx_add, K, lane, mylists + q * CHIP_MAX_TOPK, thr_s[q], thr_i[q]);
+            }
+            cur = more ? nxt : n_units;
+        }
+      }
+    } else
     for (int t = 0; t < total; t++) {
         const int base = b * (CH * U);
         if (t + 1 < total) {
@@ -750,15 +814,15 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
             CHIP_ROWS_FMA_SLOT(3, base, 0);
         }
         if (++b == nb) {   // the rows of this pass are complete: butterfly, offer, next pass
-            const int64_t r0 = g + (int64_t)pass * R * tw;
+            const int64_t r0 = rbase + (int64_t)pass * R * rstep;
 #pragma unroll
             for (int rr = 0; rr < R; rr++) {
-                const int64_t r = r0 + rr * tw;
+                const int64_t r = r0 + rr * rstep;
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
                     const double s = butterfly_sum(acc[rr][q]);
                     acc[rr][q] = 0.0;
-                    if (r < a.n_rows) wave_topk_offer_lds(s, r * a.idx_mul + a.idx_add, K, lane, mylists + q * CHIP_MAX_TOPK, thr_s[q], thr_i[q]);
+                    if (r < rlim) wave_topk_offer_lds(s, r * a.idx_mul + a.idx_add, K, lane, mylists + q * CHIP_MAX_TOPK, thr_s[q], thr_i[q]);
                 }
             }
             b = 0;
@@ -859,7 +923,7 @@ int scan_wide_ng(const Ctx *c, int nq)
 
 static size_t scan_lds_bytes(const Ctx *c, int nq, int K, int block, bool q64, bool rows_form = false)
 {
-    if (rows_form) return (size_t)nq * c->D * c->elem + (size_t)(block / 64) * nq * CHIP_MAX_TOPK * sizeof(chip_topk_entry);   // queries + running lists
+    if (rows_form) return (size_t)nq * c->D * c->elem + (size_t)(block / 64) * nq * CHIP_MAX_TOPK * sizeof(chip_topk_entry) + 16;   // queries + running lists + the claim counter
     const size_t lds_q = (size_t)(q64 ? nq : nq - scan_wide_ng(c, nq)) * c->D * (q64 ? 8 : c->elem);   // the staged queries
     const size_t lds_m = (size_t)(block / 64) * nq * K * sizeof(chip_topk_entry);
     return lds_q > lds_m ? lds_q : lds_m;

@@ -30,11 +30,12 @@ def run(rows, env, n=400):
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = v
 
-for rows in (10_000, 29_000, 60_000, 100_000):
-    ref = None
-    for env in ({}, {"CHIP_SCAN_SHORT_BPC": "0"}, {"CHIP_SCAN_HALF_MIB": "100000"}, {"CHIP_SCAN_ROWS": "2"}, {"CHIP_SCAN_ROWS": "3"},
-                {"CHIP_SCAN_ROWS": "2", "CHIP_SCAN_SHORT_BPC": "0"}, {"CHIP_TICK_FUSED": "0"}, {"CHIP_SCAN_ROWS": "-1"}):
-        out, res = run(rows, env)
-        if ref is None: ref = res
-        out["same_bits"] = res == ref
-        print(json.dumps(out), flush=True)
+if __name__ == "__main__":
+  for rows in (10_000, 29_000, 60_000, 100_000):
+      ref = None
+      for env in ({}, {"CHIP_SCAN_SHORT_BPC": "0"}, {"CHIP_SCAN_HALF_MIB": "100000"}, {"CHIP_SCAN_ROWS": "2"}, {"CHIP_SCAN_ROWS": "3"},
+                  {"CHIP_SCAN_ROWS": "2", "CHIP_SCAN_SHORT_BPC": "0"}, {"CHIP_TICK_FUSED": "0"}, {"CHIP_SCAN_ROWS": "-1"}):
+          out, res = run(rows, env)
+          if ref is None: ref = res
+          out["same_bits"] = res == ref
+          print(json.dumps(out), flush=True)
