@@ -106,9 +106,13 @@ def eigen_baseline(sample_cols: int, budget_s: float):
     import glob
     import shutil
     import subprocess
-    cands = [os.environ.get("EIGEN3_INCLUDE_DIR", "")] + ["/usr/include/eigen3", "/usr/local/include/eigen3", "/opt/eigen3", "/usr/include", "/usr/local/include"]
-    cands += glob.glob("/opt/*/include/eigen3") + glob.glob("/usr/lib/cmake/eigen3/../../../include/eigen3")
-    inc = next((c for c in cands if c and os.path.exists(os.path.join(c, "Eigen", "Dense"))), None)
+    sys.path.insert(0, str(ROOT / "scripts"))
+    try:
+        from eigen_pin import find_eigen     # fixed include dirs, /opt, every site-packages / conda prefix (scripts/eigen_pin.py)
+        hits = find_eigen()[0]
+    except Exception:  # noqa: BLE001
+        hits = []
+    inc = hits[0] if hits else None
     gxx = shutil.which("g++")
     if inc is None or gxx is None:
         return None
@@ -942,7 +946,7 @@ def main():
                                                        f"{args.cpu_sample}-column x {D} MatrixXd ({eig[2]:.1f} s), g++ -O3 -DNDEBUG without -march "
                                                        f"(the reference's Release flags), scaled to {args.rows} columns"}
             out["eigen_probe"] = "Eigen found: cpu_baseline_eigen is the reference's own statements" if eig is not None else \
-                "no <Eigen/Dense> on this host (searched EIGEN3_INCLUDE_DIR, /usr/include/eigen3, /usr/local/include/eigen3, /opt/*): cpu_baseline is the Eigen-order port"
+                "no <Eigen/Dense> on this host (searched EIGEN3_INCLUDE_DIR, the system include dirs, /opt/*, every Python site-packages / conda prefix: scripts/eigen_pin.py, profiles/r05_eigen_pin.json): cpu_baseline is the Eigen-order port"
             host = f"host has {os.cpu_count()} logical CPUs ({usable_cpus()} usable under the cgroup quota)"
             out["cpu_baseline"] = {"value": cols_per_s / args.rows, "unit": "loop-queries/s", "cores": 1, "kind": "port",
                                    "port_of": "eigen-order port: Eigen 3.3 row-major GEMV as the reference's SSE2 Release build runs it (four rows at a "

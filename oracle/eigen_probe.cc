@@ -9,10 +9,38 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 using namespace Eigen;
+
+// --dump <in.bin> <out.bin>: pins the Eigen-order restatement (oracle/dot_scan.c orc_ref_scan_f64_eigen_gemv3) against the REAL Eigen
+// once.  in.bin: i32 D, i32 k, then (k + 3) x D float64 column-major (the columns of M; the last three are the
+// queries v, vm, vmm as at Cerebro.cpp:987-989).  out.bin: the literal u, um, umm of :1026-1028, 3 x k float64.
+static int dump(const char *in, const char *out)
+{
+    FILE *f = std::fopen(in, "rb");
+    if (!f) return 2;
+    int32_t D = 0, k = 0;
+    if (std::fread(&D, 4, 1, f) != 1 || std::fread(&k, 4, 1, f) != 1 || D < 1 || k < 1) return 2;
+    MatrixXd M(D, k + 3);
+    if (std::fread(M.data(), sizeof(double), (size_t)D * (k + 3), f) != (size_t)D * (k + 3)) return 2;
+    std::fclose(f);
+    const VectorXd v = M.col(k + 2), vm = M.col(k + 1), vmm = M.col(k);
+    VectorXd u = v.transpose() * M.leftCols(k);                     // :1026
+    VectorXd um = vm.transpose() * M.leftCols(k);                   // :1027
+    VectorXd umm = vmm.transpose() * M.leftCols(k);                 // :1028
+    FILE *o = std::fopen(out, "wb");
+    if (!o) return 2;
+    std::fwrite(u.data(), sizeof(double), (size_t)k, o);
+    std::fwrite(um.data(), sizeof(double), (size_t)k, o);
+    std::fwrite(umm.data(), sizeof(double), (size_t)k, o);
+    std::fclose(o);
+    std::printf("eigen %d.%d.%d dumped u, um, umm of %d columns x %d\n", EIGEN_WORLD_VERSION, EIGEN_MAJOR_VERSION, EIGEN_MINOR_VERSION, k, D);
+    return 0;
+}
 
 int main(int argc, char **argv)
 {
+    if (argc > 3 && std::string(argv[1]) == "--dump") return dump(argv[2], argv[3]);
     const int D = argc > 1 ? std::atoi(argv[1]) : 4096;
     const int cols = argc > 2 ? std::atoi(argv[2]) : 20000;
     const double budget = argc > 3 ? std::atof(argv[3]) : 10.0;

@@ -163,6 +163,24 @@ class LoopOracle:
         return r.as_dict()
 
 
+def loop_tick_order(db: np.ndarray, l: int, order: int, nthreads: int = 8) -> dict:
+    """ONE tick at l from a fresh state (last_l = 0): order 0 = the device's fixed tree on float rows, order 1 = the reference's
+    arithmetic (fp64 M, Eigen 3.3 SSE2 GEMV order).  db: float32-valued rows."""
+    lib = load()
+    lib.orc_loop_tick_order.restype = None
+    if order == 0:
+        m, elem = np.ascontiguousarray(db, dtype=np.float32), 4
+    else:
+        m, elem = np.ascontiguousarray(db, dtype=np.float64), 8
+    st = OrcLoopState(0)
+    p = default_params()
+    out = OrcTickResult()
+    gap = (C.c_double * 3)()
+    lib.orc_loop_tick_order(C.byref(st), C.byref(p), m.ctypes.data_as(C.c_void_p), C.c_int32(elem), C.c_int32(m.shape[1]), C.c_int64(l),
+                            C.c_int32(order), C.c_int32(nthreads), C.byref(out), gap)
+    return out.as_dict()
+
+
 class LoopOracle64:
     """The same ticks on a host fp64 DB (double-row storage mode): scores by orc_dot_tree_f64 (fma chains)."""
 
