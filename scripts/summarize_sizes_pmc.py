@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/sizes_pmc/<rows>_{FETCH_SIZE,WRITE_SIZE,trace}/*_results.db -> profiles/scan_traffic_sizes.json + profiles/r04_sizes_pmc.md.
+"""gpurun_out/sizes_pmc/<rows>_{FETCH_SIZE,WRITE_SIZE,trace}/*_results.db -> profiles/scan_traffic_sizes.json + profiles/r05_sizes_pmc.md.
 Per size: the scan kernel of a SYNCHRONOUS tick (one launch at a time): launches, avg / min duration (kernel trace), FETCH_SIZE and
 WRITE_SIZE per launch (separate passes), traffic = FETCH_SIZE x 1024 x 2 (gfx950: 128-B requests tallied at 64 B for 16-B-per-lane
 streaming reads, MI355X_MICROARCH.md HBM section) + WRITE_SIZE x 1024.  Only the steady-state launches count: the warm-up ticks of
@@ -53,7 +53,7 @@ def main(src):
                       f"{e['fetch_size_kib_avg']:.1f} | {e.get('write_size_kib_avg', 0.0):.1f} | {e['hbm_bytes_per_launch']:.4e} | "
                       f"{e['hbm_bytes_per_launch'] / alg:.4f} | {alg / (e['avg_kernel_us'] * 1e-6) / 8e12:.3f} | {alg / (e['min_kernel_us'] * 1e-6) / 8e12:.3f} |")
     (ROOT / "profiles" / "scan_traffic_sizes.json").write_text(json.dumps(out, indent=1))
-    (ROOT / "profiles" / "r04_sizes_pmc.md").write_text("\n".join(md) + "\n")
+    (ROOT / "profiles" / "r05_sizes_pmc.md").write_text("\n".join(md) + "\n")
     print("\n".join(md))
 
 
