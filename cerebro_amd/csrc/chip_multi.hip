@@ -108,6 +108,9 @@ struct CommInitJob {
 // on stderr every time it fires -- a stray environment variable must not degrade a deployed process silently.
 static int comm_init_test_hook()
 {
+#ifdef CHIP_NO_TEST_HOOKS   // a deployment build: make EXTRA_HIPFLAGS=-DCHIP_NO_TEST_HOOKS (the fault-injection hooks are compiled out)
+    return 0;
+#endif
     const char *t = std::getenv("CHIP_TEST_COMM_INIT");
     if (!t || !*t) return 0;
     const int mode = std::strcmp(t, "hang") == 0 ? 1 : std::strcmp(t, "fail") == 0 ? 2 : 0;
@@ -194,6 +197,7 @@ static int exchange_create(Ctx *c, int world, bool need_gathered)
     }
     CHIP_HIP(c, hipMalloc(&x->agree_dev, sizeof(int32_t) * (size_t)(1 + world)));
     CHIP_HIP(c, hipHostMalloc(&x->agree_host, sizeof(int32_t) * (size_t)(1 + world), hipHostMallocDefault));
+#ifndef CHIP_NO_TEST_HOOKS
     if (const char *t = std::getenv("CHIP_TEST_FAIL_SHARD")) {
         int r = -1, every = 0;
         if (std::sscanf(t, "%d:%d", &r, &every) == 2 && r == c->rank && every > 0) {
@@ -201,6 +205,7 @@ static int exchange_create(Ctx *c, int world, bool need_gathered)
             std::fprintf(stderr, "[cerebro_hip] TEST HOOK ACTIVE: CHIP_TEST_FAIL_SHARD=%s -- shard %d fails every %d-th collective call\n", t, r, every);
         }
     }
+#endif
     return CHIP_OK;
 }
 
@@ -214,6 +219,9 @@ static bool test_fail_now(Exchange *x)
 // test hook: CHIP_TEST_BATCH_OOM="rank": this rank's many-query call pretends its per-call allocations failed (announced on stderr)
 static int test_oom_rank()
 {
+#ifdef CHIP_NO_TEST_HOOKS
+    return -1;
+#endif
     static const int r = [] {
         const char *t = std::getenv("CHIP_TEST_BATCH_OOM");
         if (!t || !*t) return -1;

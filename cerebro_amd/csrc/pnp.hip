@@ -1072,6 +1072,12 @@ __device__ __forceinline__ uint32_t lds_addr32(const void *p) { return (uint32_t
 __device__ __forceinline__ void qr_steps_asm(int &k, int k1, double &p, double &q, double &r, uint32_t rowaddr, uint32_t coladdr,
                                              uint32_t subaddr, uint64_t rowmask, uint64_t colmask, uint64_t nmask, uint64_t first63, int do_last, int &zero)
 {
+    // The block hard-codes the LDS geometry of the 27 x 27 matrices: row stride 0xd8 = 27 * 8 bytes, diagonal stride
+    // 0xe0 = 28 * 8, ds_read2_b64 offsets 27 / 54 / 81 (in 8-byte units: one / two / three rows down).  The row address is kept ONE
+    // ROW BEHIND and read at +216 (the bump sits in a division's wait states): for k0 = 0 it starts 216 bytes below HH(0, lane),
+    // which is inside the kernel's HsPad (28 doubles = 224 bytes in front of Hs), never below LDS address 0.
+    static_assert(EN == 27, "qr_steps_asm: LDS strides 0xd8 / 0xe0 and the ds_read2 offsets 27 / 54 / 81 are those of EN = 27");
+    static_assert(EN * 8 == 0xd8 && (EN + 1) * 8 == 0xe0, "qr_steps_asm: row / diagonal stride literals");
     const uint64_t m_odd = 0xAAAAAAAAAAAAAAAAull, m_l0 = 1ull, m_lt3 = 7ull, m_l63 = 1ull << 63;
     int kk = k, z = 0;
     double po = p, qo = q, ro = r;
@@ -1720,6 +1726,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // &H(i-1, i-1), which for lane 0 lies 224 bytes in front of H -- inside this pad, not below LDS address 0 (no address wrap-around;
     // the pad's content is never used: lane 0's H(-1,-1) / H(0,-1) only feed a comparison whose result is overridden)
     __shared__ double HsPad[28 + EN * EN], Vs4[kVRows * EN];
+    static_assert(28 * 8 >= 0xd8 + 8, "HsPad: qr_steps_asm's row address starts one row (0xd8 bytes) below HH(0, lane)");
     double *const Hs = HsPad + 28;
     __shared__ double ortm[EN], wr[EN], wi[EN], Tf[27], sxs[kSampleMax * 3], model[16];
     __shared__ __attribute__((aligned(16))) double us[EN + 5];   // the current Householder vector (orthes / ortran)

@@ -204,3 +204,51 @@ def test_bench_under_torchrun_reports_rccl_ranks():
     assert j["n_gpus"] == n and j["value"] > 0 and j["scaling"] == "strong"
     assert j["config"]["rccl_ranks"] == n and not j["config"]["exchange_fallback"], j["config"]
     assert "in-library RCCL" in j["config"]["exchange"]
+
+
+def _worker_1m(rank, world, uid_path, ret, want_path):
+    import time
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    from cerebro_amd import capi
+    w = np.load(want_path)
+    wsc, wix = w["sc"], w["ix"]
+    D, N, seed = 4096, 1_000_053, 20190412
+    l = N
+    q, p = l - 1, 777_777
+    plants = [(q - j, p - j, 1) for j in range(3)] + [(p + 4, p, 2), (123_456, p - 1, 2)]
+    with capi.Chip(D, capacity_hint=N, device=0, shard_rank=rank, shard_count=world) as chip:
+        if rank == 0:
+            with open(uid_path + ".tmp", "wb") as f:
+                f.write(capi.comm_unique_id())
+            os.replace(uid_path + ".tmp", uid_path)
+        t0 = time.time()
+        while not os.path.exists(uid_path):
+            assert time.time() - t0 < 120
+            time.sleep(0.01)
+        chip.comm_init_rank(open(uid_path, "rb").read(), world, rank)
+        assert chip.info()["comm_ranks"] == world
+        chip.append_synthetic(N, seed, plants)
+        assert chip.size() == N and chip.info()["rows_local"] == len(range(rank, N, world))
+        r = chip.loop_tick(l)
+        assert r.status == capi.CHIP_TICK_SCANNED and r.found == 1 and r.idx_curr == q and r.idx_prev == p + 4
+        assert list(r.argmax) == list(wix[:, 0]) == [p + 4, p - 1, p - 2]
+        assert [float(x).hex() for x in r.maxv] == [float(x).hex() for x in wsc[:, 0]]
+        got = chip.query_rows(l - 50, [l - 1, l - 2, l - 3], 8)
+        assert np.array_equal(got[1], wix) and np.array_equal(bits(got[0]), bits(wsc))
+        ret[rank] = (1, 0)
+
+
+def test_config4_shape_one_process_per_rank_at_full_size(tmp_path):
+    """BASELINE config 4 in its own launch shape AND at its own size: 4096-D x 1 000 053 rows row-sharded over EIGHT processes (here
+    all on device 0, 125k rows = 2 GB each), the per-shard top-k lists all-gathered inside the library (over the RCCL stand-in), merge
+    + decision on every rank: the tick and the top-8 lists are those of the full CPU-oracle scan, bit for bit, on every rank."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import scenarios
+    D, N, seed = 4096, 1_000_053, 20190412
+    l = N
+    q, p = l - 1, 777_777
+    plants = [(q - j, p - j, 1) for j in range(3)] + [(p + 4, p, 2), (123_456, p - 1, 2)]
+    wsc, wix = scenarios.cached_scan_topk_synth(seed, l - 50, D, [l - 1, l - 2, l - 3], 8, plants, nthreads=min(os.cpu_count() or 1, 128))
+    np.savez(tmp_path / "want.npz", sc=wsc, ix=wix)
+    ret = _spawn(_worker_1m, 8, tmp_path, (str(tmp_path / "want.npz"),), BASE_ENV)
+    assert len(ret) == 8
