@@ -9,7 +9,8 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 
-HIP_ARTEFACTS = [ROOT / "cerebro_amd" / "lib" / n for n in ("libcerebro_hip.so", "libcerebro_host.so", "cerebro_replay", "minimal_loop_detector")]
+HIP_ARTEFACTS = [ROOT / "cerebro_amd" / "lib" / n for n in ("libcerebro_hip.so", "libcerebro_host.so", "cerebro_replay", "minimal_loop_detector",
+                                                          "norows/libcerebro_hip.so")] + [ROOT / "tests" / "fakerccl" / "_build" / "libfakerccl.so"]
 _hip_build_error = None
 
 
@@ -31,9 +32,9 @@ def pytest_configure(config):
         if not (os.path.exists(hipcc) or shutil.which("hipcc")):
             _hip_build_error = "hipcc not found: libcerebro_hip.so cannot be built on this machine"
         else:
-            r = subprocess.run(["make", "-j4", "lib", "host"], cwd=ROOT, capture_output=True, text=True)
+            r = subprocess.run(["make", "-j4", "lib", "host", "testlibs"], cwd=ROOT, capture_output=True, text=True)
             if r.returncode != 0:
-                _hip_build_error = "make lib host failed:\n" + r.stdout[-1500:] + r.stderr[-1500:]
+                _hip_build_error = "make lib host testlibs failed:\n" + r.stdout[-1500:] + r.stderr[-1500:]
 
 
 def pytest_collection_modifyitems(config, items):
