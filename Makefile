@@ -20,7 +20,7 @@ ORC_SRCS   := $(wildcard oracle/*.c)
 all: lib oracle host testlibs verify
 lib: $(LIBDIR)/libcerebro_hip.so
 oracle: oracle/_build/liboracle.so oracle/_build/liboracle_eispack.so oracle/_build/liboracle_stats.so oracle/_build/liboracle_flops.so
-host: $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay $(LIBDIR)/minimal_loop_detector
+host: $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay $(LIBDIR)/minimal_loop_detector $(LIBDIR)/sync_tick_latency
 # test infrastructure that needs hipcc: the shared-memory stand-in for librccl (N ranks on one device, tests/test_fakerccl_gpu.py)
 testlibs: tests/fakerccl/_build/libfakerccl.so $(LIBDIR)/norows/libcerebro_hip.so
 # the degraded build (-DCHIP_NO_ROWS_FORM: what scripts/verify_codeobj.sh falls back to), kept next to the real one so that the GPU
@@ -84,6 +84,9 @@ verify: $(LIBDIR)/.codeobj_verified
 $(LIBDIR)/.codeobj_verified: $(LIBDIR)/libcerebro_hip.so tests/test_codeobj_registers.py scripts/verify_codeobj.sh $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay $(LIBDIR)/minimal_loop_detector
 	bash scripts/verify_codeobj.sh
 	@touch $@
+
+$(LIBDIR)/sync_tick_latency: examples/sync_tick_latency.cc include/cerebro_hip.h $(LIBDIR)/libcerebro_hip.so
+	$(CXX) -O2 -std=c++17 -Wall -Wextra -Iinclude $< -o $@ -L$(LIBDIR) -lcerebro_hip -Wl,-rpath,'$$ORIGIN'
 
 clean:
 	rm -rf $(LIBDIR) oracle/_build tests/fakerccl/_build

@@ -163,6 +163,7 @@ void ctx_destroy(chip_ctx *c)
     if (c->scores_dev) (void)hipFree(c->scores_dev);
     if (c->stamps_dev) (void)hipFree(c->stamps_dev);
     if (c->tickets_dev) (void)hipFree(c->tickets_dev);
+    if (c->seq_host_all) (void)hipHostFree(c->seq_host_all);
     for (Slot &s : c->slots) {
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.host) (void)hipHostFree(s.host);
@@ -240,6 +241,9 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     CHIP_HIP(c, hipMalloc(&c->tickets_dev, Ctx::kRing * sizeof(int32_t)));
     CHIP_HIP(c, hipMemset(c->tickets_dev, 0, Ctx::kRing * sizeof(int32_t)));
     c->tick_fused = env_int("CHIP_TICK_FUSED", 1) != 0;
+    c->tick_poll = env_int("CHIP_TICK_POLL", 1) != 0;
+    CHIP_HIP(c, hipHostMalloc(&c->seq_host_all, sizeof(unsigned long long) * CHIP_MAX_INFLIGHT, hipHostMallocDefault));
+    std::memset(c->seq_host_all, 0, sizeof(unsigned long long) * CHIP_MAX_INFLIGHT);
     CHIP_HIP(c, hipHostMalloc(&c->topk_host, (size_t)CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry), hipHostMallocDefault));
     CHIP_HIP(c, hipHostGetDevicePointer((void **)&c->topk_dev, c->topk_host, 0));
     for (Slot &s : c->slots) {
@@ -247,6 +251,8 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
         // pinned + mapped: the deciding workgroup stores the record here directly, no D2H copy kernel per tick
         CHIP_HIP(c, hipHostMalloc(&s.host, sizeof(chip_tick_result), hipHostMallocDefault));
         CHIP_HIP(c, hipHostGetDevicePointer((void **)&s.dev, s.host, 0));
+        s.seq_host = c->seq_host_all + (&s - c->slots);
+        CHIP_HIP(c, hipHostGetDevicePointer((void **)&s.seq_dev, s.seq_host, 0));
     }
     if (env_int("CHIP_SCAN_STAMPS", 0)) {
         CHIP_HIP(c, hipMalloc(&c->stamps_dev, (size_t)c->max_grid * 16 * 4 * sizeof(unsigned long long)));
@@ -345,7 +351,11 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
         a.tick_l = l;
         a.locality = p->locality;
         a.thresh = p->thresh;
+        a.fused_seq = c->next_seq_dev;       // (nullptr unless tick_enqueue_slot asked for a pollable completion)
+        a.fused_seq_val = c->next_seq_val;
     }
+    c->last_enqueue_fused = fused;
+    c->next_seq_dev = nullptr;
 
     // The merge that last read this buffer ran kRing ticks ago; only when it is not already complete (a stalled ctx
     // stream) does the scan stream need a barrier packet -- in steady state this costs nothing.
@@ -496,6 +506,7 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
     const int64_t n_pub = published_rows(c);
     int rc = tick_prepare(c->xchg ? INT64_MAX : n_pub, c->last_l, l, p, &status, &k);
     if (rc != CHIP_OK) return rc;
+    s.poll = false;
     s.prev_last_l = c->last_l;
     s.tick_l = l;
     s.last_l_ptr = &c->last_l;
@@ -517,8 +528,12 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
         if (rc != CHIP_OK) return rc;
         hipStream_t s_done = c->s_query;
         hipEvent_t merged = nullptr;
+        s.poll = false;
+        if (c->tick_poll) { s.seq_want = ++c->tick_seq; c->next_seq_dev = s.seq_dev; c->next_seq_val = s.seq_want; }
         rc = enqueue_scan_merge(c, k, q, 3, CHIP_DEFAULT_TOPK, l, p, nullptr, s.dev, true, &s_done, &merged);
+        c->next_seq_dev = nullptr;
         if (rc != CHIP_OK) return rc;
+        s.poll = c->tick_poll && c->last_enqueue_fused;   // the fused kernel stores the completion word itself
         // a same-stream tick is complete when its merge is: one event record per tick (the list buffer's merge event; the buffer is
         // not reused before kRing = 64 further enqueues, and at most CHIP_MAX_INFLIGHT - 1 = 63 ticks are uncollected)
         if (merged) s.wait_ev = merged;
@@ -533,7 +548,22 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
 int tick_collect_slot(Ctx *c, Slot &s, chip_tick_result *out)
 {
     if (!s.in_flight) return CHIP_ERR_BUSY;
-    if (!s.immediate) CHIP_HIP(c, hipEventSynchronize(s.wait_ev ? s.wait_ev : s.done));
+    if (!s.immediate) {
+        // A fused tick's last workgroup writes the record into the slot's pinned host memory and THEN stores the slot's completion word
+        // with a system-scope release: polling that word (acquire) hands the record over ~4-5 us before the stream's event would -- the
+        // end-of-kernel cache maintenance, the event's barrier packet and its signal are off the synchronous tick's critical path.  The
+        // event is still recorded (it orders the reuse of the list buffer); it is only waited for if the word does not arrive.
+        bool done = false;
+        if (s.poll) {
+            const volatile unsigned long long *w = s.seq_host;
+            for (long spin = 0; spin < (1L << 24) && !done; spin++) {
+                done = __atomic_load_n(w, __ATOMIC_ACQUIRE) == s.seq_want;
+                if (!done && (spin & 0x3fff) == 0x3fff && hipEventQuery(s.wait_ev ? s.wait_ev : s.done) != hipErrorNotReady) break;   // finished or failed: let the event say which
+            }
+        }
+        if (!done) CHIP_HIP(c, hipEventSynchronize(s.wait_ev ? s.wait_ev : s.done));
+        s.poll = false;
+    }
     *out = *s.host;
     s.in_flight = false;
     if (out->status == CHIP_TICK_FAILED) {   // a shard could not take part: the tick had no effect (:1098 was not reached)

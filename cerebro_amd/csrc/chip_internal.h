@@ -34,6 +34,8 @@ struct ScanArgs {
     // decision record itself -- a tick is then ONE launch.  fused_result == nullptr: lists only, K2 follows as a launch of its own.
     chip_tick_result *fused_result = nullptr;
     int32_t *fused_ticket = nullptr;        // arrival counter of this launch's list buffer (0 at launch, reset by the last workgroup)
+    unsigned long long *fused_seq = nullptr; // completion word of the tick's slot in pinned host memory: written (system-scope RELEASE) after the
+    unsigned long long fused_seq_val = 0;    // record, so that a host that polls it sees the record complete (chip_api.hip tick_collect_slot)
     int64_t tick_l = 0;
     int32_t locality = 0;
     double thresh = 0.0;
@@ -74,6 +76,9 @@ struct Slot {
     bool immediate = false;             // result already final on host (skipped / too short)
     int64_t prev_last_l = 0;            // last_l before this tick was enqueued ...
     int64_t tick_l = 0;                 // ... the l this tick committed ...
+    unsigned long long *seq_host = nullptr, *seq_dev = nullptr;   // completion word of this slot (pinned, device-mapped)
+    unsigned long long seq_want = 0;    // value the fused tick in flight will store there
+    bool poll = false;                  // collect by polling seq_host instead of waiting for the event
     int64_t *last_l_ptr = nullptr;      // ... and where to restore it if the tick comes back CHIP_TICK_FAILED (only while no newer
                                         //     tick has been enqueued: *last_l_ptr == tick_l)
 };
@@ -138,6 +143,12 @@ struct Ctx {
     hipEvent_t ev_scan[kRing] = {};             // scan into buffer b finished
     hipEvent_t ev_merged[kRing] = {};           // merge out of buffer b finished
     int32_t *tickets_dev = nullptr;             // [kRing] arrival counters of the fused tick (one per list buffer)
+    unsigned long long *seq_host_all = nullptr; // [CHIP_MAX_INFLIGHT] completion words of the slots (pinned)
+    unsigned long long tick_seq = 0;            // last value handed out
+    bool tick_poll = true;                      // CHIP_TICK_POLL: fused ticks are collected by polling the completion word
+    unsigned long long *next_seq_dev = nullptr; // set by tick_enqueue_slot for the enqueue that follows; taken (and cleared) by a fused launch
+    unsigned long long next_seq_val = 0;
+    bool last_enqueue_fused = false;
     bool tick_fused = true;                     // CHIP_TICK_FUSED=0 disables
     uint64_t n_enqueued = 0;
     int32_t max_grid = 0;

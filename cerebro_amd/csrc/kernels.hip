@@ -614,6 +614,8 @@ __device__ __forceinline__ void fused_tick_finish(const ScanArgs &a, char *smem,
         }
         *a.fused_result = res;
         *a.fused_ticket = 0;               // ready for the launch that reuses this list buffer (ordered behind this one by its event)
+        // completion word of the tick's slot (pinned host memory), system-scope RELEASE: a host polling it (acquire) sees the record above
+        if (a.fused_seq) __hip_atomic_store(a.fused_seq, a.fused_seq_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

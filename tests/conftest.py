@@ -9,7 +9,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 
-HIP_ARTEFACTS = [ROOT / "cerebro_amd" / "lib" / n for n in ("libcerebro_hip.so", "libcerebro_host.so", "cerebro_replay", "minimal_loop_detector",
+HIP_ARTEFACTS = [ROOT / "cerebro_amd" / "lib" / n for n in ("libcerebro_hip.so", "libcerebro_host.so", "cerebro_replay", "minimal_loop_detector", "sync_tick_latency",
                                                           "norows/libcerebro_hip.so")] + [ROOT / "tests" / "fakerccl" / "_build" / "libfakerccl.so"]
 _hip_build_error = None
 
