@@ -252,3 +252,93 @@ def test_config4_shape_one_process_per_rank_at_full_size(tmp_path):
     np.savez(tmp_path / "want.npz", sc=wsc, ix=wix)
     ret = _spawn(_worker_1m, 8, tmp_path, (str(tmp_path / "want.npz"),), BASE_ENV)
     assert len(ret) == 8
+
+
+def test_missing_peer_at_the_rendezvous_is_an_error_not_a_hang(tmp_path, monkeypatch):
+    """World 2, only rank 0 shows up: the communicator bootstrap cannot complete.  chip_comm_init_rank returns CHIP_ERR_COMM (the
+    stand-in's rendezvous deadline here; the library's own CHIP_COMM_INIT_TIMEOUT_MS helper-thread deadline covers a bootstrap that
+    never returns) -- through the real entry point, no fault-injection hook."""
+    import time
+    code = (
+        "import sys, time\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "from cerebro_amd import capi\n"
+        "with capi.Chip(256, device=0, shard_rank=0, shard_count=2) as chip:\n"
+        "    t0 = time.time()\n"
+        "    try:\n"
+        "        chip.comm_init_rank(capi.comm_unique_id(), 2, 0)\n"
+        "        print('UNEXPECTED ok')\n"
+        "    except capi.ChipError as e:\n"
+        "        print('status', e.status, 'after', round(time.time() - t0, 1), 's', 'exchange', chip.info()['exchange'])\n")
+    env = dict(os.environ, CHIP_RCCL_LIBRARY=str(FAKE), FAKERCCL_TIMEOUT_MS="1500", CHIP_COMM_INIT_TIMEOUT_MS="20000")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "status -11" in r.stdout and "exchange 0" in r.stdout, r.stdout + r.stderr[-500:]      # CHIP_ERR_COMM, no exchange attached
+    assert time.time() - t0 < 60
+
+
+def _worker_peer_dies(rank, world, uid_path, ret):
+    import time
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    import scenarios
+    from cerebro_amd import capi
+    D, N = 256, 600
+    db = scenarios.build_db(3, N, D, [])
+    chip = capi.Chip(D, device=0, shard_rank=rank, shard_count=world)
+    if rank == 0:
+        with open(uid_path + ".tmp", "wb") as f:
+            f.write(capi.comm_unique_id())
+        os.replace(uid_path + ".tmp", uid_path)
+    t0 = time.time()
+    while not os.path.exists(uid_path):
+        assert time.time() - t0 < 120
+        time.sleep(0.01)
+    chip.comm_init_rank(open(uid_path, "rb").read(), world, rank)
+    chip.append_f32(db)
+    for l in (300, 303, 306):
+        assert chip.loop_tick(l).status == capi.CHIP_TICK_SCANNED
+    if rank == 1:
+        ret[rank] = "left"
+        os._exit(0)                                   # the peer vanishes between two collective calls
+    t1 = time.time()
+    try:
+        chip.loop_tick(309)
+        ret[rank] = "UNEXPECTED ok"
+    except capi.ChipError as e:
+        ret[rank] = (e.status, round(time.time() - t1, 1), chip.last_comm_error())
+    os._exit(0)                                       # (the communicator has a dead member: no orderly teardown)
+
+
+def test_a_peer_that_dies_fails_the_next_collective_instead_of_hanging_it(tmp_path):
+    """Rank 1 of 2 exits after three ticks.  Rank 0's next tick posts its all-gather, the peer never arrives: the call comes back with
+    CHIP_ERR_COMM and chip_last_comm_error() says why -- bounded by the transport's deadline, not a hang."""
+    import torch.multiprocessing as mp
+    env = dict(BASE_ENV, FAKERCCL_TIMEOUT_MS="2000")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        ctx = mp.get_context("spawn")
+        ps = [ctx.Process(target=_worker_peer_dies, args=(r, 2, str(tmp_path / "uid.bin"), ret)) for r in range(2)]
+        for p_ in ps:
+            p_.start()
+        for p_ in ps:
+            p_.join(120)
+            assert not p_.is_alive()
+        out = dict(ret)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert out.get(1) == "left"
+    st = out.get(0)
+    assert isinstance(st, tuple) and st[0] == capi_status("CHIP_ERR_COMM") and st[1] < 30 and "fakerccl" in st[2], out
+
+
+def capi_status(name):
+    from cerebro_amd import capi
+    return getattr(capi, name)
