@@ -404,3 +404,11 @@ def test_fused_tick_handoff_stress(monkeypatch):
             for s, l in pending:
                 bad += bytes(chip.loop_tick_collect(s)) != want[l]
             assert bad == 0, (ls, bad, n)
+        # ... and one tick at a time (the live system's mode): the host collects by POLLING the slot's completion word, which the
+        # last workgroup stores with a system-scope release AFTER the record (round 5) -- a record read too early would differ
+        bad = 0
+        n_sync = max(3000, n_ticks // 8)
+        for i in range(n_sync):
+            l = tick_sets[i % 2][i % 3]
+            bad += bytes(chip.loop_tick(l, p)) != want[l]
+        assert bad == 0, (bad, n_sync)
