@@ -255,6 +255,7 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
     int *smp = reinterpret_cast<int *>(sm);                       // [16]
     int *flag = smp + 16;                                          // [4] : singular, spare
     int *prow_s = flag + 4;                                        // [parity][kPanel] physical pivot rows of a panel
+    unsigned long long *nzm = reinterpret_cast<unsigned long long *>(prow_s + 2 * kPanel);   // [parity][2] rows (0..63 | 64..92) with a non-zero multiplier in the panel (32 of the 64 spare bytes)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -610,6 +611,14 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
             Lpp[lane * kPanel + c] = L0(c);
             if (has1) Lpp[(lane + 64) * kPanel + c] = L1(c);
         }
+        {   // which rows have ANY non-zero multiplier in this panel (round 5): the Macaulay rows are sparse, 47 % of the (row, panel) pairs
+            // of the elimination have all four multipliers zero (instrumented oracle) -- the matrix waves skip those rows' updates, as the
+            // reference algorithm does (if (l != 0) ...), by the scalar branch that already skips rows used as pivots
+            const bool z0 = (L0(0) != 0.0) | (L0(1) != 0.0) | (L0(2) != 0.0) | (L0(3) != 0.0);
+            const bool z1 = has1 && ((L1(0) != 0.0) | (L1(1) != 0.0) | (L1(2) != 0.0) | (L1(3) != 0.0));
+            const unsigned long long q0 = __builtin_amdgcn_ballot_w64(z0), q1 = __builtin_amdgcn_ballot_w64(z1);
+            if (lane == 0) { nzm[par * 2] = q0; nzm[par * 2 + 1] = q1; }
+        }
 #pragma unroll
         for (int c = 0; c < BW; c++) {                               // pivot history (k is a multiple of 4: a panel never straddles step 64)
             if (k < 64) hist0 = lane == k + c ? pr_c[c] : hist0;
@@ -725,7 +734,15 @@ __global__ __launch_bounds__(kSolveThreads) __attribute__((amdgpu_waves_per_eu(4
             // `live` is wave-uniform (ty and the pivot rows are), but it is updated under a per-lane-looking condition and hipcc kept
             // it in a VGPR: every row paid v_and + v_cmp + s_and_saveexec + exec restore (62 VALU per wave and panel next to the 128
             // of the ~16 live rows' arithmetic).  From an SGPR the test is s_bitcmp1 + s_cbranch.
-            const unsigned live_s = __builtin_amdgcn_readfirstlane(live);
+            // ... and rows whose four multipliers of this panel are all zero (nzm, from the factor wave): e - 0*u - 0*u - 0*u - 0*u == e
+            unsigned nz_s;
+            {
+                const unsigned long long q0 = nzm[par * 2], q1 = nzm[par * 2 + 1];
+                const int ridx = ty + 3 * lane;                        // lane sl < 31 looks up physical row ty + 3 sl
+                const bool bit = lane < 31 && (((ridx < 64 ? q0 >> ridx : q1 >> (ridx - 64)) & 1ull) != 0ull);
+                nz_s = (unsigned)__builtin_amdgcn_ballot_w64(bit);
+            }
+            const unsigned live_s = __builtin_amdgcn_readfirstlane(live) & nz_s;
 #pragma unroll
             for (int sl = 0; sl < 31; sl++) {
                 if (live_s >> sl & 1u) {   // wave-uniform: rows already used as pivots are skipped by a scalar branch
