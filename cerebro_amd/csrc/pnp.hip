@@ -20,7 +20,7 @@
 // order as the CPU oracle), lanes only parallelise over independent outputs, so poses and inlier masks are
 // reproducible bit for bit.  Neither HBM nor MFMA bound: 0.865 M counted fp64 operations per hypothesis (profiles/pnp_flops.json;
 // 1.30 M with the dense elimination the device runs) = 1.5 % of the fp64-vector peak single-problem, 2.7 % batched; the vector pipe
-// is 33 % (pnp_build_solve) / 63 % (pnp_eig_score) busy in the batched call (profiles/pnp_pmc.json): dependent chains of lone waves
+// is 31 % (pnp_build_solve) / 63 % (pnp_eig_score) busy in the batched call (profiles/pnp_pmc.json): dependent chains of lone waves
 // (DESIGN.md 5).  Up to kPnpMaxBatch problems share one pair of launches.
 #include "ransac_common.h"
 #include <cfloat>
