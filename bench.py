@@ -520,6 +520,39 @@ def size_leg(chip, rows, plan, params, inflight, n_ticks=240, warm=20):
                          "isolated_kernel_ms": iso_s * 1e3, "launches": cnt, "algorithmic_bytes_per_launch": alg, "cache_resident": cache_resident}}
 
 
+def resident_leg(rows, n_ticks=400, warm=40):
+    """Synchronous ticks through the resident scan instance (opt-in mode CHIP_TICK_RESIDENT=1: the tick is a 64-byte command to a
+    kernel that stays on the chip, no launch) next to the same ticks launched, on a ctx of its own with `rows` + 400 synthetic rows:
+    host-to-host latency of chip_loop_tick through this (ctypes) binding, records compared byte for byte."""
+    p = capi.default_dot_params()
+    p.min_new = -(1 << 30)
+    ls = [rows + 50 + 3 * (i % 100) for i in range(warm + n_ticks)]
+    out = {}
+    for mode in ("launched", "resident"):
+        old = os.environ.pop("CHIP_TICK_RESIDENT", None)
+        if mode == "resident":
+            os.environ["CHIP_TICK_RESIDENT"] = "1"
+        try:
+            with capi.Chip(D, capacity_hint=rows + 500) as c:
+                c.append_synthetic(rows + 400, 777, [])
+                recs, lat = [], []
+                for l in ls:
+                    t1 = time.perf_counter()
+                    r = c.loop_tick(l, p)
+                    lat.append(time.perf_counter() - t1)
+                    recs.append(bytes(r))
+                lat = np.array(lat[warm:])
+                out[mode] = {"recs": recs, "mean_us": 1e6 * float(lat.mean()), "p50_us": 1e6 * float(np.median(lat)), "min_us": 1e6 * float(lat.min())}
+        finally:
+            os.environ.pop("CHIP_TICK_RESIDENT", None)
+            if old is not None:
+                os.environ["CHIP_TICK_RESIDENT"] = old
+    same = out["launched"].pop("recs") == out["resident"].pop("recs")
+    if not same:
+        raise SystemExit(f"bench: resident-instance ticks differ from launched ticks at {rows} rows")
+    return {"rows": rows, "launched": out["launched"], "resident": out["resident"], "records_identical": same, "ticks": n_ticks}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -908,6 +941,12 @@ def main():
             out["sizes"][fmt_rows(args.rows)] = {"db_rows": args.rows, "value": out["value"], "unit": "loop-queries/s", "ms_per_step": out["ms_per_step"],
                                                  "steps": args.steps,
                                                  "roofline": out["roofline"]}
+        if size_plans and n_gpus == 1 and world == 1 and args.storage == "f32" and (capi.load_library().chip_build_scan_forms() & 2):
+            # the opt-in resident scan instance at the two sizes of the reference's operating range (ctxs of their own, a few hundred ms)
+            out["resident_tick"] = {fmt_rows(r): resident_leg(r) for r in (10_000, 29_000)}
+            for name, leg in out["resident_tick"].items():
+                out["config"][f"size_{name}_sync_tick_resident_us"] = leg["resident"]["p50_us"]
+                out["config"][f"size_{name}_sync_tick_launched_us"] = leg["launched"]["p50_us"]
         if n_gpus == 1 and world == 1 and not args.no_pnp:
             out["pnp"] = pnp_leg(chip, min(args.cpu_budget, 5.0))
         if n_gpus == 1 and world == 1 and not args.no_pnp:

@@ -8,6 +8,7 @@
 #include "chip_internal.h"
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 
@@ -83,12 +84,204 @@ int env_int(const char *name, int dflt)
     return v && *v ? std::atoi(v) : dflt;
 }
 
+// ------------------------------------------------------------------------------------------------ resident scan instance
+// (CHIP_TICK_RESIDENT=1; kernels.hip db_scan_resident, chip_internal.h ResidentCmd).  Host side: one command at a time; the line is
+// written head first, tail last (x86 stores stay in order; the fences keep the compiler from moving them).
+static void resident_write_line(Ctx *c, const ResidentCmd &cmd)
+{
+    ResidentCmd *d = c->res_cmd_host;
+    __atomic_store_n(&d->head, cmd.head, __ATOMIC_RELAXED);
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    d->locality = cmd.locality;
+    d->n_rows = cmd.n_rows;
+    d->tick_l = cmd.tick_l;
+    d->thresh = cmd.thresh;
+    d->result = cmd.result;
+    d->seq_ptr = cmd.seq_ptr;
+    d->seq_val = cmd.seq_val;
+    d->dyn_claim = cmd.dyn_claim;
+    __atomic_store_n(&d->tail, cmd.head, __ATOMIC_RELEASE);
+}
+
+static uint32_t resident_next_number(Ctx *c)
+{
+    uint32_t n = c->res_cmd_no + 1;
+    if (n == 0u || n == kResidentLeave) n = 1u;
+    c->res_cmd_no = n;
+    return n;
+}
+
+static int resident_alloc(Ctx *c)
+{
+    if (c->s_resident) return CHIP_OK;
+    // A stream of the HIGHEST priority: the runtime multiplexes streams onto a few hardware queues per priority level, and a packet
+    // behind the resident kernel in its queue would wait for the instance to leave (measured: a tick stream that shared the queue
+    // stalled for the whole lease).  The ctx's other streams are of the default priority, so this one gets a queue to itself.
+    hipStream_t s = nullptr;
+    int pr_lo = 0, pr_hi = 0;
+    CHIP_HIP(c, hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
+    CHIP_HIP(c, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, pr_hi));
+    c->s_resident = s;
+    void *h = nullptr;
+    CHIP_HIP(c, hipHostMalloc(&h, 128, hipHostMallocDefault));   // the command line + the line of the exit word
+    std::memset(h, 0, 128);
+    c->res_cmd_host = static_cast<ResidentCmd *>(h);
+    c->res_exit_host = reinterpret_cast<unsigned long long *>(static_cast<char *>(h) + 64);
+    void *hd = nullptr;
+    CHIP_HIP(c, hipHostGetDevicePointer(&hd, h, 0));
+    c->res_cmd_hostdev = static_cast<uint32_t *>(hd);
+    c->res_exit_hostdev = reinterpret_cast<unsigned long long *>(static_cast<char *>(hd) + 64);
+    c->res_grid = c->n_cus * (c->scan_short_bpc > 0 ? c->scan_short_bpc : 1);
+    if (c->res_grid > c->max_grid) c->res_grid = c->max_grid;
+    CHIP_HIP(c, hipMalloc((void **)&c->res_cmd_dev, (size_t)c->max_grid * 64));
+    CHIP_HIP(c, hipMalloc((void **)&c->res_partial, (size_t)c->max_grid * CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry)));
+    CHIP_HIP(c, hipMalloc((void **)&c->res_ticket, 64));
+    return CHIP_OK;
+}
+
+// A new instance behind whatever the stream still holds (the previous one on its way out).  res_mu held.
+static int resident_launch(Ctx *c)
+{
+    ResidentArgs ra;
+    ScanArgs &a = ra.base;
+    a.seg_table = c->seg_table_dev;
+    a.seg_shift = c->seg_shift;
+    a.seg_mask = c->seg_rows - 1;
+    a.n_rows = 0;
+    a.D = c->D;
+    a.K = 1;
+    for (int i = 0; i < CHIP_MAX_NQ; i++) a.q[i] = nullptr;
+    a.idx_mul = 1;
+    a.idx_add = 0;
+    a.partial = c->res_partial;
+    a.rows_form = 1;
+    a.plain_loads = 1;
+    a.fused_ticket = c->res_ticket;
+    a.stamps = c->stamps_dev;            // tuning only (CHIP_SCAN_STAMPS=1)
+    ra.cmd_host = c->res_cmd_hostdev;
+    ra.cmd_dev = c->res_cmd_dev;
+    ra.exit_host = c->res_exit_hostdev;
+    ra.instance = ++c->res_instance;
+    ra.lease_ticks = (unsigned long long)c->res_lease_ms * 100000ull;   // s_memrealtime: 100 MHz
+    ra.done = c->res_done;
+    // the workgroups' lines still hold what the previous instance was told last (its leave mark included), the ticket whatever it left
+    CHIP_HIP(c, hipMemsetAsync(c->res_cmd_dev, 0, (size_t)c->max_grid * 64, c->s_resident));
+    CHIP_HIP(c, hipMemsetAsync(c->res_ticket, 0, 64, c->s_resident));
+    int rc = launch_resident(c, c->s_resident, ra, c->res_grid);
+    if (rc != CHIP_OK) return rc;
+    c->res_alive = true;
+    c->res_launches++;
+    return CHIP_OK;
+}
+
+static bool resident_has_left(const Ctx *c)
+{
+    return __atomic_load_n(c->res_exit_host, __ATOMIC_ACQUIRE) == c->res_instance;
+}
+
+void resident_stop(Ctx *c)
+{
+    if (!c->tick_resident) return;
+    std::lock_guard<std::mutex> lk(c->res_mu);
+    if (!c->s_resident || !c->res_alive) return;
+    if (c->res_busy && c->res_slot) {   // a command is still running: let it finish (its collector only reads the completion word)
+        const volatile unsigned long long *w = c->res_slot->seq_host;
+        for (long spin = 0; spin < (1L << 28) && __atomic_load_n(w, __ATOMIC_ACQUIRE) != c->res_slot->seq_want && !resident_has_left(c); spin++) {}
+    }
+    if (!resident_has_left(c)) {
+        ResidentCmd cmd{};
+        cmd.head = resident_next_number(c);
+        cmd.n_rows = -1;
+        resident_write_line(c, cmd);
+        c->res_done = cmd.head;          // nobody runs a leave command twice
+    }
+    (void)hipStreamSynchronize(c->s_resident);
+    c->res_alive = false;
+}
+
+static bool resident_eligible(Ctx *c, int64_t k)
+{
+    if (!c->tick_resident || c->nranks != 1 || c->xchg || c->parent || c->group || !c->own_query_stream || c->prof_on || !c->tick_fused ||
+        !c->tick_poll || c->res_busy)
+        return false;
+    // One workgroup per CU, so that the ctx's other kernels (append, PnP, ICP) still find registers and LDS next to the instance.  That
+    // shape is what a launch gives a cache-sized prefix anyway, and a synchronous tick loses nothing with it up to the reference's own
+    // capacity (29k rows: 93.9-94.7 us launched with one workgroup per CU, 93.8-94.1 with two; profiles/r05_resident.md).
+    if ((double)k * c->D * c->elem > c->res_max_bytes) return false;
+    const int grid = c->n_cus * (c->scan_short_bpc > 0 ? c->scan_short_bpc : 1);
+    return scan_rows_form(c, k, 3, grid, false) == 1;
+}
+
+// The tick as a command to the resident instance (launched here if there is none, or if the last one has left).  query_mu held.
+static int resident_tick_enqueue(Ctx *c, int64_t k, int64_t l, const chip_dot_params *p, Slot &s)
+{
+    std::lock_guard<std::mutex> lk(c->res_mu);
+    int rc = resident_alloc(c);
+    if (rc != CHIP_OK) return rc;
+    if (c->res_alive && resident_has_left(c)) c->res_alive = false;
+    if (!c->res_alive) {
+        rc = resident_launch(c);
+        if (rc != CHIP_OK) return rc;
+    }
+    s.seq_want = ++c->tick_seq;
+    ResidentCmd cmd{};
+    cmd.head = resident_next_number(c);
+    cmd.locality = p->locality;
+    cmd.n_rows = k;
+    cmd.tick_l = l;
+    cmd.thresh = p->thresh;
+    cmd.result = (uint64_t)(uintptr_t)s.dev;
+    cmd.seq_ptr = (uint64_t)(uintptr_t)s.seq_dev;
+    cmd.seq_val = s.seq_want;
+    // rows claimed within the workgroup: beyond cache-sized prefixes, as for launches (29k rows: 92.3 -> 91.7 us; neutral at 10k)
+    cmd.dyn_claim = (c->scan_claim == 1 || (c->scan_claim < 0 && (double)k * c->D * c->elem > c->scan_half_bytes)) ? 1u : 0u;
+    resident_write_line(c, cmd);
+    c->res_busy = true;
+    c->res_slot = &s;
+    c->res_ticks++;
+    s.poll = true;
+    s.resident = true;
+    s.wait_ev = nullptr;
+    return CHIP_OK;
+}
+
+// Wait for the command's completion word.  An instance that left before it saw the command (its lease ran out just then) is replaced:
+// the new one finds the line and runs it.
+static int resident_collect(Ctx *c, Slot &s)
+{
+    const volatile unsigned long long *w = s.seq_host;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long spin = 1;; spin++) {
+        if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == s.seq_want) break;
+        if ((spin & 0x3ff) == 0) {
+            std::lock_guard<std::mutex> lk(c->res_mu);
+            if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == s.seq_want) break;
+            if (c->res_alive && resident_has_left(c)) {
+                c->res_alive = false;
+                const int rc = resident_launch(c);
+                if (rc != CHIP_OK) return rc;
+            }
+            if ((spin & 0xfffff) == 0 && std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count() > 30) {
+                c->last_hip = hipErrorLaunchTimeOut;
+                return CHIP_ERR_HIP;
+            }
+        }
+    }
+    std::lock_guard<std::mutex> lk(c->res_mu);
+    c->res_busy = false;
+    c->res_slot = nullptr;
+    c->res_done = c->res_cmd_no;
+    s.resident = false;
+    return CHIP_OK;
+}
+
 static int ensure_capacity(Ctx *c, int64_t local_rows)
 {
     // caller holds append_mu
     const int64_t need = (local_rows + c->seg_rows - 1) >> c->seg_shift;
     if (need > kMaxSegs) return CHIP_ERR_OOM;
     bool grew = false;
+    if ((int64_t)c->segs.size() < need) resident_stop(c);   // the segment table is about to change
     while ((int64_t)c->segs.size() < need) {
         void *p = nullptr;
         CHIP_HIP(c, hipMalloc(&p, (size_t)c->seg_rows * c->D * c->elem));
@@ -109,6 +302,7 @@ static int ensure_capacity(Ctx *c, int64_t local_rows)
 // switch to double rows on the first append), with the append lock held or before the ctx is published.
 static int configure_storage(Ctx *c, int elem)
 {
+    resident_stop(c);
     for (void *p : c->segs) (void)hipFree(p);
     {
         std::lock_guard<std::mutex> lk(c->mu);
@@ -138,7 +332,13 @@ void ctx_destroy(chip_ctx *c)
     if (!c) return;
     if (c->group) { group_destroy(c); delete c; return; }
     (void)hipSetDevice(c->device);
+    resident_stop(c);
     (void)hipDeviceSynchronize();
+    if (c->s_resident) (void)hipStreamDestroy(c->s_resident);
+    if (c->res_cmd_host) (void)hipHostFree(c->res_cmd_host);
+    if (c->res_cmd_dev) (void)hipFree(c->res_cmd_dev);
+    if (c->res_partial) (void)hipFree(c->res_partial);
+    if (c->res_ticket) (void)hipFree(c->res_ticket);
     exchange_destroy(c);
     pnp_destroy(c);
     icp_destroy(c);
@@ -242,6 +442,11 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     CHIP_HIP(c, hipMemset(c->tickets_dev, 0, Ctx::kRing * sizeof(int32_t)));
     c->tick_fused = env_int("CHIP_TICK_FUSED", 1) != 0;
     c->tick_poll = env_int("CHIP_TICK_POLL", 1) != 0;
+    // opt-in: synchronous ticks over cache-sized prefixes go to a scan instance that stays on the chip (chip_internal.h ResidentCmd)
+    c->tick_resident = env_int("CHIP_TICK_RESIDENT", 0) != 0 && (scan_forms_built() & CHIP_SCAN_FORM_ROWS) != 0;
+    c->res_max_bytes = (double)env_int("CHIP_RESIDENT_MAX_MIB", 512) * 1024 * 1024;   // 32k rows of 4096 floats: the reference's capacity is 29k
+    c->res_lease_ms = env_int("CHIP_RESIDENT_LEASE_MS", 250);
+    if (c->res_lease_ms < 1) c->res_lease_ms = 1;
     CHIP_HIP(c, hipHostMalloc(&c->seq_host_all, sizeof(unsigned long long) * CHIP_MAX_INFLIGHT, hipHostMallocDefault));
     std::memset(c->seq_host_all, 0, sizeof(unsigned long long) * CHIP_MAX_INFLIGHT);
     CHIP_HIP(c, hipHostMalloc(&c->topk_host, (size_t)CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry), hipHostMallocDefault));
@@ -255,8 +460,8 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
         CHIP_HIP(c, hipHostGetDevicePointer((void **)&s.seq_dev, s.seq_host, 0));
     }
     if (env_int("CHIP_SCAN_STAMPS", 0)) {
-        CHIP_HIP(c, hipMalloc(&c->stamps_dev, (size_t)c->max_grid * 16 * 4 * sizeof(unsigned long long)));
-        CHIP_HIP(c, hipMemset(c->stamps_dev, 0, (size_t)c->max_grid * 16 * 4 * sizeof(unsigned long long)));
+        CHIP_HIP(c, hipMalloc(&c->stamps_dev, ((size_t)c->max_grid * 16 * 4 + 64) * sizeof(unsigned long long)));   // (+ 8 launch-wide stamps behind the waves')
+        CHIP_HIP(c, hipMemset(c->stamps_dev, 0, ((size_t)c->max_grid * 16 * 4 + 64) * sizeof(unsigned long long)));
     }
     rc = pnp_create(c);
     if (rc != CHIP_OK) return rc;
@@ -526,6 +731,14 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
         RingGuard rg(c);
         rc = query_row_ptrs(c, rows, 3, l, q);
         if (rc != CHIP_OK) return rc;
+        if (resident_eligible(c, k)) {
+            rc = resident_tick_enqueue(c, k, l, p, s);
+            if (rc != CHIP_OK) return rc;
+            s.immediate = false;
+            s.in_flight = true;
+            c->last_l = l;                 // :1098
+            return CHIP_OK;
+        }
         hipStream_t s_done = c->s_query;
         hipEvent_t merged = nullptr;
         s.poll = false;
@@ -554,7 +767,11 @@ int tick_collect_slot(Ctx *c, Slot &s, chip_tick_result *out)
         // end-of-kernel cache maintenance, the event's barrier packet and its signal are off the synchronous tick's critical path.  The
         // event is still recorded (it orders the reuse of the list buffer); it is only waited for if the word does not arrive.
         bool done = false;
-        if (s.poll) {
+        if (s.resident) {
+            const int rc = resident_collect(c, s);
+            if (rc != CHIP_OK) { s.in_flight = false; s.poll = false; return rc; }
+            done = true;
+        } else if (s.poll) {
             const volatile unsigned long long *w = s.seq_host;
             for (long spin = 0; spin < (1L << 24) && !done; spin++) {
                 done = __atomic_load_n(w, __ATOMIC_ACQUIRE) == s.seq_want;
@@ -1178,13 +1395,25 @@ int chip_get_info(const chip_ctx *c, chip_info *info)
     return CHIP_OK;
 }
 
+// Tuning aid, not part of the ABI (no declaration in cerebro_hip.h): how many ticks the resident scan instance (CHIP_TICK_RESIDENT=1) has
+// served and how many instances were launched for them -- tests use it to prove which path a tick took.
+int chip_debug_resident_stats(chip_ctx *c, int64_t *ticks, int64_t *launches)
+{
+    if (!c || !ticks || !launches || c->group) return CHIP_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->res_mu);
+    *ticks = c->res_ticks;
+    *launches = c->res_launches;
+    return CHIP_OK;
+}
+
 // Tuning aid, not part of the ABI (no declaration in cerebro_hip.h): with CHIP_SCAN_STAMPS=1 the row-batched scan kernel leaves four
 // s_memrealtime (100 MHz) stamps per wave -- entry, queries staged, rows done, block merge done -- of the most recent launch.
 int chip_debug_scan_stamps(chip_ctx *c, unsigned long long *out, int64_t n_waves)
 {
-    if (!c || !out || c->group || !c->stamps_dev || n_waves > (int64_t)c->max_grid * 16) return CHIP_ERR_INVALID_ARG;
+    if (!c || !out || c->group || !c->stamps_dev || n_waves > (int64_t)c->max_grid * 16 + 16) return CHIP_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> qlk(c->query_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
+    resident_stop(c);
     CHIP_HIP(c, hipDeviceSynchronize());
     CHIP_HIP(c, hipMemcpy(out, c->stamps_dev, (size_t)n_waves * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CHIP_OK;
@@ -1195,6 +1424,7 @@ int chip_profile_enable(chip_ctx *c, int32_t on)
     if (!c) return CHIP_ERR_INVALID_ARG;
     if (c->group) return group_profile_enable(c, on);
     std::lock_guard<std::mutex> qlk(c->query_mu);
+    if (on) resident_stop(c);       // profiled launches want the chip as a launch finds it
     c->prof_on = on != 0;
     return CHIP_OK;
 }

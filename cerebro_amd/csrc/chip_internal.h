@@ -41,6 +41,37 @@ struct ScanArgs {
     double thresh = 0.0;
 };
 
+// ---- resident scan (opt-in: CHIP_TICK_RESIDENT=1; kernels.hip db_scan_resident, chip_api.hip resident_*) ----
+// A synchronous tick over a cache-sized prefix is ~4 us of host API up to the doorbell + ~3 us from the doorbell to the first wave in
+// front of a ~29 us kernel (profiles/r05_short_scan.md).  With the mode on, ONE instance of the row-batched scan stays on the chip (one
+// workgroup per CU, the shape such a tick launches anyway) and runs the scan body once per COMMAND: the host writes a 64-byte line in
+// pinned memory, workgroup 0 polls it over PCIe and relays it to the other workgroups through device memory.
+struct ResidentCmd {           // exactly one 64-byte line: read by the device with ONE wave load, accepted when head == tail
+    uint32_t head;             // command number, written first ...
+    int32_t locality;
+    int64_t n_rows;            // rows of the prefix;  < 0: leave
+    int64_t tick_l;            // the tick's l (queries: rows l-1, l-2, l-3)
+    double thresh;
+    uint64_t result;           // chip_tick_result * (device address of the slot's pinned record)
+    uint64_t seq_ptr;          // the slot's completion word (device address) ...
+    uint64_t seq_val;          // ... and what to store there
+    uint32_t dyn_claim;
+    uint32_t tail;             // ... == head, written last
+};
+static_assert(sizeof(ResidentCmd) == 64, "one cache line, one PCIe read");
+constexpr uint32_t kResidentLeave = 0xffffffffu;   // head / tail of the line that sends the workgroups home (never a command number)
+
+struct ResidentArgs {
+    ScanArgs base;                    // everything a command does not carry (segment table, D, lists, ticket, shard map)
+    const uint32_t *cmd_host;         // the ResidentCmd line (device address of pinned host memory)
+    uint32_t *cmd_dev;                // one 64-byte line per workgroup in device memory: workgroup 0 copies the accepted line into each
+    unsigned long long *exit_host;    // the instance stores its id here (system-scope release) when it leaves
+    unsigned long long instance;
+    unsigned long long lease_ticks;   // 100 MHz ticks without a command after which the instance leaves by itself (a dead host must
+                                      // not hold the chip; a live one relaunches on its next tick)
+    uint32_t done;                    // number of the last command completed before this instance was launched
+};
+
 struct MergeArgs {
     const chip_topk_entry *in;      // [n_lists][NQ][K]
     int32_t n_lists;
@@ -55,6 +86,7 @@ struct MergeArgs {
 struct Ctx;
 
 // kernels.hip
+int launch_resident(Ctx *c, hipStream_t s, const ResidentArgs &ra, int grid);   // CHIP_ERR_UNSUPPORTED in a build without the rows form
 int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid);
 int launch_merge(Ctx *c, hipStream_t s, const MergeArgs &a, int nq);
 int scan_grid_for(const Ctx *c, int64_t n_rows, int nq, bool q64);
@@ -79,6 +111,7 @@ struct Slot {
     unsigned long long *seq_host = nullptr, *seq_dev = nullptr;   // completion word of this slot (pinned, device-mapped)
     unsigned long long seq_want = 0;    // value the fused tick in flight will store there
     bool poll = false;                  // collect by polling seq_host instead of waiting for the event
+    bool resident = false;              // the tick went to the resident scan instance: there is no event, the completion word is all
     int64_t *last_l_ptr = nullptr;      // ... and where to restore it if the tick comes back CHIP_TICK_FAILED (only while no newer
                                         //     tick has been enqueued: *last_l_ptr == tick_l)
 };
@@ -150,6 +183,25 @@ struct Ctx {
     unsigned long long next_seq_val = 0;
     bool last_enqueue_fused = false;
     bool tick_fused = true;                     // CHIP_TICK_FUSED=0 disables
+    // resident scan instance (CHIP_TICK_RESIDENT=1; chip_api.hip resident_*): guarded by query_mu like the slots
+    bool tick_resident = false;
+    double res_max_bytes = 512.0 * 1024 * 1024; // prefixes up to this size take it (CHIP_RESIDENT_MAX_MIB)
+    int32_t res_lease_ms = 250;                 // CHIP_RESIDENT_LEASE_MS
+    hipStream_t s_resident = nullptr;
+    ResidentCmd *res_cmd_host = nullptr;        // pinned line + its device address
+    uint32_t *res_cmd_hostdev = nullptr;
+    uint32_t *res_cmd_dev = nullptr;
+    unsigned long long *res_exit_host = nullptr, *res_exit_hostdev = nullptr;
+    chip_topk_entry *res_partial = nullptr;
+    int32_t *res_ticket = nullptr;
+    unsigned long long res_instance = 0;        // id of the instance launched last (0: none yet)
+    bool res_alive = false;                     // launched and not yet seen to have left
+    bool res_busy = false;                      // a command is in flight (one at a time)
+    uint32_t res_cmd_no = 0, res_done = 0;      // last number posted / last number seen complete
+    int32_t res_grid = 0;
+    Slot *res_slot = nullptr;                   // the slot of the command in flight
+    int64_t res_ticks = 0, res_launches = 0;    // ticks it has served / instances launched (chip_debug_resident_stats)
+    std::mutex res_mu;                          // the instance's state: queriers (query_mu held) and the appender (append_mu held) take it last
     uint64_t n_enqueued = 0;
     int32_t max_grid = 0;
     chip_topk_entry *topk_dev = nullptr;      // [CHIP_MAX_NQ][CHIP_MAX_TOPK]
@@ -256,6 +308,8 @@ int tick_collect_slot(Ctx *c, Slot &s, chip_tick_result *out);
 int sync_topk_out(Ctx *c, int nq, int K, double *scores, int64_t *idx);
 int ctx_scores_local(Ctx *c, int64_t k, const void *q, double *u_global, int64_t stride_mul, int64_t stride_add);
 int env_int(const char *name, int dflt);
+void resident_stop(Ctx *c);    // retire the resident scan instance and wait until it has left the chip (no-op without one): called before
+                               // anything that rewrites the segment table, frees device memory or wants the chip to itself
 constexpr uint32_t kCreateStoreMask = 3u;   // CHIP_CREATE_STORE_F32 | CHIP_CREATE_STORE_F64
 
 // ---- chip_multi.hip: exchange of per-shard lists inside the library (RCCL / device copies), groups of sub-contexts ----

@@ -540,8 +540,36 @@ __device__ __forceinline__ void rows_take(double (&d)[2], double)
 // into the pinned host slot: no K2 launch, no launch gap, no second kernel's ramp (a 10k-row tick spent ~15 us of its stream's time in
 // the one-workgroup merge and ~6 us in front of it, profiles/r03_tick_timeline_10k.md).  Hand-off: write-through stores + completion
 // wait + device-scope ticket on the writers' side, L2-bypassing loads on the last workgroup's side (no cache-wide fences).
-template <int NQ>
-__device__ __forceinline__ void fused_tick_finish(const ScanArgs &a, char *smem, int K, int tid, int lane, int wave, int wpb)
+// What one pass of the row-batched scan is asked to do -- the fields of ScanArgs that differ from pass to pass.  A launch takes them from
+// its kernel arguments; the resident instance from the command it was sent (they then live in SGPRs: no arrays, nothing indexed).
+struct RowsPass {
+    int64_t n_rows;
+    const void *q0, *q1, *q2, *q3;
+    int32_t dyn_claim;
+    chip_tick_result *fused_result;
+    unsigned long long *fused_seq;
+    unsigned long long fused_seq_val;
+    int64_t tick_l;
+    int32_t locality;
+    double thresh;
+};
+__device__ __forceinline__ RowsPass rows_pass_of(const ScanArgs &a)
+{
+    RowsPass t;
+    t.n_rows = a.n_rows;
+    t.q0 = a.q[0]; t.q1 = a.q[1]; t.q2 = a.q[2]; t.q3 = a.q[3];
+    t.dyn_claim = a.dyn_claim;
+    t.fused_result = a.fused_result;
+    t.fused_seq = a.fused_seq;
+    t.fused_seq_val = a.fused_seq_val;
+    t.tick_l = a.tick_l;
+    t.locality = a.locality;
+    t.thresh = a.thresh;
+    return t;
+}
+
+template <int NQ, bool TOGETHER, bool XSTAMP>
+__device__ __forceinline__ void fused_tick_finish(const ScanArgs &a, const RowsPass &t, char *smem, int K, int tid, int lane, int wave, int wpb)
 {
     int *last = reinterpret_cast<int *>(smem);                                  // LDS is free again: the lists have been consumed
     chip_topk_entry *wbest = reinterpret_cast<chip_topk_entry *>(smem + 64);    // [wpb][NQ]
@@ -561,61 +589,115 @@ __device__ __forceinline__ void fused_tick_finish(const ScanArgs &a, char *smem,
     if (tid == 0) *last = __hip_atomic_fetch_add(a.fused_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
     __syncthreads();
     if (!*last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    double bs[NQ];
-    int64_t bi[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        bs[q] = -INFINITY; bi[q] = -1;
-        // one entry per workgroup of the launch; grid-stride, so a block smaller than the grid (CHIP_SCAN_BLOCK=256) drops nothing
-        for (int wg = tid; wg < (int)gridDim.x; wg += (int)blockDim.x) {
-            const chip_topk_entry e = load_entry_agent(a.partial + ((int64_t)wg * NQ + q) * K);   // bypasses this XCD's L2
-            if (key_gt(e.score, e.idx, bs[q], bi[q])) { bs[q] = e.score; bi[q] = e.idx; }
-        }
+    unsigned long long *xstamp = nullptr;   // tuning only (the resident instance with CHIP_SCAN_STAMPS=1): pass-wide stamps behind the waves'
+    if constexpr (XSTAMP) xstamp = a.stamps ? a.stamps + (size_t)gridDim.x * wpb * 4 : nullptr;
+    if (xstamp && tid == 0) xstamp[5] = (unsigned long long)wall_clock64();
+    // (The resident instance leaves the fence out: everything this workgroup reads from memory from here on is read by agent-scope loads,
+    //  which are coherent at that scope by themselves -- 0.84 us of the pass, measured; tests/test_resident_gpu.py compares every record
+    //  of tens of thousands of consecutive, different commands.  The launched kernels keep it: belt and braces.)
+    if constexpr (!XSTAMP) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (xstamp && tid == 0) xstamp[2] = (unsigned long long)wall_clock64();
+    // One entry per workgroup of the launch and query; grid-stride, so a block smaller than the grid (CHIP_SCAN_BLOCK=256) drops
+    // nothing.  TOGETHER (the R = 1 kernels, which have the registers for it): the NQ loads of a workgroup's entries are issued
+    // before the first compare -- one round trip to memory instead of NQ; the others reduce one query at a time.
+    auto reduce_store = [&](double s, int64_t i, int q) {
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
-            const double os = __shfl_xor(bs[q], m, 64);
-            const int64_t oi = __shfl_xor(bi[q], m, 64);
-            if (key_gt(os, oi, bs[q], bi[q])) { bs[q] = os; bi[q] = oi; }
+            const double os = __shfl_xor(s, m, 64);
+            const int64_t oi = __shfl_xor(i, m, 64);
+            if (key_gt(os, oi, s, i)) { s = os; i = oi; }
         }
-        if (lane == 0) { chip_topk_entry e; e.score = bs[q]; e.idx = bi[q]; wbest[wave * NQ + q] = e; }
+        if (lane == 0) { chip_topk_entry e; e.score = s; e.idx = i; wbest[wave * NQ + q] = e; }
+    };
+    if constexpr (TOGETHER) {
+        double bs[NQ];
+        int64_t bi[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) { bs[q] = -INFINITY; bi[q] = -1; }
+        for (int wg = tid; wg < (int)gridDim.x; wg += (int)blockDim.x) {
+            chip_topk_entry e[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) e[q] = load_entry_agent(a.partial + ((int64_t)wg * NQ + q) * K);   // bypasses this XCD's L2
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+                if (key_gt(e[q].score, e[q].idx, bs[q], bi[q])) { bs[q] = e[q].score; bi[q] = e[q].idx; }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) reduce_store(bs[q], bi[q], q);
+    } else {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            double bs = -INFINITY;
+            int64_t bi = -1;
+            for (int wg = tid; wg < (int)gridDim.x; wg += (int)blockDim.x) {
+                const chip_topk_entry e = load_entry_agent(a.partial + ((int64_t)wg * NQ + q) * K);   // bypasses this XCD's L2
+                if (key_gt(e.score, e.idx, bs, bi)) { bs = e.score; bi = e.idx; }
+            }
+            reduce_store(bs, bi, q);
+        }
     }
+    if (xstamp && tid == 0) xstamp[6] = (unsigned long long)wall_clock64();
     __syncthreads();
-    if (tid == 0) {
+    if (wave != 0) return;
+    if (xstamp && tid == 0) xstamp[7] = (unsigned long long)wall_clock64();
+    // the waves' bests -> the launch's best per query.  TOGETHER: lane 16 q + w takes wave w's entry of query q and a four-step
+    // butterfly inside each group of 16 lanes finishes it (a max under a total order: the same entry whatever the order); the others
+    // keep the serial loop of one lane (1.8 us of a 10k-row tick, measured -- but no extra registers).
+    double maxv[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int64_t argmax[3] = {-1, -1, -1};
+    if constexpr (TOGETHER) {
+        const int q = lane >> 4, w = lane & 15;
+        double sc = -INFINITY;
+        int64_t ix = -1;
+        if (q < NQ && w < wpb) { const chip_topk_entry e = wbest[w * NQ + q]; sc = e.score; ix = e.idx; }
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+            const double os = __shfl_xor(sc, m, 64);
+            const int64_t oi = __shfl_xor(ix, m, 64);
+            if (key_gt(os, oi, sc, ix)) { sc = os; ix = oi; }
+        }
+#pragma unroll
+        for (int qq = 0; qq < 3; qq++)
+            if (qq < NQ) { maxv[qq] = readlane_f64(sc, 16 * qq); argmax[qq] = readlane_i64(ix, 16 * qq); }
+    } else {
+        for (int q = 0; q < 3; q++)
+            if (q < NQ)
+                for (int w = 0; w < wpb; w++) {
+                    const chip_topk_entry e = wbest[w * NQ + q];
+                    if (key_gt(e.score, e.idx, maxv[q], argmax[q])) { maxv[q] = e.score; argmax[q] = e.idx; }
+                }
+    }
+    if (lane == 0) {
         chip_tick_result res;
         res.status = CHIP_TICK_SCANNED;
         res.found = 0;
         res.idx_curr = -1;
         res.idx_prev = -1;
         res.score = 0.0;
-        for (int q = 0; q < 3; q++) {
-            double s = -INFINITY;
-            int64_t i = -1;
-            if (q < NQ)
-                for (int w = 0; w < wpb; w++) {
-                    const chip_topk_entry e = wbest[w * NQ + q];
-                    if (key_gt(e.score, e.idx, s, i)) { s = e.score; i = e.idx; }
-                }
-            res.argmax[q] = i;
-            res.maxv[q] = s;
-        }
+        for (int q = 0; q < 3; q++) { res.argmax[q] = argmax[q]; res.maxv[q] = maxv[q]; }
         if (NQ >= 3 && res.argmax[0] >= 0 && res.argmax[1] >= 0 && res.argmax[2] >= 0) {
             // Cerebro.cpp:1056  abs(u_argmax-um_argmax) < LOCALITY && abs(u_argmax-umm_argmax) < LOCALITY && u_max > THRESH
             int64_t d1 = res.argmax[0] - res.argmax[1];
             int64_t d2 = res.argmax[0] - res.argmax[2];
             if (d1 < 0) d1 = -d1;
             if (d2 < 0) d2 = -d2;
-            if (d1 < a.locality && d2 < a.locality && res.maxv[0] > a.thresh) {
+            if (d1 < t.locality && d2 < t.locality && res.maxv[0] > t.thresh) {
                 res.found = 1;
-                res.idx_curr = a.tick_l - 1;  // Cerebro.cpp:1080
+                res.idx_curr = t.tick_l - 1;  // Cerebro.cpp:1080
                 res.idx_prev = res.argmax[0];
                 res.score = res.maxv[0];
             }
         }
-        *a.fused_result = res;
-        *a.fused_ticket = 0;               // ready for the launch that reuses this list buffer (ordered behind this one by its event)
-        // completion word of the tick's slot (pinned host memory), system-scope RELEASE: a host polling it (acquire) sees the record above
-        if (a.fused_seq) __hip_atomic_store(a.fused_seq, a.fused_seq_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        *t.fused_result = res;
+        // ready for the pass that reuses this list buffer: a launch is ordered behind this one by its event; a command to the resident
+        // instance arrives with no kernel boundary in between, so the reset is written THROUGH like the entries (agent-scope store)
+        __hip_atomic_store(a.fused_ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (xstamp) xstamp[3] = (unsigned long long)wall_clock64();
+        // completion word of the tick's slot (pinned host memory), system-scope RELEASE: a host polling it (acquire) sees the record above.
+        // (The release is needed as it stands: the record's stores to host memory are held in this XCD's L2 until it is written back --
+        //  with a completed-stores wait and a relaxed store of the word instead, the host read the PREVIOUS tick's record, every time.)
+        if (t.fused_seq) __hip_atomic_store(t.fused_seq, t.fused_seq_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (xstamp) xstamp[4] = (unsigned long long)wall_clock64();
     }
 }
 
@@ -624,14 +706,14 @@ __device__ __forceinline__ void fused_tick_finish(const ScanArgs &a, char *smem,
 // the rows form (every scan takes the one-row kernel, same bits, short prefixes ~10-25 % slower) instead of no library at all;
 // chip_get_info().scan_forms says which build this is.
 #ifndef CHIP_NO_ROWS_FORM
-template <typename T, int NQ, int R, bool NTL>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase / 2))) void db_scan_topk_rows(ScanArgs a)
+// The body of the row-batched scan: one pass of the hot path over a prefix for the workgroup that runs it.  Two kernels inline it:
+// db_scan_topk_rows (one launch per scan) and db_scan_resident (below: a kernel that stays on the chip and runs it once per command).
+template <typename T, int NQ, int R, bool NTL, bool RESIDENT = false>
+__device__ __forceinline__ void scan_rows_body(const ScanArgs &a, const RowsPass &t, char *smem)
 {
     typedef typename Vec16<T>::type V;
     constexpr int N = Vec16<T>::N, CH = 64 * N, U = 4;
     static_assert(kRowsVgprBase + 16 * R <= 128, "load targets beyond the 128 VGPRs of a 16-waves-per-CU kernel");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    asm volatile("" ::: CHIP_ROWS_CLOBBERS);                       // makes the code object allocate the asm-owned registers
     const T *qs = reinterpret_cast<const T *>(smem);  // [NQ][D]
     const int D = a.D;
     const int K = a.K;
@@ -642,7 +724,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
     const int64_t tw = (int64_t)gridDim.x * wpb;
     const int64_t g = (int64_t)blockIdx.x * wpb + wave;           // this wave's first row (same row -> wave map as db_scan_topk)
     const int nb = D / (CH * U);                                   // 4 KiB batches per row
-    const int64_t rbase = g, rstep = tw, rlim = a.n_rows;        // this wave's rows: rbase + i * rstep < rlim (the same row -> wave map as db_scan_topk)
+    const int64_t rbase = g, rstep = tw, rlim = t.n_rows;        // this wave's rows: rbase + i * rstep < rlim (the same row -> wave map as db_scan_topk)
     const int npass = rbase < rlim ? (int)((rlim - 1 - rbase) / (R * rstep)) + 1 : 0;
     const int total = npass * nb;                                  // batches this wave consumes (wave-uniform)
 
@@ -652,9 +734,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
     {
         const int cpq = (int)((size_t)D * sizeof(T) / 1024);
         const uint32_t lds0 = lds_byte_addr(smem);
+        // the query bases as opaque SGPR values, SELECTED below, not indexed: the resident instance holds the pass in registers, and
+        // a select between loads of neighbouring fields would be turned back into an indexed load of a stack copy
+        uint64_t qb0 = (uint64_t)(uintptr_t)t.q0, qb1 = (uint64_t)(uintptr_t)t.q1, qb2 = (uint64_t)(uintptr_t)t.q2, qb3 = (uint64_t)(uintptr_t)t.q3;
+        asm volatile("" : "+s"(qb0), "+s"(qb1), "+s"(qb2), "+s"(qb3));
         for (int i = wave; i < NQ * cpq; i += wpb) {
             const int q = i / cpq, ch = i - q * cpq;
-            glds16_q(static_cast<const char *>(a.q[q]) + (size_t)ch * 1024 + lane * 16, lds0 + (uint32_t)i * 1024u);
+            uint64_t qp = qb0;
+            if (NQ > 1 && q == 1) qp = qb1;
+            if (NQ > 2 && q == 2) qp = qb2;
+            if (NQ > 3 && q == 3) qp = qb3;
+            glds16_q(reinterpret_cast<const char *>((uintptr_t)qp) + (size_t)ch * 1024 + lane * 16, lds0 + (uint32_t)i * 1024u);
         }
     }
 
@@ -677,7 +767,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
         if constexpr (R > 2) rows_issue<NTL, rows_slot_reg<R>(u, R > 2 ? 2 : 0), (u) * 1024>(vo_, row[R > 2 ? 2 : 0]);  \
     } while (0)
 
-    if constexpr (R == 1) if (a.dyn_claim && tid == 0)   // the claim counter: units 0 .. wpb-1 are the waves' first rows (set before the barrier below)
+    if constexpr (R == 1) if (t.dyn_claim && tid == 0)   // the claim counter: units 0 .. wpb-1 are the waves' first rows (set before the barrier below)
         *reinterpret_cast<uint32_t *>(smem + (size_t)NQ * D * sizeof(T) + (size_t)wpb * NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry)) = (uint32_t)wpb;
     if (total > 0) {
         set_rows(0);
@@ -736,7 +826,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
 
     int pass = 0, b = 0;
     bool dyn = false;
-    if constexpr (R == 1) dyn = a.dyn_claim != 0;
+    if constexpr (R == 1) dyn = t.dyn_claim != 0;
     if (dyn) {
       if constexpr (R == 1) {
         // ---- rows CLAIMED within the workgroup (round 5) -------------------------------------------------------------------------
@@ -749,8 +839,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
         uint32_t *ctr = reinterpret_cast<uint32_t *>(smem + (size_t)NQ * D * sizeof(T) + (size_t)wpb * NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry));
         const int64_t wg0 = (int64_t)blockIdx.x * wpb;
         int n_units = 0;
-        if (a.n_rows > wg0) {
-            const int64_t span = a.n_rows - wg0, pf = span / tw, rem = span - pf * tw;
+        if (t.n_rows > wg0) {
+            const int64_t span = t.n_rows - wg0, pf = span / tw, rem = span - pf * tw;
             n_units = (int)(pf * wpb + (rem < wpb ? rem : wpb));
         }
         auto unit_row = [&](int u) { return (int64_t)(u / wpb) * tw + wg0 + (u % wpb); };
@@ -835,9 +925,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
 #undef CHIP_ROWS_FMA_HALF
 #undef CHIP_ROWS_ISSUE_SLOT
     if (stamp && lane == 0) stamp[2] = wall_clock64();
-    block_merge_lists<NQ>(a, lists, K, lane, wave, wpb, a.fused_result != nullptr);
-    if (a.fused_result != nullptr) fused_tick_finish<NQ>(a, smem, K, tid, lane, wave, wpb);
+    block_merge_lists<NQ>(a, lists, K, lane, wave, wpb, t.fused_result != nullptr);
+    if (t.fused_result != nullptr) fused_tick_finish<NQ, R == 1, RESIDENT>(a, t, smem, K, tid, lane, wave, wpb);
     if (stamp && lane == 0) stamp[3] = wall_clock64();
+}
+
+template <typename T, int NQ, int R, bool NTL>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase / 2))) void db_scan_topk_rows(ScanArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    asm volatile("" ::: CHIP_ROWS_CLOBBERS);                       // makes the code object allocate the asm-owned registers
+    scan_rows_body<T, NQ, R, NTL>(a, rows_pass_of(a), smem);
 }
 
 template <typename T, int NQ, int R, bool NTL>
@@ -846,6 +944,128 @@ static int launch_scan_rows(Ctx *c, hipStream_t s, const ScanArgs &a, int grid, 
     if (lds > 65536) CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_scan_topk_rows<T, NQ, R, NTL>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((db_scan_topk_rows<T, NQ, R, NTL>), dim3(grid), dim3(block), lds, s, a);
+    CHIP_HIP(c, hipGetLastError());
+    return CHIP_OK;
+}
+
+// ---- the resident instance of the row-batched scan (opt-in, chip_internal.h ResidentCmd / ResidentArgs) ----
+// One workgroup per CU stays on the chip and runs scan_rows_body<T, 3, 1, temporal> once per command -- the fused tick with nothing
+// launched: no packet, no dispatch, no ramp of workgroup starts.  Wave 0 of workgroup 0 polls the host's 64-byte command line
+// (system-scope loads over PCIe, 16 lanes = the whole line in one request; a line is accepted when head == tail) and copies it into
+// every other workgroup's OWN line in device memory (one 64-byte write-through store each); wave 0 of the others polls its line
+// (agent-scope loads: 256 pollers on 256 different lines, no hot spot).  The command reaches the waves of a workgroup through LDS.
+// What the instance may read without a cache invalidation per command: published DB rows are immutable and a row is first read after
+// it has been published, so no cache ever holds an older copy of one; the SEGMENT TABLE does change when the DB opens a new segment,
+// so the host retires the instance before it touches the table (chip_api.hip resident_stop) and the next tick launches a new one.
+// Every wait has a way out: workgroup 0 leaves (and sends the others home) after lease_ticks without a command, the others after four
+// times that without a go word, so a host that died -- or a workgroup that never became resident -- cannot hold the chip.
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); }
+__device__ __forceinline__ unsigned long long uni_clock() { return uni64((uint64_t)wall_clock64()); }   // (the compiler takes the clock for a per-lane value)
+
+template <typename T>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase / 2))) void db_scan_resident(ResidentArgs ra)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t cmd_s[16];
+    asm volatile("" ::: CHIP_ROWS_CLOBBERS);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t done = ra.done;
+    unsigned long long t_last = uni_clock();
+    unsigned long long *xstamp = ra.base.stamps ? ra.base.stamps + (size_t)gridDim.x * (blockDim.x >> 6) * 4 : nullptr;   // tuning only
+    for (;;) {
+        if (wave == 0) {
+            // lanes 16 k .. 16 k + 15 hold the 16 words of a line; a line is accepted when head == tail, is not the last one run, is not 0
+            uint32_t v = 0, head = 0;
+            bool leave = false;
+            auto fresh = [&](uint32_t x) {
+                head = (uint32_t)__builtin_amdgcn_readlane((int)x, 0);
+                return head == (uint32_t)__builtin_amdgcn_readlane((int)x, 15) && head != done && head != 0u;
+            };
+            if (blockIdx.x == 0) {
+                // The host's line, over PCIe: FOUR loads in flight, a quarter of a round trip apart (each is re-issued when it returns, so
+                // the spacing holds) -- a command waits for the next load to leave, then for that load's round trip: 1.125 instead of 1.5.
+                const uint32_t *line = ra.cmd_host + (lane & 15);
+#define CHIP_POLL_HOST() __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define CHIP_POLL_STEP(P)                                                         \
+    if (fresh(P)) { v = P; break; }                                               \
+    if (uni_clock() - t_last > ra.lease_ticks) { leave = true; break; }           \
+    P = CHIP_POLL_HOST();
+                uint32_t p0 = CHIP_POLL_HOST();
+                __builtin_amdgcn_s_sleep(10);
+                uint32_t p1 = CHIP_POLL_HOST();
+                __builtin_amdgcn_s_sleep(10);
+                uint32_t p2 = CHIP_POLL_HOST();
+                __builtin_amdgcn_s_sleep(10);
+                uint32_t p3 = CHIP_POLL_HOST();
+                for (;;) {
+                    CHIP_POLL_STEP(p0)
+                    CHIP_POLL_STEP(p1)
+                    CHIP_POLL_STEP(p2)
+                    CHIP_POLL_STEP(p3)
+                }
+#undef CHIP_POLL_STEP
+#undef CHIP_POLL_HOST
+            } else {
+                const uint32_t *line = ra.cmd_dev + (size_t)blockIdx.x * 16 + (lane & 15);
+                for (;;) {
+                    v = __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (fresh(v)) break;
+                    if (uni_clock() - t_last > 4 * ra.lease_ticks) { leave = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (!leave) leave = __builtin_amdgcn_readlane((int)v, 3) < 0;   // n_rows < 0 (words 2, 3): the host retires the instance
+            if (leave) {   // the line every workgroup acts on: n_rows = -1 under the leave mark
+                v = (lane & 15) == 0 || (lane & 15) == 15 ? kResidentLeave : ((lane & 15) == 2 || (lane & 15) == 3 ? 0xffffffffu : 0u);
+            }
+            if (xstamp && blockIdx.x == 0 && lane == 0 && !leave) xstamp[0] = (unsigned long long)wall_clock64();
+            if (lane < 16) cmd_s[lane] = v;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            // the relay, by ALL waves of workgroup 0 (one wave alone issues a write-through store instruction every ~60 ns: 3.9 us for
+            // 64 of them, measured): one 64-byte store per workgroup, four workgroups per instruction -- a line arrives whole
+            const uint32_t w = cmd_s[lane & 15];
+            for (int j = tid >> 4; j < (int)gridDim.x; j += (int)(blockDim.x >> 4))
+                if (j > 0) __hip_atomic_store(ra.cmd_dev + (size_t)j * 16 + (lane & 15), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (xstamp && tid == 0 && cmd_s[0] != kResidentLeave) xstamp[1] = (unsigned long long)wall_clock64();
+        }
+        const ResidentCmd *cm = reinterpret_cast<const ResidentCmd *>(cmd_s);
+        const int64_t n_rows = (int64_t)uni64((uint64_t)cm->n_rows);
+        if (n_rows < 0) {
+            if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(ra.exit_host, ra.instance, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        const ScanArgs &a = ra.base;      // K = 1 and the fused-tick fields that do not change (ticket, list buffer) are set by the host
+        RowsPass t;
+        t.n_rows = n_rows;
+        t.tick_l = (int64_t)uni64((uint64_t)cm->tick_l);
+        t.locality = (int32_t)uni32((uint32_t)cm->locality);
+        t.thresh = __longlong_as_double((long long)uni64((uint64_t)__double_as_longlong(cm->thresh)));
+        t.fused_result = reinterpret_cast<chip_tick_result *>((uintptr_t)uni64(cm->result));
+        t.fused_seq = reinterpret_cast<unsigned long long *>((uintptr_t)uni64(cm->seq_ptr));
+        t.fused_seq_val = uni64(cm->seq_val);
+        t.dyn_claim = (int32_t)uni32(cm->dyn_claim);
+        const uint32_t number = uni32(cm->head);
+        t.q0 = row_base_uniform<T>(a, t.tick_l - 1);   // v, vm, vmm (Cerebro.cpp:987-989)
+        t.q1 = row_base_uniform<T>(a, t.tick_l - 2);
+        t.q2 = row_base_uniform<T>(a, t.tick_l - 3);
+        t.q3 = nullptr;
+        scan_rows_body<T, 3, 1, false, true>(a, t, smem);
+        done = number;
+        t_last = uni_clock();
+        __syncthreads();   // cmd_s and the lists are free again
+    }
+}
+
+template <typename T>
+static int launch_resident_T(Ctx *c, hipStream_t s, const ResidentArgs &ra, int grid, size_t lds, int block)
+{
+    if (lds > 65536) CHIP_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(db_scan_resident<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((db_scan_resident<T>), dim3(grid), dim3(block), lds, s, ra);
     CHIP_HIP(c, hipGetLastError());
     return CHIP_OK;
 }
@@ -1051,6 +1271,20 @@ int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid)
         return CHIP_ERR_UNSUPPORTED;   // chip_create bounds D so that two double queries always fit
     }
     return c->elem == 8 ? launch_scan_T<double>(c, s, a, nq, grid, lds, block) : launch_scan_T<float>(c, s, a, nq, grid, lds, block);
+}
+
+int launch_resident(Ctx *c, hipStream_t s, const ResidentArgs &ra, int grid)
+{
+#ifdef CHIP_NO_ROWS_FORM
+    (void)c; (void)s; (void)ra; (void)grid;
+    return CHIP_ERR_UNSUPPORTED;
+#else
+    int block, bpc;
+    scan_shape(c, 3, false, &block, &bpc);
+    const size_t lds = scan_lds_bytes(c, 3, 1, block, false, true);
+    if (lds + 64 > 160 * 1024 || grid > 512) return CHIP_ERR_UNSUPPORTED;
+    return c->elem == 8 ? launch_resident_T<double>(c, s, ra, grid, lds, block) : launch_resident_T<float>(c, s, ra, grid, lds, block);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ K1s

@@ -2383,6 +2383,7 @@ void pnp_destroy(Ctx *c)
 
 static int pnp_reserve(Ctx *c, PnpState *st, int N, int H, int words, int P)
 {
+    if (N > st->cap_N || H > st->cap_H || words > st->cap_words) resident_stop(c);   // hipFree waits for the whole device: not with a resident scan instance on it
     if (N > st->cap_N) {
         (void)hipFree(st->X); (void)hipHostFree(st->h_in);
         st->X = st->uv = st->h_in = nullptr; st->cap_N = 0;

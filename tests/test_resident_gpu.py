@@ -1,0 +1,153 @@
+"""GPU tests of the resident scan instance (opt-in, CHIP_TICK_RESIDENT=1: cerebro_amd/csrc/kernels.hip db_scan_resident,
+chip_api.hip resident_*): synchronous ticks over cache-sized prefixes are COMMANDS to a kernel that stays on the chip instead of
+launches.  The bar is the one of every other tick path -- the 64-byte decision record byte for byte -- against the two-launch path
+(CHIP_TICK_FUSED=0: ordinary kernel-boundary visibility) and, for one tick, against the CPU oracle; plus the life cycle: an instance
+whose lease ran out is replaced, appended rows are seen, a new DB segment retires it, other kernels of the ctx run next to it, ticks
+beyond its prefix bound and pipelined ticks take the launched path, and destroying the ctx sends it home."""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from cerebro_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+D = 4096
+
+
+def resident_stats(chip):
+    fn = chip.lib.chip_debug_resident_stats
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    t, n = C.c_int64(0), C.c_int64(0)
+    assert fn(chip.h, C.byref(t), C.byref(n)) == 0
+    return t.value, n.value
+
+
+def every_tick_params():
+    p = capi.default_dot_params()
+    p.min_new = -(1 << 30)          # every tick runs, whatever the previous l was
+    return p
+
+
+def test_resident_ticks_equal_launched_ticks_and_oracle(monkeypatch):
+    seed, n_rows = 424242, 12_100
+    ls = [3_003, 7_777, 10_050, 10_053, 10_056, 11_000, 12_001, 12_100]
+    plants = [(10_049 - j, 5_000 - j, 1) for j in range(3)] + [(12_000 - j, 2_000 - j, 1) for j in range(3)] + [(5_005, 5_000, 2)]
+    p = every_tick_params()
+    monkeypatch.setenv("CHIP_TICK_FUSED", "0")
+    monkeypatch.delenv("CHIP_TICK_RESIDENT", raising=False)
+    with capi.Chip(D, capacity_hint=n_rows) as ref:
+        ref.append_synthetic(n_rows, seed, plants)
+        want = {l: bytes(ref.loop_tick(l, p)) for l in ls}
+        assert resident_stats(ref) == (0, 0)
+    assert sum(capi.TickResult.from_buffer_copy(w).found for w in want.values()) >= 2
+    monkeypatch.delenv("CHIP_TICK_FUSED")
+    monkeypatch.setenv("CHIP_TICK_RESIDENT", "1")
+    monkeypatch.setenv("CHIP_RESIDENT_LEASE_MS", "40")
+    n_ticks = int(os.environ.get("CHIP_RESIDENT_TICKS", "60000"))
+    with capi.Chip(D, capacity_hint=n_rows) as chip:
+        chip.append_synthetic(n_rows, seed, plants)
+        bad = 0
+        for i in range(n_ticks):
+            l = ls[(i * 5) % len(ls)]
+            bad += bytes(chip.loop_tick(l, p)) != want[l]
+        assert bad == 0
+        ticks, launches = resident_stats(chip)
+        assert ticks == n_ticks and launches >= 1
+        # one record against the CPU oracle as well (prefix l - 50, queries l-1..l-3)
+        l = 10_050
+        r = chip.loop_tick(l, p)
+        qrows = oracle_lib.synth_rows(seed, [l - 1, l - 2, l - 3], D, plants)
+        wsc, wix = oracle_lib.scan_topk_synth(seed, l - 50, D, qrows, 1, plants, nthreads=os.cpu_count() or 1)
+        assert list(r.argmax) == list(wix[:, 0]) and [float(x).hex() for x in r.maxv] == [float(x).hex() for x in wsc[:, 0]]
+        assert r.found == 1 and r.idx_curr == l - 1 and r.idx_prev == 5_005   # the later exact duplicate wins the tie (Cerebro.cpp:1035-1043)
+        # the lease runs out (40 ms without a command): the instance leaves by itself, the next tick launches another
+        before = resident_stats(chip)[1]
+        time.sleep(0.4)
+        for l in ls:
+            assert bytes(chip.loop_tick(l, p)) == want[l]
+        assert resident_stats(chip)[1] == before + 1
+        # pipelined ticks: one command at a time -- the second enqueue takes the launched path; both records are right
+        chip.loop_tick_enqueue(ls[2], 0, p)
+        chip.loop_tick_enqueue(ls[3], 1, p)
+        assert bytes(chip.loop_tick_collect(1)) == want[ls[3]] and bytes(chip.loop_tick_collect(0)) == want[ls[2]]
+        t1 = resident_stats(chip)[0]
+        assert t1 == n_ticks + 1 + len(ls) + 1
+
+
+def test_resident_sees_appends_new_segments_and_other_kernels(monkeypatch):
+    """Rows appended while the instance is alive are scanned and used as queries by the next tick; a tick beyond the resident bound
+    (512 MiB prefix) is launched; opening a new DB segment (capacity exceeded) retires the instance and the following tick gets a new
+    one; a PnP-RANSAC call of the same ctx runs next to the waiting instance."""
+    seed = 99
+    n0, n1, n2 = 9_000, 10_500, 40_000
+    rng = np.random.default_rng(5)
+    extra = rng.standard_normal((n1 - n0, D)).astype(np.float32)
+    extra /= np.linalg.norm(extra, axis=1, keepdims=True)
+    extra[-2] = extra[100]                       # a revisit among the appended rows: query row n1-2 == appended row n0+100
+    extra[-3] = extra[99]
+    extra[-4] = extra[98]
+    p = every_tick_params()
+
+    def run(resident):
+        if resident:
+            monkeypatch.setenv("CHIP_TICK_RESIDENT", "1")
+            monkeypatch.setenv("CHIP_RESIDENT_LEASE_MS", "3000")
+        else:
+            monkeypatch.delenv("CHIP_TICK_RESIDENT", raising=False)
+        out = []
+        with capi.Chip(D, capacity_hint=n1) as chip:
+            chip.append_synthetic(n0, seed, [])
+            out.append(bytes(chip.loop_tick(n0, p)))
+            chip.append_f32(extra)
+            out.append(bytes(chip.loop_tick(n1 - 1, p)))           # queries n1-2, n1-3, n1-4: the planted revisit
+            out.append(bytes(chip.loop_tick(n1, p)))
+            stats_a = resident_stats(chip)
+            X, uv, _, _ = synth.make_scene(N=256, seed=3)
+            chip.pnp_ransac(X, uv, capi.default_ransac_params())   # (its first call allocates: the instance is retired for that)
+            chip.loop_tick(n1, p)
+            chip.pnp_ransac(X, uv, capi.default_ransac_params())   # ... the second runs next to the waiting instance
+            out.append(bytes(chip.loop_tick(n1, p)))
+            chip.append_synthetic(n2 - n1, seed + 1, [])           # far beyond capacity_hint: new segments
+            stats_b = resident_stats(chip)
+            out.append(bytes(chip.loop_tick(10_000, p)))           # resident again (new instance)
+            out.append(bytes(chip.loop_tick(n2, p)))               # 655 MB prefix: launched
+            out.append(bytes(chip.loop_tick(9_500, p)))
+            stats_c = resident_stats(chip)
+        return out, stats_a, stats_b, stats_c
+
+    want, *_ = run(False)
+    got, sa, sb, sc = run(True)
+    assert got == want
+    r = capi.TickResult.from_buffer_copy(got[1])
+    assert r.found == 1 and r.idx_prev == n0 + 100
+    assert sa[0] == 3 and sa[1] >= 1
+    assert sc[0] == sa[0] + 4 and sc[1] >= sa[1] + 2   # the ticks after the PnP allocation and after the new segment each found no instance
+
+
+def test_resident_at_the_reference_capacity(monkeypatch):
+    """29k rows (the reference's own capacity, Cerebro.cpp:946): the instance runs the prefix with one workgroup per CU and rows
+    claimed within the workgroup (the launched tick: two workgroups per CU) -- same records, and the ticks went through it."""
+    seed, n_rows = 31, 29_400
+    ls = [20_000, 25_003, 29_000, 29_003, 29_399, 29_400]
+    plants = [(28_999 - j, 14_000 - j, 1) for j in range(3)] + [(29_398 - j, 50 - j, 1) for j in range(3)]
+    p = every_tick_params()
+    monkeypatch.delenv("CHIP_TICK_RESIDENT", raising=False)
+    with capi.Chip(D, capacity_hint=n_rows) as ref:
+        ref.append_synthetic(n_rows, seed, plants)
+        want = {l: bytes(ref.loop_tick(l, p)) for l in ls}
+    assert sum(capi.TickResult.from_buffer_copy(w).found for w in want.values()) == 2
+    monkeypatch.setenv("CHIP_TICK_RESIDENT", "1")
+    with capi.Chip(D, capacity_hint=n_rows) as chip:
+        chip.append_synthetic(n_rows, seed, plants)
+        n = int(os.environ.get("CHIP_RESIDENT_TICKS_29K", "3000"))
+        bad = 0
+        for i in range(n):
+            l = ls[(i * 5) % len(ls)]
+            bad += bytes(chip.loop_tick(l, p)) != want[l]
+        assert bad == 0
+        assert resident_stats(chip)[0] == n
