@@ -101,6 +101,8 @@ static void resident_write_line(Ctx *c, const ResidentCmd &cmd)
     d->seq_val = cmd.seq_val;
     d->dyn_claim = cmd.dyn_claim;
     __atomic_store_n(&d->tail, cmd.head, __ATOMIC_RELEASE);
+    // a line in device memory is written through the write-combining BAR mapping: push it out (one full 64-byte line = one PCIe write)
+    if (c->res_cmd_in_vram) __builtin_ia32_sfence();
 }
 
 static uint32_t resident_next_number(Ctx *c)
@@ -125,12 +127,42 @@ static int resident_alloc(Ctx *c)
     void *h = nullptr;
     CHIP_HIP(c, hipHostMalloc(&h, 128, hipHostMallocDefault));   // the command line + the line of the exit word
     std::memset(h, 0, 128);
+    c->res_pinned = h;
     c->res_cmd_host = static_cast<ResidentCmd *>(h);
     c->res_exit_host = reinterpret_cast<unsigned long long *>(static_cast<char *>(h) + 64);
     void *hd = nullptr;
     CHIP_HIP(c, hipHostGetDevicePointer(&hd, h, 0));
     c->res_cmd_hostdev = static_cast<uint32_t *>(hd);
     c->res_exit_hostdev = reinterpret_cast<unsigned long long *>(static_cast<char *>(hd) + 64);
+    // Where the command line lives.  With a large PCIe BAR the host can store straight into device memory, and a posted write that the
+    // device then finds locally beats a line the device has to fetch over PCIe (ping-pong with one polling wave: 1.89 us against 2.52,
+    // scripts/probes/bar_pingpong.hip).  Used when the device says so AND a pattern written that way reads back through a copy;
+    // CHIP_RESIDENT_BAR=0 keeps the line in pinned host memory.
+    int large_bar = 0;
+    if (env_int("CHIP_RESIDENT_BAR", 1) != 0 && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) == hipSuccess && large_bar) {
+        void *v = nullptr;
+        if (hipMalloc(&v, 64) == hipSuccess) {
+            bool ok = hipMemset(v, 0, 64) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+            uint32_t back[16] = {0};
+            if (ok) {
+                volatile uint32_t *w = static_cast<volatile uint32_t *>(v);
+                for (int i = 0; i < 16; i++) w[i] = 0x5eed0000u + (uint32_t)i;
+                __builtin_ia32_sfence();
+                ok = hipMemcpy(back, v, 64, hipMemcpyDeviceToHost) == hipSuccess;
+                for (int i = 0; ok && i < 16; i++) ok = back[i] == 0x5eed0000u + (uint32_t)i;
+                for (int i = 0; i < 16; i++) w[i] = 0u;
+                __builtin_ia32_sfence();
+            }
+            if (ok) {
+                c->res_cmd_vram = v;
+                c->res_cmd_in_vram = true;
+                c->res_cmd_host = static_cast<ResidentCmd *>(v);
+                c->res_cmd_hostdev = static_cast<uint32_t *>(v);
+            } else {
+                (void)hipFree(v);
+            }
+        }
+    }
     c->res_grid = c->n_cus * (c->scan_short_bpc > 0 ? c->scan_short_bpc : 1);
     if (c->res_grid > c->max_grid) c->res_grid = c->max_grid;
     CHIP_HIP(c, hipMalloc((void **)&c->res_cmd_dev, (size_t)c->max_grid * 64));
@@ -335,7 +367,8 @@ void ctx_destroy(chip_ctx *c)
     resident_stop(c);
     (void)hipDeviceSynchronize();
     if (c->s_resident) (void)hipStreamDestroy(c->s_resident);
-    if (c->res_cmd_host) (void)hipHostFree(c->res_cmd_host);
+    if (c->res_pinned) (void)hipHostFree(c->res_pinned);
+    if (c->res_cmd_vram) (void)hipFree(c->res_cmd_vram);
     if (c->res_cmd_dev) (void)hipFree(c->res_cmd_dev);
     if (c->res_partial) (void)hipFree(c->res_partial);
     if (c->res_ticket) (void)hipFree(c->res_ticket);

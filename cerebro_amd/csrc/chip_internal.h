@@ -63,7 +63,7 @@ constexpr uint32_t kResidentLeave = 0xffffffffu;   // head / tail of the line th
 
 struct ResidentArgs {
     ScanArgs base;                    // everything a command does not carry (segment table, D, lists, ticket, shard map)
-    const uint32_t *cmd_host;         // the ResidentCmd line (device address of pinned host memory)
+    const uint32_t *cmd_host;         // the ResidentCmd line the host writes: pinned host memory, or device memory behind a large PCIe BAR
     uint32_t *cmd_dev;                // one 64-byte line per workgroup in device memory: workgroup 0 copies the accepted line into each
     unsigned long long *exit_host;    // the instance stores its id here (system-scope release) when it leaves
     unsigned long long instance;
@@ -188,7 +188,9 @@ struct Ctx {
     double res_max_bytes = 512.0 * 1024 * 1024; // prefixes up to this size take it (CHIP_RESIDENT_MAX_MIB)
     int32_t res_lease_ms = 250;                 // CHIP_RESIDENT_LEASE_MS
     hipStream_t s_resident = nullptr;
-    ResidentCmd *res_cmd_host = nullptr;        // pinned line + its device address
+    void *res_pinned = nullptr, *res_cmd_vram = nullptr;   // the allocations behind the pointers below
+    bool res_cmd_in_vram = false;               // the command line is in device memory, written by the host through the PCIe BAR
+    ResidentCmd *res_cmd_host = nullptr;        // the line as the host writes it + its device address
     uint32_t *res_cmd_hostdev = nullptr;
     uint32_t *res_cmd_dev = nullptr;
     unsigned long long *res_exit_host = nullptr, *res_exit_hostdev = nullptr;
