@@ -524,6 +524,7 @@ def resident_leg(rows, n_ticks=400, warm=40):
     """Synchronous ticks through the resident scan instance (opt-in mode CHIP_TICK_RESIDENT=1: the tick is a 64-byte command to a
     kernel that stays on the chip, no launch) next to the same ticks launched, on a ctx of its own with `rows` + 400 synthetic rows:
     host-to-host latency of chip_loop_tick through this (ctypes) binding, records compared byte for byte."""
+    from cerebro_amd import capi
     p = capi.default_dot_params()
     p.min_new = -(1 << 30)
     ls = [rows + 50 + 3 * (i % 100) for i in range(warm + n_ticks)]

@@ -16,6 +16,6 @@ for r in 10000 29000; do timeout 300 python scripts/gpu_resident_stamps.py $r 2>
 } > $OUT/resident_latency.txt 2>&1
 cat $OUT/resident_latency.txt | cut -c1-200
 if [ "${1:-}" = "full" ]; then
-  timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee $OUT/pytest_gpu.log
+  timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu_full.log 2>&1; grep -E "passed|failed|Error|^FAILED" $OUT/pytest_gpu_full.log | tail -8 | tee $OUT/pytest_gpu.log
   timeout 600 python bench.py > $OUT/bench_default.log 2>&1; tail -c 3000 $OUT/bench_default.log
 fi

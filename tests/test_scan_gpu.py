@@ -326,12 +326,18 @@ def test_sharded_tick_over_rccl_world1():
     import torch
     import torch.distributed as dist
     from cerebro_amd import sharded
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    for attempt in range(5):     # (a port that was free a moment ago can be taken by the time the store binds it: seen once on the pool)
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            break
+        except (RuntimeError, OSError):
+            if attempt == 4:
+                raise
     try:
         D, N = 1024, 900
         plants, loops, _ = scenarios.loop_plants(N, 4, seed=3)
