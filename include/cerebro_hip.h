@@ -231,7 +231,11 @@ typedef struct {
     double  maxv[3];     /* u_max, um_max, umm_max                                                        */
 } chip_tick_result;
 
-/* Synchronous tick (single-GPU ctx, shard_count == 1). */
+/* Synchronous tick (single-GPU ctx, shard_count == 1).
+ * Environment, read at chip_create: CHIP_TICK_RESIDENT=1 turns ticks over prefixes of up to 512 MiB into commands to a scan kernel
+ * that stays on the chip between ticks (no launch per tick: ~3.5 us less per call; same results).  The instance leaves by itself
+ * 250 ms after its last command and is retired before the library frees device memory or grows the DB by a segment; calls of OTHER
+ * libraries that wait for the whole device (hipFree, hipDeviceSynchronize) wait for that lease.  Off by default. */
 int chip_loop_tick(chip_ctx *ctx, int64_t l, const chip_dot_params *p, chip_tick_result *out);
 /* Pipelined form: enqueue up to CHIP_MAX_INFLIGHT - 1 ticks without host synchronisation, collect later.  Scans run
  * back to back on an internal stream; the one-workgroup merge of tick i (ctx stream) overlaps the scan of tick i+1. */
