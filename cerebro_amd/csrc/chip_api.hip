@@ -288,7 +288,7 @@ static int resident_collect(Ctx *c, Slot &s)
         if ((spin & 0x3ff) == 0) {
             std::lock_guard<std::mutex> lk(c->res_mu);
             if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == s.seq_want) break;
-            if (c->res_alive && resident_has_left(c)) {
+            if (!c->res_alive || resident_has_left(c)) {   // left by its lease, or retired by another thread (resident_stop) before it saw the line
                 c->res_alive = false;
                 const int rc = resident_launch(c);
                 if (rc != CHIP_OK) return rc;
@@ -326,6 +326,10 @@ static int ensure_capacity(Ctx *c, int64_t local_rows)
     if (grew) {
         CHIP_HIP(c, hipMemcpyAsync(c->seg_table_dev, c->segs.data(), c->segs.size() * sizeof(void *), hipMemcpyHostToDevice, c->s_append));
         CHIP_HIP(c, hipStreamSynchronize(c->s_append));
+        // a querier may have launched another instance since the first resident_stop (a tick that was in flight): it has read the
+        // OLD table through caches nothing invalidates while it lives -- retire it too, now that the table is final.  Rows of the
+        // new segment are published only after this function returns, so no instance older than this line ever looks them up.
+        resident_stop(c);
     }
     return CHIP_OK;
 }

@@ -151,3 +151,49 @@ def test_resident_at_the_reference_capacity(monkeypatch):
             bad += bytes(chip.loop_tick(l, p)) != want[l]
         assert bad == 0
         assert resident_stats(chip)[0] == n
+
+
+def test_resident_ticks_while_another_thread_appends_across_segments(monkeypatch):
+    """The live system's two threads: the dot-product thread ticks (resident instance) while the descriptor thread appends -- here past
+    a segment boundary (32 768 rows of 4096 floats), which retires the instance while ticks are in flight and makes the ticking thread
+    launch new ones.  Every tick over the old rows must return the record it returned before the appends."""
+    import threading
+    seed, n0 = 4711, 12_000
+    ls = [5_000, 9_999, 10_050, 11_990]
+    plants = [(10_049 - j, 3_000 - j, 1) for j in range(3)]
+    p = every_tick_params()
+    monkeypatch.setenv("CHIP_TICK_RESIDENT", "1")
+    monkeypatch.setenv("CHIP_RESIDENT_LEASE_MS", "50")
+    with capi.Chip(D, capacity_hint=n0) as chip:
+        chip.append_synthetic(n0, seed, plants)
+        want = {l: bytes(chip.loop_tick(l, p)) for l in ls}
+        assert capi.TickResult.from_buffer_copy(want[10_050]).found == 1
+        stop = threading.Event()
+        errors = []
+
+        def appender():
+            try:
+                for i in range(24):
+                    chip.append_synthetic(2_000, seed + 1 + i, [])      # 12k -> 60k rows: crosses into a second segment
+                    time.sleep(0.01)
+            except Exception as e:      # noqa: BLE001
+                errors.append(e)
+            finally:
+                stop.set()
+
+        th = threading.Thread(target=appender)
+        th.start()
+        n = bad = 0
+        while not stop.is_set() or n < 2000:
+            l = ls[n % len(ls)]
+            bad += bytes(chip.loop_tick(l, p)) != want[l]
+            n += 1
+        th.join()
+        assert not errors, errors
+        assert bad == 0, (bad, n)
+        ticks, launches = resident_stats(chip)
+        assert ticks == n + len(ls) and launches >= 2
+        # ... and a tick whose queries and prefix lie in the NEW segment (launched: 0.9 GB), then a resident one again
+        r = chip.loop_tick(60_000, p)
+        assert r.status == capi.CHIP_TICK_SCANNED
+        assert bytes(chip.loop_tick(10_050, p)) == want[10_050]
