@@ -89,6 +89,29 @@ int env_int(const char *name, int dflt)
 // written head first, tail last (x86 stores stay in order; the fences keep the compiler from moving them).
 static void resident_write_line(Ctx *c, const ResidentCmd &cmd)
 {
+    if (c->res_direct) {
+        // every workgroup's own line, through the write-combining BAR mapping: eight 8-byte stores per line in address order (head first,
+        // tail last; a full 64-byte line leaves the CPU as one PCIe write), one fence for all of them
+        ResidentCmd t = cmd;
+        t.tail = t.head;
+        uint64_t w[8];
+        std::memcpy(w, &t, 64);
+        volatile uint64_t *d = reinterpret_cast<volatile uint64_t *>(c->res_cmd_host);
+        int first = 0;
+#ifndef CHIP_NO_TEST_HOOKS
+        // CHIP_TEST_RESIDENT_SKIP_MASTER=k: the k-th command never reaches workgroup 0's line -- the other workgroups run it, workgroup 0
+        // leaves at its lease without it: exactly what a command posted in the moment the lease runs out can look like (tests drive
+        // resident_collect's recovery with it)
+        if (cmd.n_rows >= 0 && c->res_test_skip_master > 0 && c->res_ticks + 1 == c->res_test_skip_master && !c->res_test_skipped) {
+            first = 1;
+            c->res_test_skipped = true;
+        }
+#endif
+        for (int j = first; j < c->res_grid; j++)
+            for (int i = 0; i < 8; i++) d[j * 8 + i] = w[i];
+        __builtin_ia32_sfence();
+        return;
+    }
     ResidentCmd *d = c->res_cmd_host;
     __atomic_store_n(&d->head, cmd.head, __ATOMIC_RELAXED);
     __atomic_thread_fence(__ATOMIC_RELEASE);
@@ -138,8 +161,15 @@ static int resident_alloc(Ctx *c)
     // device then finds locally beats a line the device has to fetch over PCIe (ping-pong with one polling wave: 1.89 us against 2.52,
     // scripts/probes/bar_pingpong.hip).  Used when the device says so AND a pattern written that way reads back through a copy;
     // CHIP_RESIDENT_BAR=0 keeps the line in pinned host memory.
+    // CHIP_RESIDENT_BAR=2 (the default) goes one step further: the host writes EVERY workgroup's line that way (16 KiB per command,
+    // 0.6 us of host time) and nobody relays: 10k rows 35.9-36.4 -> 34.7-35.0 us.  1: only workgroup 0's line, relayed on the device.
+    c->res_grid = c->n_cus * (c->scan_short_bpc > 0 ? c->scan_short_bpc : 1);
+    if (c->res_grid > c->max_grid) c->res_grid = c->max_grid;
+    CHIP_HIP(c, hipMalloc((void **)&c->res_cmd_dev, (size_t)c->max_grid * 64));
+    CHIP_HIP(c, hipMemset(c->res_cmd_dev, 0, (size_t)c->max_grid * 64));
+    const int bar_mode = env_int("CHIP_RESIDENT_BAR", 2);
     int large_bar = 0;
-    if (env_int("CHIP_RESIDENT_BAR", 1) != 0 && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) == hipSuccess && large_bar) {
+    if (bar_mode != 0 && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) == hipSuccess && large_bar) {
         void *v = nullptr;
         if (hipMalloc(&v, 64) == hipSuccess) {
             bool ok = hipMemset(v, 0, 64) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
@@ -153,7 +183,13 @@ static int resident_alloc(Ctx *c)
                 for (int i = 0; i < 16; i++) w[i] = 0u;
                 __builtin_ia32_sfence();
             }
-            if (ok) {
+            if (ok && bar_mode == 2) {          // the workgroups' lines themselves are the host's target; line 0 is workgroup 0's
+                (void)hipFree(v);
+                c->res_cmd_in_vram = true;
+                c->res_direct = true;
+                c->res_cmd_host = reinterpret_cast<ResidentCmd *>(c->res_cmd_dev);
+                c->res_cmd_hostdev = c->res_cmd_dev;
+            } else if (ok) {
                 c->res_cmd_vram = v;
                 c->res_cmd_in_vram = true;
                 c->res_cmd_host = static_cast<ResidentCmd *>(v);
@@ -163,9 +199,6 @@ static int resident_alloc(Ctx *c)
             }
         }
     }
-    c->res_grid = c->n_cus * (c->scan_short_bpc > 0 ? c->scan_short_bpc : 1);
-    if (c->res_grid > c->max_grid) c->res_grid = c->max_grid;
-    CHIP_HIP(c, hipMalloc((void **)&c->res_cmd_dev, (size_t)c->max_grid * 64));
     CHIP_HIP(c, hipMalloc((void **)&c->res_partial, (size_t)c->max_grid * CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry)));
     CHIP_HIP(c, hipMalloc((void **)&c->res_ticket, 64));
     return CHIP_OK;
@@ -196,8 +229,10 @@ static int resident_launch(Ctx *c)
     ra.instance = ++c->res_instance;
     ra.lease_ticks = (unsigned long long)c->res_lease_ms * 100000ull;   // s_memrealtime: 100 MHz
     ra.done = c->res_done;
-    // the workgroups' lines still hold what the previous instance was told last (its leave mark included), the ticket whatever it left
-    CHIP_HIP(c, hipMemsetAsync(c->res_cmd_dev, 0, (size_t)c->max_grid * 64, c->s_resident));
+    ra.direct = c->res_direct ? 1u : 0u;
+    // the workgroups' lines still hold what the previous instance was told last (its leave mark included), the ticket whatever it left.
+    // (direct mode: the lines are the host's to write -- the caller has posted the command the new instance is to find there)
+    if (!c->res_direct) CHIP_HIP(c, hipMemsetAsync(c->res_cmd_dev, 0, (size_t)c->max_grid * 64, c->s_resident));
     CHIP_HIP(c, hipMemsetAsync(c->res_ticket, 0, 64, c->s_resident));
     int rc = launch_resident(c, c->s_resident, ra, c->res_grid);
     if (rc != CHIP_OK) return rc;
@@ -251,10 +286,8 @@ static int resident_tick_enqueue(Ctx *c, int64_t k, int64_t l, const chip_dot_pa
     int rc = resident_alloc(c);
     if (rc != CHIP_OK) return rc;
     if (c->res_alive && resident_has_left(c)) c->res_alive = false;
-    if (!c->res_alive) {
-        rc = resident_launch(c);
-        if (rc != CHIP_OK) return rc;
-    }
+    const bool launch = !c->res_alive;
+    if (launch && c->res_direct) (void)hipStreamSynchronize(c->s_resident);   // the old instance is gone before its lines are rewritten
     s.seq_want = ++c->tick_seq;
     ResidentCmd cmd{};
     cmd.head = resident_next_number(c);
@@ -267,7 +300,12 @@ static int resident_tick_enqueue(Ctx *c, int64_t k, int64_t l, const chip_dot_pa
     cmd.seq_val = s.seq_want;
     // rows claimed within the workgroup: beyond cache-sized prefixes, as for launches (29k rows: 92.3 -> 91.7 us; neutral at 10k)
     cmd.dyn_claim = (c->scan_claim == 1 || (c->scan_claim < 0 && (double)k * c->D * c->elem > c->scan_half_bytes)) ? 1u : 0u;
-    resident_write_line(c, cmd);
+    c->res_pending = cmd;
+    resident_write_line(c, cmd);           // (before the launch: an instance must never find the previous one's leave mark in its lines)
+    if (launch) {
+        rc = resident_launch(c);
+        if (rc != CHIP_OK) return rc;
+    }
     c->res_busy = true;
     c->res_slot = &s;
     c->res_ticks++;
@@ -290,6 +328,17 @@ static int resident_collect(Ctx *c, Slot &s)
             if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == s.seq_want) break;
             if (!c->res_alive || resident_has_left(c)) {   // left by its lease, or retired by another thread (resident_stop) before it saw the line
                 c->res_alive = false;
+                if (c->res_direct) {
+                    // some workgroups may have found the command in their lines while workgroup 0 was already leaving: send everybody
+                    // home, wait until the instance is gone, then post the command again for a new one
+                    ResidentCmd bye{};
+                    bye.head = bye.tail = kResidentLeave;
+                    bye.n_rows = -1;
+                    resident_write_line(c, bye);
+                    (void)hipStreamSynchronize(c->s_resident);
+                    if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == s.seq_want) break;   // (it had run after all)
+                    resident_write_line(c, c->res_pending);
+                }
                 const int rc = resident_launch(c);
                 if (rc != CHIP_OK) return rc;
             }
@@ -483,6 +532,7 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     c->tick_resident = env_int("CHIP_TICK_RESIDENT", 0) != 0 && (scan_forms_built() & CHIP_SCAN_FORM_ROWS) != 0;
     c->res_max_bytes = (double)env_int("CHIP_RESIDENT_MAX_MIB", 512) * 1024 * 1024;   // 32k rows of 4096 floats: the reference's capacity is 29k
     c->res_lease_ms = env_int("CHIP_RESIDENT_LEASE_MS", 250);
+    c->res_test_skip_master = env_int("CHIP_TEST_RESIDENT_SKIP_MASTER", 0);
     if (c->res_lease_ms < 1) c->res_lease_ms = 1;
     CHIP_HIP(c, hipHostMalloc(&c->seq_host_all, sizeof(unsigned long long) * CHIP_MAX_INFLIGHT, hipHostMallocDefault));
     std::memset(c->seq_host_all, 0, sizeof(unsigned long long) * CHIP_MAX_INFLIGHT);
@@ -1441,6 +1491,16 @@ int chip_debug_resident_stats(chip_ctx *c, int64_t *ticks, int64_t *launches)
     *ticks = c->res_ticks;
     *launches = c->res_launches;
     return CHIP_OK;
+}
+
+// ... and where its command lines live: -1 no instance has been set up yet, 0 pinned host memory + relay, 1 workgroup 0's line in
+// device memory behind the PCIe BAR + relay, 2 every workgroup's line written by the host through the BAR
+int chip_debug_resident_mode(chip_ctx *c)
+{
+    if (!c || c->group) return -1;
+    std::lock_guard<std::mutex> lk(c->res_mu);
+    if (!c->s_resident) return -1;
+    return c->res_direct ? 2 : (c->res_cmd_in_vram ? 1 : 0);
 }
 
 // Tuning aid, not part of the ABI (no declaration in cerebro_hip.h): with CHIP_SCAN_STAMPS=1 the row-batched scan kernel leaves four

@@ -70,6 +70,8 @@ struct ResidentArgs {
     unsigned long long lease_ticks;   // 100 MHz ticks without a command after which the instance leaves by itself (a dead host must
                                       // not hold the chip; a live one relaunches on its next tick)
     uint32_t done;                    // number of the last command completed before this instance was launched
+    uint32_t direct;                  // 1: the HOST writes every workgroup's line (device memory behind the PCIe BAR); workgroup 0 relays
+                                      //    nothing but its own decision to leave
 };
 
 struct MergeArgs {
@@ -190,6 +192,10 @@ struct Ctx {
     hipStream_t s_resident = nullptr;
     void *res_pinned = nullptr, *res_cmd_vram = nullptr;   // the allocations behind the pointers below
     bool res_cmd_in_vram = false;               // the command line is in device memory, written by the host through the PCIe BAR
+    bool res_direct = false;                    // ... and so is every workgroup's own line (no relay): CHIP_RESIDENT_BAR=2
+    ResidentCmd res_pending{};                  // the command in flight (re-posted to an instance launched for it)
+    int64_t res_test_skip_master = 0;           // test hook (CHIP_TEST_RESIDENT_SKIP_MASTER)
+    bool res_test_skipped = false;
     ResidentCmd *res_cmd_host = nullptr;        // the line as the host writes it + its device address
     uint32_t *res_cmd_hostdev = nullptr;
     uint32_t *res_cmd_dev = nullptr;

@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
             } else {
                 const uint32_t *line = ra.cmd_dev + (size_t)blockIdx.x * 16 + (lane & 15);
                 for (;;) {
-                    v = __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = __hip_atomic_load(line, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (written by workgroup 0, or by the host through the BAR)
                     if (fresh(v)) break;
                     if (uni_clock() - t_last > 4 * ra.lease_ticks) { leave = true; break; }
                     __builtin_amdgcn_s_sleep(2);
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(kRowsVgprBase 
             if (lane < 16) cmd_s[lane] = v;
         }
         __syncthreads();
-        if (blockIdx.x == 0) {
+        if (blockIdx.x == 0 && (!ra.direct || cmd_s[0] == kResidentLeave)) {
             // the relay, by ALL waves of workgroup 0 (one wave alone issues a write-through store instruction every ~60 ns: 3.9 us for
             // 64 of them, measured): one 64-byte store per workgroup, four workgroups per instruction -- a line arrives whole
             const uint32_t w = cmd_s[lane & 15];

@@ -233,7 +233,7 @@ typedef struct {
 
 /* Synchronous tick (single-GPU ctx, shard_count == 1).
  * Environment, read at chip_create: CHIP_TICK_RESIDENT=1 turns ticks over prefixes of up to 512 MiB into commands to a scan kernel
- * that stays on the chip between ticks (no launch per tick: ~3.5 us less per call; same results).  The instance leaves by itself
+ * that stays on the chip between ticks (no launch per tick: ~4.7 us less per call; same results).  The instance leaves by itself
  * 250 ms after its last command and is retired before the library frees device memory or grows the DB by a segment; calls of OTHER
  * libraries that wait for the whole device (hipFree, hipDeviceSynchronize) wait for that lease.  Off by default. */
 int chip_loop_tick(chip_ctx *ctx, int64_t l, const chip_dot_params *p, chip_tick_result *out);

@@ -197,3 +197,38 @@ def test_resident_ticks_while_another_thread_appends_across_segments(monkeypatch
         r = chip.loop_tick(60_000, p)
         assert r.status == capi.CHIP_TICK_SCANNED
         assert bytes(chip.loop_tick(10_050, p)) == want[10_050]
+
+
+def test_resident_command_that_workgroup_0_never_saw_is_recovered(monkeypatch):
+    """A command posted in the moment the lease runs out can reach the other workgroups while workgroup 0 is already leaving: they run
+    it, the ticket never fills, the instance goes.  The test hook reproduces exactly that (the 5th command is not written into
+    workgroup 0's line); the collecting call must notice the exit, send the stragglers home, post the command again to a new instance
+    and return the right record."""
+    seed, n_rows = 5, 11_000
+    ls = [10_050, 10_053, 9_000, 10_990]
+    plants = [(10_049 - j, 1_000 - j, 1) for j in range(3)]
+    p = every_tick_params()
+    monkeypatch.delenv("CHIP_TICK_RESIDENT", raising=False)
+    with capi.Chip(D, capacity_hint=n_rows) as ref:
+        ref.append_synthetic(n_rows, seed, plants)
+        want = {l: bytes(ref.loop_tick(l, p)) for l in ls}
+    monkeypatch.setenv("CHIP_TICK_RESIDENT", "1")
+    monkeypatch.setenv("CHIP_RESIDENT_LEASE_MS", "30")
+    monkeypatch.setenv("CHIP_TEST_RESIDENT_SKIP_MASTER", "5")
+    with capi.Chip(D, capacity_hint=n_rows) as chip:
+        chip.append_synthetic(n_rows, seed, plants)
+        took = []
+        for i in range(12):
+            l = ls[i % len(ls)]
+            t0 = time.perf_counter()
+            assert bytes(chip.loop_tick(l, p)) == want[l], i
+            took.append(time.perf_counter() - t0)
+        ticks, launches = resident_stats(chip)
+        assert ticks == 12
+        fn = chip.lib.chip_debug_resident_mode
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p]
+        mode = fn(chip.h)
+        if mode == 2:                          # direct lines (large PCIe BAR): the 5th tick waited for the lease and a new instance
+            assert launches == 2 and took[4] > 0.02 and max(took[5:]) < 0.02, (launches, took)
+        else:                                  # one command line for all: nothing to skip, nothing to recover
+            assert launches == 1
