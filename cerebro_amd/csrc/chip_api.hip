@@ -1209,6 +1209,7 @@ int chip_set_stream(chip_ctx *c, void *hip_stream)
     std::lock_guard<std::mutex> lk(c->query_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
     CHIP_HIP(c, hipStreamSynchronize(c->s_query));
+    resident_stop(c);                       // ticks of a ctx on a caller's stream are launched behind that stream's work
     if (c->own_query_stream) CHIP_HIP(c, hipStreamDestroy(c->s_query));
     c->s_query = (hipStream_t)hip_stream;   // may be 0: HIP's null stream is a valid external stream
     c->own_query_stream = false;
@@ -1240,6 +1241,13 @@ int chip_synchronize(chip_ctx *c)
         if (x) CHIP_HIP(c, hipStreamSynchronize(x));
     CHIP_HIP(c, hipStreamSynchronize(c->s_query));
     CHIP_HIP(c, hipStreamSynchronize(c->s_pnp));
+    {   // a tick that went to the resident scan instance is on no stream: it is complete when its slot's completion word says so
+        std::lock_guard<std::mutex> lk(c->res_mu);
+        if (c->res_busy && c->res_slot) {
+            const volatile unsigned long long *w = c->res_slot->seq_host;
+            for (long spin = 0; spin < (1L << 28) && __atomic_load_n(w, __ATOMIC_ACQUIRE) != c->res_slot->seq_want && c->res_alive && !resident_has_left(c); spin++) {}
+        }
+    }
     return CHIP_OK;
 }
 

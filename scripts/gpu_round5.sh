@@ -1,5 +1,7 @@
 # round-5 GPU calls, one parameterised script:  bash scripts/gpu_round5.sh <step> [<step> ...]
 #   suite      pytest -m gpu (whole parity suite)             -> gpurun_out/r05/pytest_gpu.log
+#   suiteres   the same suite with CHIP_TICK_RESIDENT=1 in the environment (every synchronous tick of every test that qualifies goes through the
+#              resident scan instance)                         -> gpurun_out/r05/pytest_gpu_resident.log
 #   bench      default python bench.py                        -> gpurun_out/r05/bench_default.log
 #   trace      rocprofv3 --kernel-trace --stats of the same   -> gpurun_out/r05/prof/trace (summarised by scripts/summarize_rocprof.py r05 gpurun_out/r05/prof)
 #   scanpmc    FETCH_SIZE / WRITE_SIZE passes of the 1M tick  -> gpurun_out/r05/prof/pmc_*
@@ -13,6 +15,7 @@ O=gpurun_out/r05
 for step in "$@"; do
   case $step in
     suite) (timeout 2400 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.log 2>&1; echo pytest_exit=$? >> $O/pytest_gpu.log); grep -E "passed|failed|pytest_exit|Error" $O/pytest_gpu.log | tail -5 ;;
+    suiteres) (CHIP_TICK_RESIDENT=1 timeout 2400 python -m pytest tests -m gpu -q -x > $O/pytest_gpu_resident.log 2>&1; echo pytest_exit=$? >> $O/pytest_gpu_resident.log); grep -E "passed|failed|pytest_exit|Error" $O/pytest_gpu_resident.log | tail -5 ;;
     bench) (timeout 900 python bench.py > $O/bench_default.log 2> $O/bench_default.err; echo exit=$? >> $O/bench_default.log); tail -2 $O/bench_default.log | cut -c1-600; tail -3 $O/bench_default.err ;;
     trace) rm -rf $O/prof/trace; timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof/trace -o r05 -- python bench.py --cpu-budget 0 > $O/trace.log 2>&1; grep '^{' $O/trace.log | cut -c1-200 ;;
     scanpmc) for c in FETCH_SIZE WRITE_SIZE; do rm -rf $O/prof/pmc_$c; timeout 600 rocprofv3 --pmc $c --kernel-trace -d $O/prof/pmc_$c -o r05 -- python bench.py --steps 10 --warmup 2 --cpu-budget 0 --no-pnp --no-batch --no-sizes > $O/pmc_$c.log 2>&1; done ;;
