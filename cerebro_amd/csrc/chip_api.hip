@@ -337,13 +337,17 @@ static int resident_collect(Ctx *c, Slot &s)
                     resident_write_line(c, bye);
                     (void)hipStreamSynchronize(c->s_resident);
                     if (__atomic_load_n(w, __ATOMIC_ACQUIRE) == s.seq_want) break;   // (it had run after all)
-                    resident_write_line(c, c->res_pending);
                 }
+                // (one line for all: it may hold the leave command of a resident_stop that gave up waiting for this one)
+                resident_write_line(c, c->res_pending);
                 const int rc = resident_launch(c);
-                if (rc != CHIP_OK) return rc;
+                if (rc != CHIP_OK) { c->res_busy = false; c->res_slot = nullptr; s.resident = false; return rc; }
             }
             if ((spin & 0xfffff) == 0 && std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count() > 30) {
                 c->last_hip = hipErrorLaunchTimeOut;
+                c->res_busy = false;          // whatever state the instance is in, its lease ends it; later ticks may try again
+                c->res_slot = nullptr;
+                s.resident = false;
                 return CHIP_ERR_HIP;
             }
         }
@@ -820,11 +824,16 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
         if (rc != CHIP_OK) return rc;
         if (resident_eligible(c, k)) {
             rc = resident_tick_enqueue(c, k, l, p, s);
-            if (rc != CHIP_OK) return rc;
-            s.immediate = false;
-            s.in_flight = true;
-            c->last_l = l;                 // :1098
-            return CHIP_OK;
+            if (rc == CHIP_OK) {
+                s.immediate = false;
+                s.in_flight = true;
+                c->last_l = l;             // :1098
+                return CHIP_OK;
+            }
+            if (rc != CHIP_ERR_UNSUPPORTED) return rc;
+            c->tick_resident = false;      // this ctx's shape has no resident form: every tick is launched from here on
+            s.resident = false;
+            s.poll = false;
         }
         hipStream_t s_done = c->s_query;
         hipEvent_t merged = nullptr;
