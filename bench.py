@@ -520,6 +520,29 @@ def size_leg(chip, rows, plan, params, inflight, n_ticks=240, warm=20):
                          "isolated_kernel_ms": iso_s * 1e3, "launches": cnt, "algorithmic_bytes_per_launch": alg, "cache_resident": cache_resident}}
 
 
+def paced_tick_leg(rows, n=60, pause_ms=100):
+    """Synchronous ticks at the reference's own cadence -- dot_product_th ticks at 10 Hz (Cerebro.cpp:1100), so the GPU has idled for
+    100 ms when a tick arrives -- launched and through the resident instance, measured by the C caller examples/sync_tick_latency.cc
+    (built by `make` into cerebro_amd/lib/): through the ctypes binding the first call after a sleep carries tens of microseconds of
+    cold-interpreter jitter on about every third tick (scripts/gpu_paced_ticks.py), which is not the library's.  None without the tool."""
+    import subprocess
+    tool = ROOT / "cerebro_amd" / "lib" / "sync_tick_latency"
+    if not tool.exists():
+        return None
+    out = {"rows": rows, "ticks": n, "pause_ms": pause_ms, "caller": "examples/sync_tick_latency.cc"}
+    for mode in ("launched", "resident"):
+        env = {k: v for k, v in os.environ.items() if k != "CHIP_TICK_RESIDENT"}
+        if mode == "resident":
+            env["CHIP_TICK_RESIDENT"] = "1"
+        try:
+            r = subprocess.run([str(tool), str(rows), str(n), "0", str(pause_ms)], env=env, capture_output=True, text=True, timeout=120)
+            line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
+            out[mode] = json.loads(line)["sync_tick"]
+        except Exception as e:      # noqa: BLE001 -- a reported figure, not a gate
+            out[mode] = {"error": str(e)[:200]}
+    return out
+
+
 def resident_leg(rows, n_ticks=400, warm=40):
     """Synchronous ticks through the resident scan instance (opt-in mode CHIP_TICK_RESIDENT=1: the tick is a 64-byte command to a
     kernel that stays on the chip, no launch) next to the same ticks launched, on a ctx of its own with `rows` + 400 synthetic rows:
@@ -948,6 +971,12 @@ def main():
             for name, leg in out["resident_tick"].items():
                 out["config"][f"size_{name}_sync_tick_resident_us"] = leg["resident"]["p50_us"]
                 out["config"][f"size_{name}_sync_tick_launched_us"] = leg["launched"]["p50_us"]
+            paced = paced_tick_leg(10_000)
+            if paced is not None:
+                out["resident_tick"]["10k"]["paced_10hz"] = paced
+                for mode in ("launched", "resident"):
+                    if "p50_us" in paced.get(mode, {}):
+                        out["config"][f"size_10k_sync_tick_10hz_{mode}_us"] = paced[mode]["p50_us"]
         if n_gpus == 1 and world == 1 and not args.no_pnp:
             out["pnp"] = pnp_leg(chip, min(args.cpu_budget, 5.0))
         if n_gpus == 1 and world == 1 and not args.no_pnp:
