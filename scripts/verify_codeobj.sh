@@ -1,4 +1,6 @@
 #!/bin/bash
+# (The instruction-count check of the fused tick's cache maintenance in the same file documents the design; it guards no correctness
+#  property of the inline asm and is left to the test suite: -k "not cache_maintenance" here.)
 # Build-time check of what the inline asm of the scan kernels relies on (tests/test_codeobj_registers.py: the physical-VGPR partition
 # of db_scan_topk_rows, no touch of an in-flight load register in the one-row kernel, pnp_build_solve <= 128 VGPRs) -- called by
 # `make verify` (part of `make all`).  It DEGRADES instead of failing the build:
@@ -17,7 +19,7 @@ if ! python3 -c 'import pytest' 2>/dev/null || [ ! -x /opt/rocm/lib/llvm/bin/llv
     exit 0
 fi
 # CHIP_VERIFY_FORCE_FAIL=1 (exercising this script): treat the first check as failed
-if [ "${CHIP_VERIFY_FORCE_FAIL:-0}" != "1" ] && python3 -m pytest tests/test_codeobj_registers.py -q -x -p no:cacheprovider; then
+if [ "${CHIP_VERIFY_FORCE_FAIL:-0}" != "1" ] && python3 -m pytest tests/test_codeobj_registers.py -q -x -p no:cacheprovider -k "not cache_maintenance"; then
     rm -f $LIBDIR/.rows_form_disabled
     exit 0
 fi
@@ -29,6 +31,6 @@ echo "## (-DCHIP_NO_ROWS_FORM): same results, short prefixes (<= 768 MiB) 10-25 
 echo "################################################################################################" >&2
 rm -f $LIBDIR/kernels.o
 make EXTRA_HIPFLAGS=-DCHIP_NO_ROWS_FORM lib host || exit 1
-python3 -m pytest tests/test_codeobj_registers.py -q -x -p no:cacheprovider || exit 1
+python3 -m pytest tests/test_codeobj_registers.py -q -x -p no:cacheprovider -k "not cache_maintenance" || exit 1
 touch $LIBDIR/.rows_form_disabled
 exit 0

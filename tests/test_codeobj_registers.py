@@ -229,3 +229,29 @@ def test_pnp_eig_score_fits_four_waves_per_simd(tmp_path):
             assert get(r"\.private_segment_fixed_size") <= 32, (name, get(r"\.private_segment_fixed_size"))
             seen += 1
     assert seen == 2          # the product kernel and its stamped (tuning) twin
+
+
+@pytest.mark.skipif(not (LLVM / "llvm-objdump").exists(), reason="llvm-objdump not available")
+def test_fused_tick_cache_maintenance_is_what_the_design_says(tmp_path):
+    """The fused tick hands data across workgroups with write-through stores, a device-scope ticket and agent-scope loads -- NOT with
+    cache-wide fences in every workgroup (an agent-scope release by 256-512 workgroups made a 25 us tick take 120).  What the built
+    kernels may contain, counted on the code object:
+      * launched row-batched kernel (R = 1, three queries): ONE buffer_inv (the last workgroup's acquire), ONE buffer_wbl2 (the
+        system-scope release in front of the completion word), ONE global atomic (the ticket);
+      * resident instance: NO buffer_inv (its entry loads are agent-scope themselves), TWO buffer_wbl2 (completion word; the exit word
+        when it leaves), ONE global atomic, and its poll loops sleep (s_sleep) between loads."""
+    if not SO.exists():
+        pytest.skip("libcerebro_hip.so not built")
+    import ctypes
+    if not ctypes.CDLL(str(SO)).chip_build_scan_forms() & 2:
+        pytest.skip("a -DCHIP_NO_ROWS_FORM build has neither kernel")
+    listings = _kernel_listings(tmp_path, lambda n: ("db_scan_residentIf" in n or "db_scan_topk_rowsIfLi3ELi1ELb0" in n) and not n.endswith(".kd"))
+    assert len(listings) == 2, list(listings)
+    for name, ins in listings.items():
+        ops = [t.split(None, 1)[0] for t in ins if t]
+        count = lambda prefix: sum(o.startswith(prefix) for o in ops)      # noqa: E731
+        if "resident" in name:
+            assert count("buffer_inv") == 0 and count("buffer_wbl2") == 2 and count("global_atomic") == 1, (name, count("buffer_inv"), count("buffer_wbl2"))
+            assert count("s_sleep") >= 4
+        else:
+            assert count("buffer_inv") == 1 and count("buffer_wbl2") == 1 and count("global_atomic") == 1, (name, count("buffer_inv"), count("buffer_wbl2"))
