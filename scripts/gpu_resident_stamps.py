@@ -38,13 +38,13 @@ with capi.Chip(4096, capacity_hint=rows + 500) as chip:
             continue
         us = lambda v: (v - x[0]) / 100.0
         ent, stg, rdone, wend = us(w[:, 0]), us(w[:, 1]), us(w[:, 2]), us(w[:, 3])
-        lines.append([us(x[1]), np.median(ent), ent.max(), np.median(stg), stg.max(), rdone.mean(), rdone.max(), wend.max(), us(x[5]), us(x[2]), us(x[6]), us(x[7]),
+        lines.append([us(x[1]) if x[1] > 0 else np.nan, np.median(ent), ent.max(), np.median(stg), stg.max(), rdone.mean(), rdone.max(), wend.max(), us(x[5]), us(x[2]), us(x[6]), us(x[7]),
                       us(x[3]), us(x[4]), dt])
     a = np.array(lines)
-    names = ["relay stores issued", "wave entry p50", "wave entry max", "queries staged p50", "queries staged max", "rows done mean", "rows done max",
+    names = ["relay stores issued (nan: the host wrote every line)", "wave entry p50", "wave entry max", "queries staged p50", "queries staged max", "rows done mean", "rows done max",
              "wave end max", "last workgroup has the ticket", "its acquire fence done", "entries gathered + reduced", "barrier passed", "record stored",
              "completion word stored", "(python sync tick, us)"]
     print(f"rows={rows}  resident instance, {len(a)} samples (median over samples; us after workgroup 0 saw the command)")
     for n, col in zip(names, a.T):
-        print(f"  {n:26s} {np.median(col):7.2f}   (min {col.min():6.2f} max {col.max():6.2f})")
+        print(f"  {n:26s} {np.nanmedian(col):7.2f}   (min {np.nanmin(col):6.2f} max {np.nanmax(col):6.2f})" if not np.all(np.isnan(col)) else f"  {n:26s}     n/a")
     print(f"  ideal stream at 8 TB/s     {rows * 16384 / 8e6:7.2f}")
