@@ -212,6 +212,7 @@ def pnp_roofline(hyp_per_s: float, batch8_hyp_per_s: float):
         r["peak_measured_source"] = "profiles/r05_fp64_peak.txt (scripts/ubench/fp64_peak.hip: 8 independent chains per lane, 8 waves per SIMD)"
     if pm:
         r["valu_busy"] = pm.get("valu_busy")
+        r["valu_insts_per_hypothesis"] = pm.get("valu_insts_per_hypothesis")
         r["valu_busy_source"] = pm.get("source")
         r["kernels"] = pm.get("kernels")
     return r
@@ -449,7 +450,12 @@ def check_results(results, exp):
 SIZES_TRAFFIC = None
 
 
-def sizes_traffic(rows: int):
+def shape_name(rows: int, dim: int = 4096, storage: str = "f32") -> str:
+    """10k / 29k / 100k for the BASELINE shape (4096-D float rows); 8192x29k, f64_1M for the reference's two production shapes."""
+    return ("f64_" if storage == "f64" else "") + (f"{dim}x" if dim != 4096 else "") + fmt_rows(rows)
+
+
+def sizes_traffic(rows: int, dim: int | None = None, storage: str = "f32"):
     """HBM-side bytes per launch of the size legs' launch shapes, from the committed PMC passes (profiles/scan_traffic_sizes.json:
     rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, scripts/gpu_scan_sizes_pmc.sh); None when that shape was not measured."""
     global SIZES_TRAFFIC
@@ -458,11 +464,15 @@ def sizes_traffic(rows: int):
             SIZES_TRAFFIC = json.loads((ROOT / "profiles" / "scan_traffic_sizes.json").read_text())
         except Exception:
             SIZES_TRAFFIC = {}
-    e = SIZES_TRAFFIC.get("sizes", {}).get(str(rows)) if D == 4096 else None
+    dim = D if dim is None else dim
+    if dim == 4096 and storage == "f32":
+        e = SIZES_TRAFFIC.get("sizes", {}).get(str(rows))
+    else:
+        e = SIZES_TRAFFIC.get("shapes", {}).get(shape_name(rows, dim, storage))
     return (e or {}).get("hbm_bytes_per_launch")
 
 
-def size_leg(chip, rows, plan, params, inflight, n_ticks=240, warm=20):
+def size_leg(chip, rows, plan, params, inflight, n_ticks=240, warm=20, dim=None, elem_bytes=4):
     """The same tick loop over a SHORTER prefix of the resident DB (BASELINE configs 2 and 3: 10k and 100k keyframes).
     `plan` = (ls, expect) of plan_ticks(rows, ...).  Three figures per size, each named for what it is:
       * ms_per_step / frac_step : the pipelined loop (up to `inflight` ticks enqueued ahead; launches of consecutive ticks overlap
@@ -498,9 +508,11 @@ def size_leg(chip, rows, plan, params, inflight, n_ticks=240, warm=20):
         lat.append(time.perf_counter() - t1)
         assert r.status == 2
     lat = np.array(lat[10:])
-    alg = 4.0 * D * rows
-    cache_resident = alg <= 256 * 2**20
-    rows_form = alg <= 768 * 2**20
+    dim = D if dim is None else dim
+    alg = 4.0 * dim * rows                                   # priced on the fp32 layout whatever the storage type
+    actual = float(elem_bytes) * dim * rows                  # what the launch really has to read
+    cache_resident = actual <= 256 * 2**20
+    rows_form = actual <= 768 * 2**20
     return {"db_rows": rows, "value": n / dt, "unit": "loop-queries/s", "ms_per_step": 1e3 * step_s, "steps": n,
             "sync_tick_us": 1e6 * float(lat.mean()), "sync_tick_us_min": 1e6 * float(lat.min()),
             "roofline": {"bound": "hbm" if not cache_resident else "hbm (the 164 MB prefix is Infinity-Cache sized, 256 MiB: part of every re-read is served by the "
@@ -512,12 +524,30 @@ def size_leg(chip, rows, plan, params, inflight, n_ticks=240, warm=20):
                                         "achieved_step / frac_step: algorithmic bytes / ms_per_step of the pipelined loop, where the launches of consecutive "
                                         "ticks overlap on four tick streams (the ramp-up of one hides under the drain of the previous)",
                          "kernel_overlap_in_step": True,
-                         "traffic": sizes_traffic(rows),
+                         "frac_kernel_actual_bytes": actual / iso_s / 1e9 / HBM_PEAK_GBS, "actual_bytes_per_launch": actual,
+                         "traffic": sizes_traffic(rows, dim, "f64" if elem_bytes == 8 else "f32"),
                          "traffic_source": "profiles/scan_traffic_sizes.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this launch shape, synchronous ticks, separate run)"
-                                           if sizes_traffic(rows) is not None else None,
+                                           if sizes_traffic(rows, dim, "f64" if elem_bytes == 8 else "f32") is not None else None,
                          "kernel": "db_scan_topk_rows (row-batched form, R = 1, temporal loads: prefixes <= 768 MiB; the synchronous and the pipelined "
                                    "tick run it fused: one launch per tick)" if rows_form else "db_scan_topk",
                          "isolated_kernel_ms": iso_s * 1e3, "launches": cnt, "algorithmic_bytes_per_launch": alg, "cache_resident": cache_resident}}
+
+
+def shape_leg(rows, dim, storage, inflight, n_ticks=240):
+    """The reference's two PRODUCTION shapes on a ctx of their own: the default model emits 8192-D float32
+    descriptors into a DB capped at 29 000 columns (Cerebro.cpp:946,1021; whole_image_desc_compute_server.py:206-218), the only 4096-D
+    model (ReljaNetVLAD, server.py:148-149) emits genuine float64 => double rows.  Same tick loop, same three figures as size_leg; the
+    roofline is priced on 4*D*k (never inflated by the storage type) AND on the bytes the launch really reads."""
+    from cerebro_amd import capi
+    ls, plants, expect = plan_ticks(rows, 20 + n_ticks)
+    params = capi.default_dot_params()
+    with capi.Chip(dim, capacity_hint=ls[-1], storage=(None if storage == "f32" else "f64")) as c:
+        c.append_synthetic(ls[-1], SEED, plants)
+        c.synchronize()
+        leg = size_leg(c, rows, (ls, expect), params, inflight, n_ticks=n_ticks, dim=dim, elem_bytes=8 if storage == "f64" else 4)
+    leg["D"] = dim
+    leg["storage"] = storage
+    return leg
 
 
 def paced_tick_leg(rows, n=60, pause_ms=100):
@@ -576,6 +606,98 @@ def resident_leg(rows, n_ticks=400, warm=40):
         raise SystemExit(f"bench: resident-instance ticks differ from launched ticks at {rows} rows")
     return {"rows": rows, "launched": out["launched"], "resident": out["resident"], "records_identical": same, "ticks": n_ticks}
 
+CONFIG_KEY_CAP = 24   # the driver's record keeps the first 24 keys of `config` (BENCH_r05.json: everything appended later was dropped)
+
+# (key in the record, path into the legs) -- in PRIORITY order: the PnP half of BASELINE's metric first, then the isolated-launch
+# roofline fractions of every prefix size / production shape, then the tick latencies at the reference's cadence.
+HEADLINE_SCALARS = [
+    ("pnp_hyp_per_s", "pnp.value"),
+    ("pnp_batch8_hypotheses_per_s", "pnp.batch8_hypotheses_per_s"),
+    ("pnp_reference_mode_ms_per_call", "pnp.reference_mode_ms_per_call"),
+    ("pnp_reference_mode_pair_ms_per_call", "pnp.reference_mode_pair_ms_per_call"),
+    ("pnp_roofline_frac", "pnp.roofline.frac"),
+    ("pnp_roofline_frac_batch8", "pnp.roofline.frac_batch8"),
+    ("size_10k_roofline_frac_kernel", "sizes.10k.roofline.frac_kernel"),
+    ("size_29k_roofline_frac_kernel", "sizes.29k.roofline.frac_kernel"),
+    ("size_100k_roofline_frac_kernel", "sizes.100k.roofline.frac_kernel"),
+    ("size_8192x29k_roofline_frac_kernel", "shapes.8192x29k.roofline.frac_kernel"),
+    ("size_f64_1M_roofline_frac_kernel", "shapes.f64_1M.roofline.frac_kernel"),
+    ("size_f64_1M_roofline_frac_actual_bytes", "shapes.f64_1M.roofline.frac_kernel_actual_bytes"),
+    ("size_10k_sync_tick_10hz_launched_us", "paced_10hz.first.launched.p50_us"),
+    ("size_10k_sync_tick_10hz_resident_us", "paced_10hz.first.resident.p50_us"),
+    ("size_10k_sync_tick_us", "sizes.10k.sync_tick_us"),
+    ("size_8192x29k_sync_tick_us", "shapes.8192x29k.sync_tick_us"),
+]
+# scalars that ride in `roofline` only (after the ones above): everything else the round-5 record carried as config.* keys
+ROOFLINE_EXTRA_SCALARS = [
+    ("size_29k_sync_tick_us", "sizes.29k.sync_tick_us"),
+    ("size_f64_1M_ms_per_step", "shapes.f64_1M.ms_per_step"),
+    ("size_10k_sync_tick_10hz_launched_after_contexts_us", "paced_10hz.after_contexts.launched.p50_us"),
+    ("size_10k_sync_tick_10hz_resident_after_contexts_us", "paced_10hz.after_contexts.resident.p50_us"),
+    ("size_10k_sync_tick_launched_us", "resident_tick.10k.launched.p50_us"),
+    ("size_10k_sync_tick_resident_us", "resident_tick.10k.resident.p50_us"),
+    ("size_29k_sync_tick_launched_us", "resident_tick.29k.launched.p50_us"),
+    ("size_29k_sync_tick_resident_us", "resident_tick.29k.resident.p50_us"),
+    ("pnp_ms_per_call_1000_hyp", "pnp.ms_per_call_1000_hyp"),
+    ("pnp_flops_per_hypothesis", "pnp.roofline.flops_per_hypothesis"),
+    ("pnp_valu_insts_per_hypothesis_build_solve", "pnp.roofline.valu_insts_per_hypothesis.pnp_build_solve"),
+    ("pnp_valu_busy_build_solve", "pnp.roofline.valu_busy.pnp_build_solve"),
+    ("pnp_valu_busy_eig_score", "pnp.roofline.valu_busy.pnp_eig_score"),
+    ("pnp_cpu_baseline_hyp_per_s", "pnp.cpu_baseline.value"),
+    ("icp_hyp_per_s", "icp.value"),
+    ("icp_three_way_pose_ms", "icp.three_way_pose_ms"),
+    ("batch256_queries_per_s", "batch.value"),
+    ("batch256_roofline_frac", "batch.roofline.frac"),
+]
+
+
+def _dig(src, path):
+    v = src
+    for part in path.split("."):
+        v = v.get(part) if isinstance(v, dict) else None
+    return v if isinstance(v, (int, float)) and not isinstance(v, bool) else None
+
+
+def finalize_record(out: dict) -> dict:
+    """Lay the one JSON line out so that the DRIVER's record keeps both halves of BASELINE's metric (VERDICT r5 missing 1).  The driver
+    keeps the top-level contract keys, the scalar entries of `roofline`, and the first CONFIG_KEY_CAP keys of `config`; whole legs
+    (`pnp`, `sizes`, `shapes`, `icp`, `batch`, `resident_tick`, `paced_10hz`) are listed as extra keys and dropped.  So the legs'
+    headline scalars are repeated (a) inside `roofline`, right after the contract's own keys and before any string, and (b) as the
+    FIRST keys of `config` after `workload`; `config` is cut to CONFIG_KEY_CAP keys, what does not fit moves to `config_more`.
+    Pure function of `out` (tests/test_bench_plan.py pins the ordering and the count on a synthetic record)."""
+    head = {k: _dig(out, path) for k, path in HEADLINE_SCALARS}
+    head = {k: v for k, v in head.items() if v is not None}
+    extra = {k: _dig(out, path) for k, path in ROOFLINE_EXTRA_SCALARS}
+    extra = {k: v for k, v in extra.items() if v is not None}
+
+    roof = out["roofline"]
+    contract = ["bound", "achieved", "peak", "unit", "frac", "traffic"]
+    own_scalars = [k for k, v in roof.items() if k not in contract and isinstance(v, (int, float)) and not isinstance(v, bool)]
+    own_text = [k for k, v in roof.items() if k not in contract and k not in own_scalars and not isinstance(v, dict)]
+    new_roof = {k: roof.get(k) for k in contract}
+    for k in own_scalars:
+        new_roof[k] = roof[k]
+    new_roof.update(head)
+    new_roof.update(extra)
+    for k in own_text:
+        new_roof[k] = roof[k]
+    nested = {k: v for k, v in roof.items() if isinstance(v, dict)}
+    if nested:
+        out["roofline_context"] = nested
+    out["roofline"] = new_roof
+
+    cfg = out["config"]
+    new_cfg = {"workload": cfg["workload"]}
+    new_cfg.update(head)
+    for k, v in cfg.items():
+        new_cfg.setdefault(k, v)
+    if len(new_cfg) > CONFIG_KEY_CAP:
+        keys = list(new_cfg)
+        out["config_more"] = {k: new_cfg[k] for k in keys[CONFIG_KEY_CAP:]}
+        new_cfg = {k: new_cfg[k] for k in keys[:CONFIG_KEY_CAP]}
+    out["config"] = new_cfg
+    return out
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -603,7 +725,19 @@ def main():
                     help="testing aid for a 1-GPU box: one process, --gpus N sub-contexts all on device 0 (device-copy exchange)")
     ap.add_argument("--host-exchange", action="store_true",
                     help="N > 1 under torchrun: exchange through torch.distributed (cerebro_amd/sharded.py) instead of the in-library RCCL")
+    ap.add_argument("--no-shapes", action="store_true",
+                    help="skip the legs over the reference's production shapes (8192-D x 29k float rows, 4096-D x 1M double rows; ctxs of their own, 34 GB)")
+    ap.add_argument("--paced-ticks", type=int, default=40,
+                    help="N = 1: synchronous ticks at the reference's 10 Hz cadence per mode and position (0 = skip; each costs 0.1 s)")
     args = ap.parse_args()
+
+    # The paced (10 Hz) tick leg runs FIRST, in a process of its own, before this process has touched the GPU: round 5's record showed
+    # 69.6 us for a launched tick at 10 Hz where the standalone tool on an otherwise idle box reads 52 us, and blamed the bench
+    # process's held contexts.  Running it here, and again once every context exists (after_contexts), measures that blame.
+    paced_first = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_sizes and not args.force_sharded and not args.force_group \
+            and args.storage == "f32" and args.paced_ticks > 0 and args.rows >= 1_000_000:
+        paced_first = paced_tick_leg(10_000, n=args.paced_ticks)
 
     import gc
     import torch
@@ -936,22 +1070,27 @@ def main():
             "dtype": "f64",
             "data": "synthetic (on-device integer-domain generator, seed 20190412, planted revisits; rows are unit-norm in expectation, "
                     "norm spread ~1.1 % rms at D=4096: Irwin-Hall integers x one constant, so that CPU and GPU generate identical bits)",
-            "config": {"workload": f"{D}-D fp32 descriptors x {args.rows} keyframe DB, 3 queries/tick, top-{TOPK} + accept rule",
-                       "db_rows": args.rows, "D": D, "queries_per_tick": 3, "topk": TOPK,
-                       "storage": "fp32 rows (verified-lossless narrowing of the f64 wire type), fp64 accumulate" if args.storage == "f32"
-                                  else "fp64 rows (double-row mode: 2x the HBM bytes of the fp32 layout; roofline still priced on 4*D*k algorithmic bytes)",
-                       "loop_query": "one tick of Cerebro::descrip_N__dot__descrip_0_N = 3 descriptor queries + top-k + accept rule",
-                       "process_layout": "one process" if world == 1 else f"{world} processes (one per GPU)",
-                       "exchange": exchange,
-                       "rccl_ranks": rccl_ranks,                    # 0 = no RCCL communicator inside the library
-                       "exchange_fallback": exchange_fallback,      # True: RCCL was asked for and did NOT carry the exchange of all ranks
-                       "exchange_runtime_fallback": runtime_fallback,   # not None: the first collective (warmup) hung / failed and the run was rebuilt on another exchange
-                       "comm_init_abandoned": bool(info.get("comm_init_abandoned")) or abandon_process,   # something of this process is still stuck in RCCL: it leaves through os._exit
-                       "control_plane": (dist.get_backend() if dist is not None else None),
-                       "sharding": "single GPU" if n_gpus == 1 else (f"{world} replicas of the whole DB, independent tick streams, no collective" if replicated
-                                                                     else f"row round-robin over {n_gpus} GPUs + all-gather of top-k"),
-                       "descriptor_queries_per_s": 3 * args.steps / elapsed,
-                       "db_fill_s": t_fill, "arch": info["arch"], "n_cus": info["n_cus"]},
+            # <= CONFIG_KEY_CAP keys once finalize_record has put the legs' headline scalars in front (N = 1: 8 keys here; N > 1: no legs)
+            "config": ({"workload": f"{D}-D fp32 descriptors x {args.rows} keyframe DB, 3 queries/tick, top-{TOPK} + accept rule",
+                        "db_rows": args.rows, "D": D, "queries_per_tick": 3, "topk": TOPK,
+                        "storage": "fp32 rows, fp64 accumulate" if args.storage == "f32" else "fp64 rows (2x the HBM bytes; roofline priced on 4*D*k)",
+                        "sharding": "single GPU", "exchange": exchange}
+                       if (n_gpus == 1 and world == 1 and not args.force_sharded and not args.force_group) else
+                       {"workload": f"{D}-D fp32 descriptors x {args.rows} keyframe DB, 3 queries/tick, top-{TOPK} + accept rule",
+                        "db_rows": args.rows, "D": D, "queries_per_tick": 3, "topk": TOPK,
+                        "storage": "fp32 rows, fp64 accumulate" if args.storage == "f32" else "fp64 rows (2x the HBM bytes; roofline priced on 4*D*k)",
+                        "process_layout": "one process" if world == 1 else f"{world} processes (one per GPU)",
+                        "exchange": exchange,
+                        "rccl_ranks": rccl_ranks,                    # 0 = no RCCL communicator inside the library
+                        "exchange_fallback": exchange_fallback,      # True: RCCL was asked for and did NOT carry the exchange of all ranks
+                        "exchange_runtime_fallback": runtime_fallback,   # not None: the first collective (warmup) hung / failed and the run was rebuilt on another exchange
+                        "comm_init_abandoned": bool(info.get("comm_init_abandoned")) or abandon_process,   # something of this process is still stuck in RCCL: it leaves through os._exit
+                        "control_plane": (dist.get_backend() if dist is not None else None),
+                        "sharding": "single GPU" if n_gpus == 1 else (f"{world} replicas of the whole DB, independent tick streams, no collective" if replicated
+                                                                      else f"row round-robin over {n_gpus} GPUs + all-gather of top-k"),
+                        "descriptor_queries_per_s": 3 * args.steps / elapsed,
+                        "preflight": os.environ.get("BENCH_PREFLIGHT"),   # scripts/preflight_8gpu.sh: verdict of the device-count-gated tests, run before this line
+                        "db_fill_s": t_fill, "arch": info["arch"], "n_cus": info["n_cus"]}),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "db_scan_topk", "avg_kernel_ms": avg_s * 1e3, "launches": n_launch,
@@ -965,47 +1104,32 @@ def main():
             out["sizes"][fmt_rows(args.rows)] = {"db_rows": args.rows, "value": out["value"], "unit": "loop-queries/s", "ms_per_step": out["ms_per_step"],
                                                  "steps": args.steps,
                                                  "roofline": out["roofline"]}
-        if size_plans and n_gpus == 1 and world == 1 and args.storage == "f32" and (capi.load_library().chip_build_scan_forms() & 2):
+        single = n_gpus == 1 and world == 1 and not args.force_sharded and not args.force_group
+        out["details"] = {"storage": "fp32 rows (verified-lossless narrowing of the f64 wire type), fp64 accumulate" if args.storage == "f32"
+                                     else "fp64 rows (double-row mode: 2x the HBM bytes of the fp32 layout; roofline still priced on 4*D*k algorithmic bytes)",
+                          "loop_query": "one tick of Cerebro::descrip_N__dot__descrip_0_N = 3 descriptor queries + top-k + accept rule",
+                          "descriptor_queries_per_s": 3 * args.steps / elapsed, "db_fill_s": t_fill, "arch": info["arch"], "n_cus": info["n_cus"],
+                          "rccl_ranks": rccl_ranks, "exchange_fallback": exchange_fallback, "exchange_runtime_fallback": runtime_fallback,
+                          "test_hooks": info.get("test_hooks")}
+        if paced_first is not None:
+            # the paced leg ran BEFORE this process created any HIP context (first) and runs again now, with the
+            # bench's contexts, streams and 16+ GB of device memory alive (after_contexts) -- the pair says what the held queues cost
+            out["paced_10hz"] = {"first": paced_first, "after_contexts": paced_tick_leg(10_000, n=args.paced_ticks),
+                                 "what": "synchronous chip_loop_tick at the reference's 10 Hz cadence (100 ms idle before every tick), C caller "
+                                         "examples/sync_tick_latency.cc in a process of its own; `first` = nothing else on the GPU, `after_contexts` = "
+                                         "while this bench process holds its contexts (DB, tick streams, PnP / ICP / batch buffers)"}
+        if size_plans and single and args.storage == "f32" and (capi.load_library().chip_build_scan_forms() & 2):
             # the opt-in resident scan instance at the two sizes of the reference's operating range (ctxs of their own, a few hundred ms)
             out["resident_tick"] = {fmt_rows(r): resident_leg(r) for r in (10_000, 29_000)}
-            for name, leg in out["resident_tick"].items():
-                out["config"][f"size_{name}_sync_tick_resident_us"] = leg["resident"]["p50_us"]
-                out["config"][f"size_{name}_sync_tick_launched_us"] = leg["launched"]["p50_us"]
-            paced = paced_tick_leg(10_000)
-            if paced is not None:
-                out["resident_tick"]["10k"]["paced_10hz"] = paced
-                for mode in ("launched", "resident"):
-                    if "p50_us" in paced.get(mode, {}):
-                        out["config"][f"size_10k_sync_tick_10hz_{mode}_us"] = paced[mode]["p50_us"]
-        if n_gpus == 1 and world == 1 and not args.no_pnp:
+        if size_plans and single and args.storage == "f32" and D == 4096 and args.rows >= 1_000_000 and not args.no_shapes:
+            # the reference's two production shapes, each on a ctx of its own
+            out["shapes"] = {shape_name(29_000, 8192): shape_leg(29_000, 8192, "f32", args.inflight),
+                             shape_name(1_000_000, 4096, "f64"): shape_leg(1_000_000, 4096, "f64", args.inflight, n_ticks=60)}
+        if single and not args.no_pnp:
             out["pnp"] = pnp_leg(chip, min(args.cpu_budget, 5.0))
-        if n_gpus == 1 and world == 1 and not args.no_pnp:
             out["icp"] = icp_leg(chip)
-        if n_gpus == 1 and world == 1 and not args.no_batch and args.storage == "f32":
+        if single and not args.no_batch and args.storage == "f32":
             out["batch"] = batch_leg(chip, args.rows)
-        # The driver's record keeps the top-level contract keys plus the SCALAR entries of `config` and `roofline`; the other legs
-        # (second half of BASELINE's metric, BASELINE configs 2 / 3) are repeated there as flat scalars so that they survive.
-        def flat(dst, prefix, src, keys):
-            for k in keys:
-                v = src
-                for part in k.split("."):
-                    v = v.get(part) if isinstance(v, dict) else None
-                if isinstance(v, (int, float)) and not isinstance(v, bool):
-                    dst[prefix + k.replace(".", "_")] = v
-        if "pnp" in out:
-            flat(out["config"], "pnp_", out["pnp"], ["value", "ms_per_call_1000_hyp", "batch8_hypotheses_per_s", "reference_mode_ms_per_call",
-                                                     "reference_mode_pair_ms_per_call", "roofline.flops_per_hypothesis", "roofline.achieved",
-                                                     "roofline.frac", "roofline.frac_batch8", "roofline.peak", "roofline.peak_measured_mul_add",
-                                                     "roofline.valu_busy.pnp_build_solve", "roofline.valu_busy.pnp_eig_score", "cpu_baseline.value"])
-            out["config"]["pnp_hyp_per_s"] = out["config"].pop("pnp_value")
-        if "icp" in out:
-            flat(out["config"], "icp_", out["icp"], ["value", "reference_mode_ms_per_call", "ms_per_call_1000_hyp", "three_way_pose_ms"])
-        if "batch" in out:
-            flat(out["config"], "batch256_", out["batch"], ["value", "roofline.frac", "roofline.achieved"])
-        for name, leg in (out.get("sizes") or {}).items():
-            if name != fmt_rows(args.rows):
-                flat(out["config"], f"size_{name}_", leg, ["value", "ms_per_step", "sync_tick_us", "roofline.frac_kernel", "roofline.frac_step",
-                                                           "roofline.isolated_kernel_ms"])
         if n_gpus == 1 and world == 1 and args.cpu_budget > 0:
             eig = eigen_baseline(args.cpu_sample, min(args.cpu_budget, 10.0))
             cols_per_s, n, dt = cpu_baseline(args.cpu_sample, args.cpu_budget * 2 / 3, "eigen")
@@ -1034,7 +1158,7 @@ def main():
                                              "sample": f"{n} ticks over a {ac_cols}-column x {D} fp64 M ({dt:.1f} s), the same Eigen-order port with OpenMP "
                                                        f"static over columns, scaled to {args.rows} columns; {os.cpu_count()} logical CPUs visible, "
                                                        f"{nt} usable under the affinity mask / cgroup quota"}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(finalize_record(out)), flush=True)
 
     # whatever C stdio output is still buffered in this process (RCCL banners of torch's own communicator, ...) leaves through
     # stderr: stdout has carried the JSON line and must carry nothing after it

@@ -98,7 +98,10 @@ def test_bench_sizes_key_and_f64_storage():
             assert 0 < r["frac_kernel"] < 1 and 0 < r["frac_step"] < 1        # nothing implies more than the 8 TB/s peak
             assert leg["sync_tick_us"] >= leg["sync_tick_us_min"] > 0
             assert leg["sync_tick_us_min"] * 1e-3 >= 0.9 * r["isolated_kernel_ms"] * 0.5   # a synchronous tick contains its kernel
-    assert j["config"]["rccl_ranks"] == 0 and j["config"]["exchange_fallback"] is False
+    assert j["config"]["exchange"] == "none" and j["details"]["rccl_ranks"] == 0 and j["details"]["exchange_fallback"] is False
+    assert len(j["config"]) <= 24 and list(j["config"])[0] == "workload"
+    assert list(j["config"])[1:4] == ["size_10k_roofline_frac_kernel", "size_29k_roofline_frac_kernel", "size_100k_roofline_frac_kernel"]   # --no-pnp: the size scalars lead
+    assert j["roofline"]["size_29k_roofline_frac_kernel"] == j["sizes"]["29k"]["roofline"]["frac_kernel"]
     assert j["sizes"]["10k"]["roofline"]["cache_resident"] and not j["sizes"]["100k"]["roofline"]["cache_resident"]
     assert j["roofline"]["traffic"] is None and "ms_per_step_median" not in j
     j64 = _run_single(["--rows", "60000", "--storage", "f64", "--no-sizes"])
