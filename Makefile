@@ -22,7 +22,18 @@ lib: $(LIBDIR)/libcerebro_hip.so
 oracle: oracle/_build/liboracle.so oracle/_build/liboracle_eispack.so oracle/_build/liboracle_stats.so oracle/_build/liboracle_flops.so
 host: $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay $(LIBDIR)/minimal_loop_detector $(LIBDIR)/sync_tick_latency
 # test infrastructure that needs hipcc: the shared-memory stand-in for librccl (N ranks on one device, tests/test_fakerccl_gpu.py)
-testlibs: tests/fakerccl/_build/libfakerccl.so $(LIBDIR)/norows/libcerebro_hip.so
+testlibs: tests/fakerccl/_build/libfakerccl.so $(LIBDIR)/norows/libcerebro_hip.so $(LIBDIR)/hooks/libcerebro_hip.so
+# The TEST build of the library (-DCHIP_TEST_HOOKS): the fault-injection hooks (CHIP_TEST_COMM_INIT, CHIP_TEST_FAIL_SHARD,
+# CHIP_TEST_BATCH_OOM, CHIP_TEST_RESIDENT_SKIP_MASTER) and the knobs that change what a kernel computes (CHIP_PNP_BACKSUB,
+# CHIP_PNP_DEBUG_STOP) exist ONLY here.  `make lib` -- the product -- compiles none of them in (chip_get_info().test_hooks == 0);
+# tests/ load this one for the tests that inject faults (cerebro_amd.capi.use_hooks_library).  Never deploy it.
+HOOK_SRCS  := chip_api chip_multi pnp
+HOOK_OBJS  := $(HOOK_SRCS:%=$(LIBDIR)/hooks/%.o)
+$(LIBDIR)/hooks/%.o: $(CSRC)/%.hip $(CSRC)/chip_internal.h $(CSRC)/ransac_common.h $(CSRC)/topk_merge.h include/cerebro_hip.h
+	@mkdir -p $(LIBDIR)/hooks
+	$(HIPCC) $(HIPFLAGS) -DCHIP_TEST_HOOKS -c $< -o $@
+$(LIBDIR)/hooks/libcerebro_hip.so: $(HOOK_OBJS) $(HIP_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HOOK_OBJS) $(filter-out $(HOOK_SRCS:%=$(LIBDIR)/%.o),$(HIP_OBJS)) -o $@ -lpthread -ldl
 # the degraded build (-DCHIP_NO_ROWS_FORM: what scripts/verify_codeobj.sh falls back to), kept next to the real one so that the GPU
 # suite proves BOTH builds (tests/test_norows_build_gpu.py): only kernels.hip differs, the other objects are shared
 $(LIBDIR)/norows/libcerebro_hip.so: $(CSRC)/kernels.hip $(HIP_OBJS)

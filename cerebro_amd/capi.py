@@ -13,7 +13,22 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = Path(os.environ["CHIP_LIB"]).resolve() if os.environ.get("CHIP_LIB") else _HERE / "lib" / "libcerebro_hip.so"   # CHIP_LIB: A/B runs of another build
+PRODUCT_LIB_PATH = _HERE / "lib" / "libcerebro_hip.so"
+HOOKS_LIB_PATH = _HERE / "lib" / "hooks" / "libcerebro_hip.so"    # the TEST build (-DCHIP_TEST_HOOKS, `make testlibs`): fault injection; tests only
+
+
+def _lib_path() -> Path:
+    """CHIP_LIB=<path> loads another build of the library (same-box A/B runs, the degraded and the test builds) -- but only together with
+    CHIP_ALLOW_LIB_OVERRIDE=1: a stray CHIP_LIB must not redirect a deployed process to some other .so."""
+    override = os.environ.get("CHIP_LIB")
+    if override:
+        if os.environ.get("CHIP_ALLOW_LIB_OVERRIDE") == "1":
+            return Path(override).resolve()
+        sys.stderr.write(f"[cerebro_amd] CHIP_LIB={override} IGNORED: set CHIP_ALLOW_LIB_OVERRIDE=1 to load another build of the library\n")
+    return PRODUCT_LIB_PATH
+
+
+LIB_PATH = _lib_path()
 
 CHIP_OK = 0
 CHIP_ERR_INVALID_ARG = -1
@@ -88,7 +103,7 @@ class Info(C.Structure):
                 ("shard_count", C.c_int32), ("n_cus", C.c_int32), ("rows_global", C.c_int64),
                 ("rows_local", C.c_int64), ("capacity_local", C.c_int64), ("lossy_rows", C.c_int64),
                 ("arch", C.c_char * 32), ("storage_bytes", C.c_int32), ("n_devices", C.c_int32), ("exchange", C.c_int32),
-                ("comm_ranks", C.c_int32), ("comm_init_abandoned", C.c_int32), ("scan_forms", C.c_int32)]
+                ("comm_ranks", C.c_int32), ("comm_init_abandoned", C.c_int32), ("scan_forms", C.c_int32), ("test_hooks", C.c_int32)]
 
 
 # every symbol include/cerebro_hip.h declares: name -> (restype, argtypes)
@@ -97,6 +112,7 @@ _SIGS = {
     "chip_strerror": (C.c_char_p, [C.c_int]),
     "chip_abi_version": (C.c_int, []),
     "chip_build_scan_forms": (C.c_int, []),
+    "chip_build_test_hooks": (C.c_int, []),
     "chip_last_hip_error": (C.c_int, [_P, C.POINTER(C.c_char_p)]),
     "chip_last_comm_error": (C.c_int, [_P, C.POINTER(C.c_char_p)]),
     "chip_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
@@ -121,6 +137,8 @@ _SIGS = {
     "chip_query_batch_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
     "chip_dot_params_default": (None, [C.POINTER(DotParams)]),
     "chip_loop_tick": (C.c_int, [_P, C.c_int64, C.POINTER(DotParams), C.POINTER(TickResult)]),
+    "chip_resident_pause": (C.c_int, [_P]),
+    "chip_resident_resume": (C.c_int, [_P]),
     "chip_loop_tick_enqueue": (C.c_int, [_P, C.c_int64, C.POINTER(DotParams), C.c_int32]),
     "chip_loop_tick_collect": (C.c_int, [_P, C.c_int32, C.POINTER(TickResult)]),
     "chip_loop_last_l": (C.c_int64, [_P]),
@@ -172,6 +190,26 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
     if path is None:
         _lib = lib
     return lib
+
+
+class use_hooks_library:
+    """Context manager for tests/: Chip objects created inside it run on the TEST build of the library (lib/hooks/, fault-injection hooks
+    compiled in); outside it -- and in every product path -- the product build, which has none.  Both builds may be mapped in one process
+    (RTLD_LOCAL; each registers its own code objects)."""
+
+    def __enter__(self):
+        global _lib
+        self.saved = _lib
+        lib = load_library(HOOKS_LIB_PATH)
+        if lib.chip_build_test_hooks() != 1:
+            raise RuntimeError(f"{HOOKS_LIB_PATH} is not a -DCHIP_TEST_HOOKS build")
+        _lib = lib
+        return lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
+        return False
 
 
 def declared_symbols():
@@ -379,6 +417,12 @@ class Chip:
         r = TickResult()
         self._chk(self.lib.chip_loop_tick(self.h, l, C.byref(p), C.byref(r)), "chip_loop_tick")
         return r
+
+    def resident_pause(self):
+        self._chk(self.lib.chip_resident_pause(self.h), "chip_resident_pause")
+
+    def resident_resume(self):
+        self._chk(self.lib.chip_resident_resume(self.h), "chip_resident_resume")
 
     def loop_tick_enqueue(self, l: int, slot: int, params: DotParams | None = None):
         p = params or default_dot_params()

@@ -427,7 +427,7 @@ int batch_local_enqueue(Ctx *c, int64_t k, const float *queries, int32_t Q, int3
         if (!c->batch_state) return CHIP_ERR_OOM;
     }
     BatchState *st = static_cast<BatchState *>(c->batch_state);
-    resident_stop(c);   // the many-query scan fills every CU (and may free / allocate): a resident scan instance goes home first
+    ResidentPause paused(c, c->tick_resident);   // the many-query scan fills every CU (and may free / allocate): no resident scan instance until it returns
     const int D = c->D;
     const int Qpad = batch_qpad(Q);
     const int64_t n_rows = local_count(c, k);

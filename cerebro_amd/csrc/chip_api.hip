@@ -39,6 +39,14 @@ const char *chip_strerror(int status)
 
 int chip_abi_version(void) { return CHIP_ABI_VERSION; }
 int chip_build_scan_forms(void) { return scan_forms_built(); }
+int chip_build_test_hooks(void)
+{
+#ifdef CHIP_TEST_HOOKS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int chip_last_hip_error(const chip_ctx *ctx, const char **text)
 {
@@ -85,6 +93,14 @@ int env_int(const char *name, int dflt)
 }
 
 // ------------------------------------------------------------------------------------------------ resident scan instance
+static inline void host_store_fence()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_sfence();                        // drains the write-combining buffers of the BAR mapping
+#else
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+}
 // (CHIP_TICK_RESIDENT=1; kernels.hip db_scan_resident, chip_internal.h ResidentCmd).  Host side: one command at a time; the line is
 // written head first, tail last (x86 stores stay in order; the fences keep the compiler from moving them).
 static void resident_write_line(Ctx *c, const ResidentCmd &cmd)
@@ -98,7 +114,7 @@ static void resident_write_line(Ctx *c, const ResidentCmd &cmd)
         std::memcpy(w, &t, 64);
         volatile uint64_t *d = reinterpret_cast<volatile uint64_t *>(c->res_cmd_host);
         int first = 0;
-#ifndef CHIP_NO_TEST_HOOKS
+#ifdef CHIP_TEST_HOOKS   // test build only (make testlibs -> cerebro_amd/lib/hooks/): the product library has no fault injection
         // CHIP_TEST_RESIDENT_SKIP_MASTER=k: the k-th command never reaches workgroup 0's line -- the other workgroups run it, workgroup 0
         // leaves at its lease without it: exactly what a command posted in the moment the lease runs out can look like (tests drive
         // resident_collect's recovery with it)
@@ -109,7 +125,7 @@ static void resident_write_line(Ctx *c, const ResidentCmd &cmd)
 #endif
         for (int j = first; j < c->res_grid; j++)
             for (int i = 0; i < 8; i++) d[j * 8 + i] = w[i];
-        __builtin_ia32_sfence();
+        host_store_fence();
         return;
     }
     ResidentCmd *d = c->res_cmd_host;
@@ -125,7 +141,7 @@ static void resident_write_line(Ctx *c, const ResidentCmd &cmd)
     d->dyn_claim = cmd.dyn_claim;
     __atomic_store_n(&d->tail, cmd.head, __ATOMIC_RELEASE);
     // a line in device memory is written through the write-combining BAR mapping: push it out (one full 64-byte line = one PCIe write)
-    if (c->res_cmd_in_vram) __builtin_ia32_sfence();
+    if (c->res_cmd_in_vram) host_store_fence();
 }
 
 static uint32_t resident_next_number(Ctx *c)
@@ -136,17 +152,42 @@ static uint32_t resident_next_number(Ctx *c)
     return n;
 }
 
-static int resident_alloc(Ctx *c)
+static void resident_free(Ctx *c)
 {
-    if (c->s_resident) return CHIP_OK;
+    if (c->s_resident) { (void)hipStreamDestroy(c->s_resident); c->s_resident = nullptr; }
+    if (c->res_pinned) { (void)hipHostFree(c->res_pinned); c->res_pinned = nullptr; }
+    if (c->res_cmd_vram) { (void)hipFree(c->res_cmd_vram); c->res_cmd_vram = nullptr; }
+    if (c->res_cmd_dev) { (void)hipFree(c->res_cmd_dev); c->res_cmd_dev = nullptr; }
+    if (c->res_partial) { (void)hipFree(c->res_partial); c->res_partial = nullptr; }
+    if (c->res_ticket) { (void)hipFree(c->res_ticket); c->res_ticket = nullptr; }
+    c->res_cmd_host = nullptr; c->res_cmd_hostdev = nullptr; c->res_exit_host = nullptr; c->res_exit_hostdev = nullptr;
+    c->res_cmd_in_vram = false; c->res_direct = false;
+    c->res_ready = false;
+}
+
+// does a pattern the CPU stores through the BAR mapping of `v` (64 bytes of device memory) read back through a copy?  Leaves zeros.
+static bool bar_write_probe(void *v)
+{
+    if (hipMemset(v, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return false;
+    uint32_t back[16] = {0};
+    volatile uint32_t *w = static_cast<volatile uint32_t *>(v);
+    for (int i = 0; i < 16; i++) w[i] = 0x5eed0000u + (uint32_t)i;
+    host_store_fence();
+    bool ok = hipMemcpy(back, v, 64, hipMemcpyDeviceToHost) == hipSuccess;
+    for (int i = 0; ok && i < 16; i++) ok = back[i] == 0x5eed0000u + (uint32_t)i;
+    for (int i = 0; i < 16; i++) w[i] = 0u;
+    host_store_fence();
+    return ok;
+}
+
+static int resident_alloc_body(Ctx *c)
+{
     // A stream of the HIGHEST priority: the runtime multiplexes streams onto a few hardware queues per priority level, and a packet
     // behind the resident kernel in its queue would wait for the instance to leave (measured: a tick stream that shared the queue
     // stalled for the whole lease).  The ctx's other streams are of the default priority, so this one gets a queue to itself.
-    hipStream_t s = nullptr;
     int pr_lo = 0, pr_hi = 0;
     CHIP_HIP(c, hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
-    CHIP_HIP(c, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, pr_hi));
-    c->s_resident = s;
+    CHIP_HIP(c, hipStreamCreateWithPriority(&c->s_resident, hipStreamNonBlocking, pr_hi));
     void *h = nullptr;
     CHIP_HIP(c, hipHostMalloc(&h, 128, hipHostMallocDefault));   // the command line + the line of the exit word
     std::memset(h, 0, 128);
@@ -159,8 +200,9 @@ static int resident_alloc(Ctx *c)
     c->res_exit_hostdev = reinterpret_cast<unsigned long long *>(static_cast<char *>(hd) + 64);
     // Where the command line lives.  With a large PCIe BAR the host can store straight into device memory, and a posted write that the
     // device then finds locally beats a line the device has to fetch over PCIe (ping-pong with one polling wave: 1.89 us against 2.52,
-    // scripts/probes/bar_pingpong.hip).  Used when the device says so AND a pattern written that way reads back through a copy;
-    // CHIP_RESIDENT_BAR=0 keeps the line in pinned host memory.
+    // scripts/probes/bar_pingpong.hip).  Used when the device says so AND a pattern written that way into THE buffer itself reads back
+    // through a copy (probing a throw-away allocation says nothing about this one); CHIP_RESIDENT_BAR=0 keeps the line in
+    // pinned host memory.
     // CHIP_RESIDENT_BAR=2 (the default) goes one step further: the host writes EVERY workgroup's line that way (16 KiB per command,
     // 0.6 us of host time) and nobody relays: 10k rows 35.9-36.4 -> 34.7-35.0 us.  1: only workgroup 0's line, relayed on the device.
     c->res_grid = c->n_cus * (c->scan_short_bpc > 0 ? c->scan_short_bpc : 1);
@@ -170,37 +212,47 @@ static int resident_alloc(Ctx *c)
     const int bar_mode = env_int("CHIP_RESIDENT_BAR", 2);
     int large_bar = 0;
     if (bar_mode != 0 && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) == hipSuccess && large_bar) {
-        void *v = nullptr;
-        if (hipMalloc(&v, 64) == hipSuccess) {
-            bool ok = hipMemset(v, 0, 64) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
-            uint32_t back[16] = {0};
-            if (ok) {
-                volatile uint32_t *w = static_cast<volatile uint32_t *>(v);
-                for (int i = 0; i < 16; i++) w[i] = 0x5eed0000u + (uint32_t)i;
-                __builtin_ia32_sfence();
-                ok = hipMemcpy(back, v, 64, hipMemcpyDeviceToHost) == hipSuccess;
-                for (int i = 0; ok && i < 16; i++) ok = back[i] == 0x5eed0000u + (uint32_t)i;
-                for (int i = 0; i < 16; i++) w[i] = 0u;
-                __builtin_ia32_sfence();
-            }
-            if (ok && bar_mode == 2) {          // the workgroups' lines themselves are the host's target; line 0 is workgroup 0's
-                (void)hipFree(v);
+        if (bar_mode == 2) {
+            // the workgroups' lines themselves are the host's target (line 0 is workgroup 0's): probe the first and the last line of them
+            if (bar_write_probe(c->res_cmd_dev) && bar_write_probe(reinterpret_cast<char *>(c->res_cmd_dev) + (size_t)(c->max_grid - 1) * 64)) {
                 c->res_cmd_in_vram = true;
                 c->res_direct = true;
                 c->res_cmd_host = reinterpret_cast<ResidentCmd *>(c->res_cmd_dev);
                 c->res_cmd_hostdev = c->res_cmd_dev;
-            } else if (ok) {
-                c->res_cmd_vram = v;
-                c->res_cmd_in_vram = true;
-                c->res_cmd_host = static_cast<ResidentCmd *>(v);
-                c->res_cmd_hostdev = static_cast<uint32_t *>(v);
-            } else {
-                (void)hipFree(v);
+            }
+        }
+        if (!c->res_direct) {                   // mode 1, or mode 2 whose lines are not host-writable: one line of its own, relayed on the device
+            void *v = nullptr;
+            if (hipMalloc(&v, 64) == hipSuccess) {
+                if (bar_write_probe(v)) {
+                    c->res_cmd_vram = v;
+                    c->res_cmd_in_vram = true;
+                    c->res_cmd_host = static_cast<ResidentCmd *>(v);
+                    c->res_cmd_hostdev = static_cast<uint32_t *>(v);
+                } else {
+                    (void)hipFree(v);
+                }
             }
         }
     }
     CHIP_HIP(c, hipMalloc((void **)&c->res_partial, (size_t)c->max_grid * CHIP_MAX_NQ * CHIP_MAX_TOPK * sizeof(chip_topk_entry)));
     CHIP_HIP(c, hipMalloc((void **)&c->res_ticket, 64));
+    return CHIP_OK;
+}
+
+// res_mu held.  Either everything exists afterwards (res_ready, published last) or nothing does and the mode is off for this ctx: the
+// caller falls back to the launched tick (a half-built state must not be entered by the next tick).
+static int resident_alloc(Ctx *c)
+{
+    if (c->res_ready) return CHIP_OK;
+    const int rc = resident_alloc_body(c);
+    if (rc != CHIP_OK) {
+        resident_free(c);
+        c->tick_resident = false;
+        std::fprintf(stderr, "[cerebro_hip] resident scan instance: allocation failed (%s) -- this ctx launches its ticks\n", chip_strerror(rc));
+        return CHIP_ERR_UNSUPPORTED;
+    }
+    c->res_ready = true;
     return CHIP_OK;
 }
 
@@ -246,11 +298,9 @@ static bool resident_has_left(const Ctx *c)
     return __atomic_load_n(c->res_exit_host, __ATOMIC_ACQUIRE) == c->res_instance;
 }
 
-void resident_stop(Ctx *c)
+static void resident_stop_locked(Ctx *c)
 {
-    if (!c->tick_resident) return;
-    std::lock_guard<std::mutex> lk(c->res_mu);
-    if (!c->s_resident || !c->res_alive) return;
+    if (!c->res_ready || !c->res_alive) return;
     if (c->res_busy && c->res_slot) {   // a command is still running: let it finish (its collector only reads the completion word)
         const volatile unsigned long long *w = c->res_slot->seq_host;
         for (long spin = 0; spin < (1L << 28) && __atomic_load_n(w, __ATOMIC_ACQUIRE) != c->res_slot->seq_want && !resident_has_left(c); spin++) {}
@@ -266,6 +316,26 @@ void resident_stop(Ctx *c)
     c->res_alive = false;
 }
 
+void resident_stop(Ctx *c)
+{
+    if (!c->tick_resident) return;
+    std::lock_guard<std::mutex> lk(c->res_mu);
+    resident_stop_locked(c);
+}
+
+void resident_pause(Ctx *c)
+{
+    std::lock_guard<std::mutex> lk(c->res_mu);
+    c->res_inhibit++;                    // from here on resident_tick_enqueue launches nothing (it checks under this mutex)
+    resident_stop_locked(c);
+}
+
+void resident_resume(Ctx *c)
+{
+    std::lock_guard<std::mutex> lk(c->res_mu);
+    if (c->res_inhibit > 0) c->res_inhibit--;
+}
+
 static bool resident_eligible(Ctx *c, int64_t k)
 {
     if (!c->tick_resident || c->nranks != 1 || c->xchg || c->parent || c->group || !c->own_query_stream || c->prof_on || !c->tick_fused ||
@@ -279,10 +349,13 @@ static bool resident_eligible(Ctx *c, int64_t k)
     return scan_rows_form(c, k, 3, grid, false) == 1;
 }
 
+constexpr int kResidentPaused = 1;   // (internal, > 0: not a status code) the mode is paused, launch this tick
+
 // The tick as a command to the resident instance (launched here if there is none, or if the last one has left).  query_mu held.
 static int resident_tick_enqueue(Ctx *c, int64_t k, int64_t l, const chip_dot_params *p, Slot &s)
 {
     std::lock_guard<std::mutex> lk(c->res_mu);
+    if (c->res_inhibit > 0) return kResidentPaused;   // a section that frees / allocates / rewrites the table is open: this tick is launched
     int rc = resident_alloc(c);
     if (rc != CHIP_OK) return rc;
     if (c->res_alive && resident_has_left(c)) c->res_alive = false;
@@ -366,7 +439,9 @@ static int ensure_capacity(Ctx *c, int64_t local_rows)
     const int64_t need = (local_rows + c->seg_rows - 1) >> c->seg_shift;
     if (need > kMaxSegs) return CHIP_ERR_OOM;
     bool grew = false;
-    if ((int64_t)c->segs.size() < need) resident_stop(c);   // the segment table is about to change
+    // the segment table is about to change: no instance from here until the table is final (an instance reads the table through
+    // caches nothing invalidates while it lives; rows of the new segment are published only after this function returns)
+    ResidentPause paused(c, c->tick_resident && (int64_t)c->segs.size() < need);
     while ((int64_t)c->segs.size() < need) {
         void *p = nullptr;
         CHIP_HIP(c, hipMalloc(&p, (size_t)c->seg_rows * c->D * c->elem));
@@ -379,10 +454,6 @@ static int ensure_capacity(Ctx *c, int64_t local_rows)
     if (grew) {
         CHIP_HIP(c, hipMemcpyAsync(c->seg_table_dev, c->segs.data(), c->segs.size() * sizeof(void *), hipMemcpyHostToDevice, c->s_append));
         CHIP_HIP(c, hipStreamSynchronize(c->s_append));
-        // a querier may have launched another instance since the first resident_stop (a tick that was in flight): it has read the
-        // OLD table through caches nothing invalidates while it lives -- retire it too, now that the table is final.  Rows of the
-        // new segment are published only after this function returns, so no instance older than this line ever looks them up.
-        resident_stop(c);
     }
     return CHIP_OK;
 }
@@ -391,7 +462,7 @@ static int ensure_capacity(Ctx *c, int64_t local_rows)
 // switch to double rows on the first append), with the append lock held or before the ctx is published.
 static int configure_storage(Ctx *c, int elem)
 {
-    resident_stop(c);
+    ResidentPause paused(c, c->tick_resident);
     for (void *p : c->segs) (void)hipFree(p);
     {
         std::lock_guard<std::mutex> lk(c->mu);
@@ -423,12 +494,7 @@ void ctx_destroy(chip_ctx *c)
     (void)hipSetDevice(c->device);
     resident_stop(c);
     (void)hipDeviceSynchronize();
-    if (c->s_resident) (void)hipStreamDestroy(c->s_resident);
-    if (c->res_pinned) (void)hipHostFree(c->res_pinned);
-    if (c->res_cmd_vram) (void)hipFree(c->res_cmd_vram);
-    if (c->res_cmd_dev) (void)hipFree(c->res_cmd_dev);
-    if (c->res_partial) (void)hipFree(c->res_partial);
-    if (c->res_ticket) (void)hipFree(c->res_ticket);
+    resident_free(c);
     exchange_destroy(c);
     pnp_destroy(c);
     icp_destroy(c);
@@ -536,7 +602,9 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     c->tick_resident = env_int("CHIP_TICK_RESIDENT", 0) != 0 && (scan_forms_built() & CHIP_SCAN_FORM_ROWS) != 0;
     c->res_max_bytes = (double)env_int("CHIP_RESIDENT_MAX_MIB", 512) * 1024 * 1024;   // 32k rows of 4096 floats: the reference's capacity is 29k
     c->res_lease_ms = env_int("CHIP_RESIDENT_LEASE_MS", 250);
+#ifdef CHIP_TEST_HOOKS
     c->res_test_skip_master = env_int("CHIP_TEST_RESIDENT_SKIP_MASTER", 0);
+#endif
     if (c->res_lease_ms < 1) c->res_lease_ms = 1;
     CHIP_HIP(c, hipHostMalloc(&c->seq_host_all, sizeof(unsigned long long) * CHIP_MAX_INFLIGHT, hipHostMallocDefault));
     std::memset(c->seq_host_all, 0, sizeof(unsigned long long) * CHIP_MAX_INFLIGHT);
@@ -830,8 +898,8 @@ static int tick_enqueue_slot(Ctx *c, int64_t l, const chip_dot_params *p, Slot &
                 c->last_l = l;             // :1098
                 return CHIP_OK;
             }
-            if (rc != CHIP_ERR_UNSUPPORTED) return rc;
-            c->tick_resident = false;      // this ctx's shape has no resident form: every tick is launched from here on
+            if (rc != CHIP_ERR_UNSUPPORTED && rc != kResidentPaused) return rc;
+            if (rc == CHIP_ERR_UNSUPPORTED) c->tick_resident = false;      // this ctx's shape has no resident form: every tick is launched from here on
             s.resident = false;
             s.poll = false;
         }
@@ -1260,6 +1328,25 @@ int chip_synchronize(chip_ctx *c)
     return CHIP_OK;
 }
 
+// Public form of the pause the library takes around its own frees / allocations (include/cerebro_hip.h): an integrator brackets
+// device-wide operations of OTHER libraries in the same process with it.  No-ops (CHIP_OK) on ctxs without the resident mode.
+int chip_resident_pause(chip_ctx *c)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    if (c->group) return CHIP_OK;                 // group / sharded ctxs never run the resident instance
+    (void)hipSetDevice(c->device);
+    resident_pause(c);
+    return CHIP_OK;
+}
+
+int chip_resident_resume(chip_ctx *c)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    if (c->group) return CHIP_OK;
+    resident_resume(c);
+    return CHIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ append
 int chip_db_append_f64(chip_ctx *c, const double *desc, int64_t n, uint32_t flags, int64_t *first_index)
 {
@@ -1496,6 +1583,7 @@ int chip_get_info(const chip_ctx *c, chip_info *info)
     info->comm_ranks = exchange_comm_ranks(c->group ? r : c);
     info->comm_init_abandoned = c->comm_init_abandoned;
     info->scan_forms = scan_forms_built();
+    info->test_hooks = chip_build_test_hooks();
     return CHIP_OK;
 }
 

@@ -204,6 +204,8 @@ struct Ctx {
     int32_t *res_ticket = nullptr;
     unsigned long long res_instance = 0;        // id of the instance launched last (0: none yet)
     bool res_alive = false;                     // launched and not yet seen to have left
+    bool res_ready = false;                     // resident_alloc has completed: every buffer below exists (published LAST)
+    int32_t res_inhibit = 0;                    // > 0: no instance may be launched (resident_pause .. resident_resume); ticks are launched meanwhile
     bool res_busy = false;                      // a command is in flight (one at a time)
     uint32_t res_cmd_no = 0, res_done = 0;      // last number posted / last number seen complete
     int32_t res_grid = 0;
@@ -318,6 +320,19 @@ int ctx_scores_local(Ctx *c, int64_t k, const void *q, double *u_global, int64_t
 int env_int(const char *name, int dflt);
 void resident_stop(Ctx *c);    // retire the resident scan instance and wait until it has left the chip (no-op without one): called before
                                // anything that rewrites the segment table, frees device memory or wants the chip to itself
+// resident_stop + NO new instance until resident_resume: ticks that arrive meanwhile are launched.  For sections that free / allocate
+// device memory (hipFree waits for the whole device -- a tick thread relaunching the instance in between would make it wait for as long
+// as ticks keep coming: ADVICE r5) or rewrite the segment table.  Nests; chip_resident_pause / _resume are the public form.
+void resident_pause(Ctx *c);
+void resident_resume(Ctx *c);
+struct ResidentPause {          // scope guard: every early return of a CHIP_HIP(...) inside the section resumes
+    Ctx *c;
+    bool on;
+    explicit ResidentPause(Ctx *ctx, bool cond = true) : c(ctx), on(cond) { if (on) resident_pause(c); }
+    ~ResidentPause() { if (on) resident_resume(c); }
+    ResidentPause(const ResidentPause &) = delete;
+    ResidentPause &operator=(const ResidentPause &) = delete;
+};
 constexpr uint32_t kCreateStoreMask = 3u;   // CHIP_CREATE_STORE_F32 | CHIP_CREATE_STORE_F64
 
 // ---- chip_multi.hip: exchange of per-shard lists inside the library (RCCL / device copies), groups of sub-contexts ----

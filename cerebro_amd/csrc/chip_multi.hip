@@ -104,18 +104,21 @@ struct CommInitJob {
     bool all = false;                        // ncclCommInitAll over `devices` / ncclCommInitRank(rank of n_ranks) on `device`
 };
 
-// Fault injection for the two bootstraps: CHIP_TEST_COMM_INIT=hang | fail.  A test hook inside a production library is announced
-// on stderr every time it fires -- a stray environment variable must not degrade a deployed process silently.
+// Fault injection for the two bootstraps: CHIP_TEST_COMM_INIT=hang | fail.  Compiled only into the TEST build of the library
+// (-DCHIP_TEST_HOOKS: `make testlibs` -> cerebro_amd/lib/hooks/libcerebro_hip.so, which only tests/ load; chip_get_info().test_hooks
+// says which build a process runs).  `make lib` -- the product -- contains none of it: a stray environment variable cannot degrade a
+// deployed node.  Where compiled in, a hook still announces itself on stderr every time it fires.
 static int comm_init_test_hook()
 {
-#ifdef CHIP_NO_TEST_HOOKS   // a deployment build: make EXTRA_HIPFLAGS=-DCHIP_NO_TEST_HOOKS (the fault-injection hooks are compiled out)
+#ifndef CHIP_TEST_HOOKS
     return 0;
-#endif
+#else
     const char *t = std::getenv("CHIP_TEST_COMM_INIT");
     if (!t || !*t) return 0;
     const int mode = std::strcmp(t, "hang") == 0 ? 1 : std::strcmp(t, "fail") == 0 ? 2 : 0;
     if (mode) std::fprintf(stderr, "[cerebro_hip] TEST HOOK ACTIVE: CHIP_TEST_COMM_INIT=%s -- the RCCL bootstrap is made to %s\n", t, mode == 1 ? "hang" : "fail");
     return mode;
+#endif
 }
 
 static int comm_init_timeout_ms()
@@ -197,7 +200,7 @@ static int exchange_create(Ctx *c, int world, bool need_gathered)
     }
     CHIP_HIP(c, hipMalloc(&x->agree_dev, sizeof(int32_t) * (size_t)(1 + world)));
     CHIP_HIP(c, hipHostMalloc(&x->agree_host, sizeof(int32_t) * (size_t)(1 + world), hipHostMallocDefault));
-#ifndef CHIP_NO_TEST_HOOKS
+#ifdef CHIP_TEST_HOOKS
     if (const char *t = std::getenv("CHIP_TEST_FAIL_SHARD")) {
         int r = -1, every = 0;
         if (std::sscanf(t, "%d:%d", &r, &every) == 2 && r == c->rank && every > 0) {
@@ -219,9 +222,9 @@ static bool test_fail_now(Exchange *x)
 // test hook: CHIP_TEST_BATCH_OOM="rank": this rank's many-query call pretends its per-call allocations failed (announced on stderr)
 static int test_oom_rank()
 {
-#ifdef CHIP_NO_TEST_HOOKS
+#ifndef CHIP_TEST_HOOKS
     return -1;
-#endif
+#else
     static const int r = [] {
         const char *t = std::getenv("CHIP_TEST_BATCH_OOM");
         if (!t || !*t) return -1;
@@ -229,6 +232,7 @@ static int test_oom_rank()
         return std::atoi(t);
     }();
     return r;
+#endif
 }
 
 void exchange_destroy(Ctx *c)

@@ -276,7 +276,7 @@ static int icp_reserve(Ctx *c, IcpState *st, int N, int H)
     const int words = (N + 63) / 64;
     if (N <= st->cap_N && H <= st->cap_H && words <= st->cap_words) return CHIP_OK;
     const int nN = N > st->cap_N ? N : st->cap_N, nH = H > st->cap_H ? H : st->cap_H, nW = words > st->cap_words ? words : st->cap_words;
-    resident_stop(c);   // hipFree waits for the whole device: not with a resident scan instance on it
+    ResidentPause paused(c, c->tick_resident);   // hipFree waits for the whole device: no resident scan instance on it until the last allocation is done
     icp_free(st);
     CHIP_HIP(c, hipMalloc(&st->A, sizeof(double) * 3 * (size_t)nN));
     CHIP_HIP(c, hipMalloc(&st->B, sizeof(double) * 3 * (size_t)nN));

@@ -2383,7 +2383,9 @@ void pnp_destroy(Ctx *c)
 
 static int pnp_reserve(Ctx *c, PnpState *st, int N, int H, int words, int P)
 {
-    if (N > st->cap_N || H > st->cap_H || words > st->cap_words) resident_stop(c);   // hipFree waits for the whole device: not with a resident scan instance on it
+    // hipFree waits for the whole device: not with a resident scan instance on it, and none launched by the tick thread until the last
+    // allocation below is done (at 10 Hz the lease never runs out, the frees would wait for as long as ticks keep coming)
+    ResidentPause paused(c, c->tick_resident && (N > st->cap_N || H > st->cap_H || words > st->cap_words));
     if (N > st->cap_N) {
         (void)hipFree(st->X); (void)hipHostFree(st->h_in);
         st->X = st->uv = st->h_in = nullptr; st->cap_N = 0;
@@ -2494,6 +2496,9 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
     }
     ea.H = H; ea.S = S; ea.thresh = p->error_thresh; ea.use_mle = p->use_mle;
     ea.Sg = st->Sg; ea.Tg = st->Tg; ea.sample = st->sample; ea.ok = st->ok; ea.mask_words = words;
+    ea.debug_stop = 0;
+    ea.backsub_loop = 0;
+#ifdef CHIP_TEST_HOOKS   // knobs that change what the kernels compute or which code path they take: test build only (lib/hooks/)
     { const char *dv = std::getenv("CHIP_PNP_DEBUG_STOP"); ea.debug_stop = dv ? std::atoi(dv) : 0; }
     {
         static const int loop_form = [] {
@@ -2504,6 +2509,7 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
         }();
         ea.backsub_loop = loop_form;
     }
+#endif
     ea.T_out = st->T_out; ea.cost = st->cost; ea.nin = st->nin; ea.valid = st->valid; ea.nsol = st->nsol; ea.mask = st->mask;
     if (want_stamps) ea.stamps = st->stamps;
     // A batch of several problems may go out as `groups` launch pairs on as many streams (CHIP_PNP_GROUPS, tuning): both kernels are

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CHIP_ABI_VERSION 5
+#define CHIP_ABI_VERSION 6
 
 /* ------------------------------------------------------------------------------------------ status codes */
 enum {
@@ -233,10 +233,19 @@ typedef struct {
 
 /* Synchronous tick (single-GPU ctx, shard_count == 1).
  * Environment, read at chip_create: CHIP_TICK_RESIDENT=1 turns ticks over prefixes of up to 512 MiB into commands to a scan kernel
- * that stays on the chip between ticks (no launch per tick: ~4.7 us less per call; same results).  The instance leaves by itself
- * 250 ms after its last command and is retired before the library frees device memory or grows the DB by a segment; calls of OTHER
- * libraries that wait for the whole device (hipFree, hipDeviceSynchronize) wait for that lease.  Off by default. */
+ * that stays on the chip between ticks (no launch per tick: ~4.7 us less per call back to back, ~14 us at the reference's 10 Hz
+ * cadence; same results).  The instance leaves by itself once NO tick has arrived for a whole lease (CHIP_RESIDENT_LEASE_MS,
+ * default 250) -- so at 10 Hz it never leaves by itself.  The library itself pauses it around everything of its own that frees /
+ * allocates device memory, grows the DB by a segment or wants the whole chip (no instance is launched until that section is over;
+ * ticks that arrive meanwhile are launched).  Calls of OTHER libraries in the same process that wait for the whole device
+ * (hipFree, hipMalloc of a new pool block, hipDeviceSynchronize) would wait for as long as ticks keep coming: bracket them with
+ * chip_resident_pause / chip_resident_resume, or leave the mode off in such a process.  Off by default. */
 int chip_loop_tick(chip_ctx *ctx, int64_t l, const chip_dot_params *p, chip_tick_result *out);
+/* Retire the resident scan instance (waits until it has left the chip, <= one tick) and keep the mode from launching another one
+ * until the matching chip_resident_resume; ticks in between are ordinary launches with identical results.  Calls nest.  CHIP_OK and
+ * no effect on a ctx that does not run the mode.  Thread-safe against the tick, append and PnP threads (ABI 6). */
+int chip_resident_pause(chip_ctx *ctx);
+int chip_resident_resume(chip_ctx *ctx);
 /* Pipelined form: enqueue up to CHIP_MAX_INFLIGHT - 1 ticks without host synchronisation, collect later.  Scans run
  * back to back on an internal stream; the one-workgroup merge of tick i (ctx stream) overlaps the scan of tick i+1. */
 #define CHIP_MAX_INFLIGHT 64
@@ -364,10 +373,16 @@ typedef struct {
                                    The row-batched form (short prefixes) depends on how the building hipcc allocates registers; a
                                    build whose code-object check failed is made with -DCHIP_NO_ROWS_FORM and serves every scan with
                                    the one-row kernel -- same results, short prefixes slower                                    */
+    int32_t test_hooks;         /* 0: the product build (`make lib`): no fault-injection hook, no test knob is compiled in, the
+                                   CHIP_TEST_* / CHIP_PNP_BACKSUB / CHIP_PNP_DEBUG_STOP environment variables are never read.
+                                   1: the test build (-DCHIP_TEST_HOOKS, `make testlibs` -> cerebro_amd/lib/hooks/), which only
+                                   tests/ load -- never deploy it (ABI 6)                                                       */
 } chip_info;
 enum { CHIP_SCAN_FORM_ONE_ROW = 1, CHIP_SCAN_FORM_ROWS = 2 };
 /* the same bits without a ctx (what `make verify` and the build log ask) */
 int chip_build_scan_forms(void);
+/* chip_info.test_hooks without a ctx */
+int chip_build_test_hooks(void);
 enum { CHIP_EXCHANGE_NONE = 0, CHIP_EXCHANGE_RCCL = 1, CHIP_EXCHANGE_COPY = 2 };
 int chip_get_info(const chip_ctx *ctx, chip_info *info);
 

@@ -5,6 +5,6 @@ R=$1; shift
 mkdir -p gpurun_out/r04
 for i in $(seq $R); do
   for L in "$@"; do
-    echo -n "$(basename $L): "; CHIP_LIB=$L timeout 300 python scripts/gpu_pnp_rates.py 2>&1 | tail -1
+    echo -n "$(basename $L): "; CHIP_ALLOW_LIB_OVERRIDE=1 CHIP_LIB=$L timeout 300 python scripts/gpu_pnp_rates.py 2>&1 | tail -1
   done
 done | tee gpurun_out/r04/pnp_ab.txt

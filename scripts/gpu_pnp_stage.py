@@ -3,6 +3,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 import np_mirror_pnp as M
 from cerebro_amd import capi
+capi.use_hooks_library().__enter__()   # CHIP_PNP_DEBUG_STOP exists in the TEST build of the library only
 X, uv, T, inl = M.make_scene(N=512, outlier_frac=0.3, noise_px=0.5, seed=4242)
 for H in (50, 1000):
     for stop in (1, 2, 3, 4, 0):

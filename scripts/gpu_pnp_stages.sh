@@ -6,7 +6,7 @@ O=gpurun_out/r04
 mkdir -p $O
 for stop in 1 2 3 4 0; do
   rm -rf $O/pnp_stage_$stop
-  CHIP_PNP_DEBUG_STOP=$stop timeout 300 rocprofv3 --kernel-trace -d $O/pnp_stage_$stop -o r -- python scripts/run_pnp_ref_mode.py $H > $O/pnp_stage_$stop.log 2>&1
+  CHIP_ALLOW_LIB_OVERRIDE=1 CHIP_LIB=cerebro_amd/lib/hooks/libcerebro_hip.so CHIP_PNP_DEBUG_STOP=$stop timeout 300 rocprofv3 --kernel-trace -d $O/pnp_stage_$stop -o r -- python scripts/run_pnp_ref_mode.py $H > $O/pnp_stage_$stop.log 2>&1
   python - <<PY
 import sqlite3,glob
 for db in glob.glob("$O/pnp_stage_$stop/**/*_results.db", recursive=True):

@@ -10,7 +10,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 
 HIP_ARTEFACTS = [ROOT / "cerebro_amd" / "lib" / n for n in ("libcerebro_hip.so", "libcerebro_host.so", "cerebro_replay", "minimal_loop_detector", "sync_tick_latency",
-                                                          "norows/libcerebro_hip.so")] + [ROOT / "tests" / "fakerccl" / "_build" / "libfakerccl.so"]
+                                                          "norows/libcerebro_hip.so", "hooks/libcerebro_hip.so")] + [ROOT / "tests" / "fakerccl" / "_build" / "libfakerccl.so"]
 _hip_build_error = None
 
 
@@ -50,6 +50,19 @@ def pytest_collection_modifyitems(config, items):
 def oracle():
     import oracle_lib
     return oracle_lib.load()
+
+
+@pytest.fixture
+def hooks_lib():
+    """Chip objects created by this test run on the TEST build of the library (cerebro_amd/lib/hooks/, -DCHIP_TEST_HOOKS): the only
+    build that contains the fault-injection hooks.  Every other test -- and every product path -- runs the product build, which reads
+    none of the CHIP_TEST_* variables."""
+    from cerebro_amd import capi
+    with capi.use_hooks_library() as lib:
+        yield lib
+
+
+HOOKS_ENV = {"CHIP_LIB": str(ROOT / "cerebro_amd" / "lib" / "hooks" / "libcerebro_hip.so"), "CHIP_ALLOW_LIB_OVERRIDE": "1"}   # for subprocesses
 
 
 @pytest.fixture(scope="session")

@@ -126,15 +126,18 @@ def test_bench_group_mode_survives_a_hung_or_failed_rccl_bootstrap():
     or fails must cost the run its RCCL exchange, never its JSON line.  --force-group runs that layout on the
     1-GPU box (devices = [0]: RCCL transport, one rank)."""
     base = ["--force-group", "--rows", "60000"]
-    j = _run_single(base)                                   # healthy: RCCL carries the (one-rank) exchange
+    j = _with_env({"CHIP_TEST_COMM_INIT": "fail"}, base)    # healthy, and the PRODUCT build does not even read the fault-injection variable
+    assert j["details"]["test_hooks"] == 0
     assert "in-library RCCL (ncclCommInitAll" in j["config"]["exchange"] and j["config"]["rccl_ranks"] == 1
     assert j["config"]["exchange_fallback"] is False and j["config"]["comm_init_abandoned"] is False
     # the library's own deadline: ncclCommInitAll never returns -> abandoned on its helper thread, device-copy exchange
-    j = _with_env({"CHIP_TEST_COMM_INIT": "hang", "BENCH_COMM_INIT_TIMEOUT": "2"}, base)
+    from conftest import HOOKS_ENV          # fault injection exists in the TEST build of the library only (cerebro_amd/lib/hooks/)
+    j = _with_env({"CHIP_TEST_COMM_INIT": "hang", "BENCH_COMM_INIT_TIMEOUT": "2", **HOOKS_ENV}, base)
+    assert j["details"]["test_hooks"] == 1
     assert "FALLBACK" in j["config"]["exchange"] and "hung" in j["config"]["exchange"]
     assert j["config"]["rccl_ranks"] == 0 and j["config"]["exchange_fallback"] is True and j["config"]["comm_init_abandoned"] is True and j["value"] > 0
     # ncclCommInitAll fails outright
-    j = _with_env({"CHIP_TEST_COMM_INIT": "fail"}, base)
+    j = _with_env({"CHIP_TEST_COMM_INIT": "fail", **HOOKS_ENV}, base)
     assert "FALLBACK" in j["config"]["exchange"] and j["config"]["rccl_ranks"] == 0 and j["config"]["exchange_fallback"] is True and j["value"] > 0
     # something else inside the create hangs: bench.py's outer deadline rebuilds the group on the copy exchange
     j = _with_env({"BENCH_HANG_GROUP_CREATE": "1", "BENCH_GROUP_CREATE_TIMEOUT": "2"}, base)

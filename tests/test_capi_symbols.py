@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(chip_lib):
 
 
 def test_abi_version_and_defaults(chip_lib):
-    assert chip_lib.chip_abi_version() == 5
+    assert chip_lib.chip_abi_version() == 6
     p = capi.default_dot_params()
     assert (p.locality, p.lag, p.min_new, p.min_k) == (12, 50, 3, 5)        # Cerebro.cpp:912-914,962,1022
     assert p.thresh == 0.85000002384185791015625                           # (double)(float)0.85
@@ -67,3 +67,45 @@ def test_no_gpu_fails_loudly(chip_lib):
 def test_missing_library_is_an_error(tmp_path):
     with pytest.raises(FileNotFoundError):
         capi.load_library(tmp_path / "libcerebro_hip.so")
+
+
+HOOK_NAMES = [b"CHIP_TEST_COMM_INIT", b"CHIP_TEST_FAIL_SHARD", b"CHIP_TEST_BATCH_OOM", b"CHIP_TEST_RESIDENT_SKIP_MASTER", b"CHIP_PNP_BACKSUB", b"CHIP_PNP_DEBUG_STOP"]
+
+
+def test_product_library_contains_no_test_hook(chip_lib):
+    """`make lib` compiles the fault-injection hooks and the result-changing test knobs OUT -- the product .so does not
+    even contain the names of their environment variables, so a stray variable cannot degrade a deployed node; the TEST build
+    (`make testlibs` -> lib/hooks/, loaded by tests/ only) contains all of them and says so (chip_build_test_hooks / chip_info.test_hooks)."""
+    assert chip_lib.chip_build_test_hooks() == 0
+    blob = capi.PRODUCT_LIB_PATH.read_bytes()
+    for name in HOOK_NAMES:
+        assert name not in blob, name
+    assert b"TEST HOOK ACTIVE" not in blob and b"TEST KNOB ACTIVE" not in blob
+    hooks = capi.load_library(capi.HOOKS_LIB_PATH)
+    assert hooks.chip_build_test_hooks() == 1 and hooks.chip_abi_version() == chip_lib.chip_abi_version()
+    blob = capi.HOOKS_LIB_PATH.read_bytes()
+    for name in HOOK_NAMES:
+        assert name in blob, name
+    # the other shipped variant (the degraded build) is a product build too
+    assert capi.load_library(ROOT / "cerebro_amd" / "lib" / "norows" / "libcerebro_hip.so").chip_build_test_hooks() == 0
+
+
+def test_chip_lib_override_needs_its_switch(tmp_path):
+    """CHIP_LIB redirects the Python binding to another build only together with CHIP_ALLOW_LIB_OVERRIDE=1; alone it is ignored, loudly."""
+    import os
+    import subprocess
+    import sys
+    code = "from cerebro_amd import capi; print(capi.LIB_PATH)"
+    other = str(capi.HOOKS_LIB_PATH)
+    env = {k: v for k, v in os.environ.items() if k not in ("CHIP_LIB", "CHIP_ALLOW_LIB_OVERRIDE")}
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(env, CHIP_LIB=other), capture_output=True, text=True)
+    assert r.stdout.strip() == str(capi.PRODUCT_LIB_PATH) and "IGNORED" in r.stderr
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(env, CHIP_LIB=other, CHIP_ALLOW_LIB_OVERRIDE="1"), capture_output=True, text=True)
+    assert r.stdout.strip() == other and "IGNORED" not in r.stderr
+
+
+def test_use_hooks_library_is_scoped():
+    before = capi.load_library()
+    with capi.use_hooks_library() as lib:
+        assert capi.load_library() is lib and lib.chip_build_test_hooks() == 1
+    assert capi.load_library() is before and before.chip_build_test_hooks() == 0

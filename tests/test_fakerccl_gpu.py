@@ -18,6 +18,8 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+from conftest import HOOKS_ENV   # fault injection exists in the TEST build of the library only (cerebro_amd/lib/hooks/)
+
 pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 FAKE = ROOT / "tests" / "fakerccl" / "_build" / "libfakerccl.so"
@@ -177,12 +179,12 @@ def test_exchange_with_real_processes_on_one_device(world, tmp_path):
 def test_failed_shard_mark_across_processes(tmp_path):
     """Rank 1 of 3 cannot take part in every 5th collective call: it sends the marked neutral list, the merge of EVERY rank reports
     the mark (CHIP_ERR_SHARD_FAILED everywhere, last_l unchanged), the retry succeeds -- across real process boundaries."""
-    ret = _spawn(_worker, 3, tmp_path, ("fail",), dict(BASE_ENV, CHIP_TEST_FAIL_SHARD="1:5"))
+    ret = _spawn(_worker, 3, tmp_path, ("fail",), dict(BASE_ENV, CHIP_TEST_FAIL_SHARD="1:5", **HOOKS_ENV))
     assert len(ret) == 3 and len(set(ret.values())) == 1 and next(iter(ret.values()))[1] >= 10
 
 
 def test_rank_out_of_memory_in_many_query_call(tmp_path):
-    ret = _spawn(_worker_oom, 2, tmp_path, (), dict(BASE_ENV, CHIP_TEST_BATCH_OOM="1"))
+    ret = _spawn(_worker_oom, 2, tmp_path, (), dict(BASE_ENV, CHIP_TEST_BATCH_OOM="1", **HOOKS_ENV))
     assert len(ret) == 2
 
 

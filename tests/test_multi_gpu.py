@@ -386,7 +386,7 @@ def test_group_auto_switch_to_double_is_one_decision():
         assert ix[0][0] == 6
 
 
-def test_failed_shard_marks_the_tick_for_everyone(monkeypatch):
+def test_failed_shard_marks_the_tick_for_everyone(monkeypatch, hooks_lib):
     """A shard whose own validation fails must not leave a collective tick (the others have enqueued their exchange): it takes part
     with the marked neutral list, the merge reports the mark, the call fails with CHIP_ERR_SHARD_FAILED, last_l is as before, and
     the NEXT tick is correct again -- the exchange never goes out of step.  CHIP_TEST_FAIL_SHARD makes shard 2 fail every 5th call."""
@@ -450,7 +450,7 @@ def test_failed_shard_marks_the_tick_for_everyone(monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["hang", "fail"])
-def test_rccl_bootstrap_under_a_deadline(monkeypatch, mode):
+def test_rccl_bootstrap_under_a_deadline(monkeypatch, mode, hooks_lib):
     """ncclCommInitAll / ncclCommInitRank are blocking rendezvous; on a node where they cannot complete they hang.  The library runs
     them on a helper thread under CHIP_COMM_INIT_TIMEOUT_MS: a group falls back to the device-copy exchange (same answers), a
     sharded ctx gets CHIP_ERR_COMM, chip_get_info().comm_init_abandoned says a helper is still stuck.  CHIP_TEST_COMM_INIT makes the
@@ -513,7 +513,7 @@ def test_group_copy_exchange_distinct_devices():
         assert [float(x).hex() for x in r.maxv] == [float(x).hex() for x in wsc[:, 0]]
 
 
-def test_two_consecutive_failed_pipelined_ticks_unwind_to_the_last_good_l(monkeypatch):
+def test_two_consecutive_failed_pipelined_ticks_unwind_to_the_last_good_l(monkeypatch, hooks_lib):
     """ticks A and B are both enqueued and both come back CHIP_TICK_FAILED.  A's collect cannot roll back (B was enqueued on
     top of it); B's collect must not restore A's l (a pass that never reached Cerebro.cpp:1098) but the last_l from before A."""
     monkeypatch.setenv("CHIP_TEST_FAIL_SHARD", "1:1")           # shard 1 fails EVERY collective call

@@ -22,7 +22,7 @@ def test_full_build_has_both_forms():
 
 def test_degraded_build_says_so_and_passes_the_scan_suite():
     assert NOROWS.exists(), "make testlibs builds cerebro_amd/lib/norows/libcerebro_hip.so"
-    env = dict(os.environ, CHIP_LIB=str(NOROWS))
+    env = dict(os.environ, CHIP_LIB=str(NOROWS), CHIP_ALLOW_LIB_OVERRIDE="1")
     code = ("from cerebro_amd import capi\n"
             "with capi.Chip(4096) as c:\n"
             "    i = c.info(); assert i['scan_forms'] == capi.CHIP_SCAN_FORM_ONE_ROW, i\n"

@@ -148,7 +148,8 @@ def test_back_substitution_forms_agree():
     import os, subprocess, sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    env = dict(os.environ, CHIP_PNP_BACKSUB="loop")
+    from conftest import HOOKS_ENV          # the knob exists in the TEST build of the library only (cerebro_amd/lib/hooks/)
+    env = dict(os.environ, CHIP_PNP_BACKSUB="loop", **HOOKS_ENV)
     r = subprocess.run([sys.executable, str(root / "scripts" / "gpu_pnp_fuzz.py"), "36"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert "TEST KNOB ACTIVE: CHIP_PNP_BACKSUB=loop" in r.stderr, r.stderr[-400:]
     assert "fuzz: 0 mismatches" in r.stdout, (r.stdout[-400:], r.stderr[-400:])

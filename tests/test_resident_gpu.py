@@ -199,7 +199,7 @@ def test_resident_ticks_while_another_thread_appends_across_segments(monkeypatch
         assert bytes(chip.loop_tick(10_050, p)) == want[10_050]
 
 
-def test_resident_command_that_workgroup_0_never_saw_is_recovered(monkeypatch):
+def test_resident_command_that_workgroup_0_never_saw_is_recovered(monkeypatch, hooks_lib):
     """A command posted in the moment the lease runs out can reach the other workgroups while workgroup 0 is already leaving: they run
     it, the ticket never fills, the instance goes.  The test hook reproduces exactly that (the 5th command is not written into
     workgroup 0's line); the collecting call must notice the exit, send the stragglers home, post the command again to a new instance
@@ -232,3 +232,68 @@ def test_resident_command_that_workgroup_0_never_saw_is_recovered(monkeypatch):
             assert launches >= 2 and took[4] > 0.02 and float(np.median(took[5:])) < 0.02, (launches, took)
         else:                                  # one command line for all: nothing to skip, nothing to recover
             assert launches >= 1
+
+
+def test_pause_resume_and_frees_under_a_10hz_style_tick_stream(monkeypatch):
+    """resident_stop in front of a hipFree did not keep the tick thread from relaunching the instance; with ticks
+    arriving faster than the lease the device-wide frees of pnp_reserve / icp_reserve then waited for as long as ticks kept coming.
+    Now those sections PAUSE the mode (no instance is launched until they are over; ticks in between are ordinary launches), and the
+    same pause is public (chip_resident_pause / chip_resident_resume) for device-wide calls of other libraries in the process."""
+    import threading
+    seed, n_rows = 5, 11_000
+    ls = [10_050, 10_053, 9_000, 10_990]
+    p = every_tick_params()
+    monkeypatch.delenv("CHIP_TICK_RESIDENT", raising=False)
+    with capi.Chip(D, capacity_hint=n_rows) as ref:
+        ref.append_synthetic(n_rows, seed, [])
+        want = {l: bytes(ref.loop_tick(l, p)) for l in ls}
+    monkeypatch.setenv("CHIP_TICK_RESIDENT", "1")
+    monkeypatch.setenv("CHIP_RESIDENT_LEASE_MS", "2000")          # far longer than any gap between the ticks below: it never leaves by itself
+    with capi.Chip(D, capacity_hint=n_rows) as chip:
+        chip.append_synthetic(n_rows, seed, [])
+        for l in ls:
+            assert bytes(chip.loop_tick(l, p)) == want[l]
+        t0, n0 = resident_stats(chip)
+        assert t0 == len(ls) and n0 == 1
+        # the public pause: ticks are launched, records identical, no new instance; nested pauses need as many resumes
+        chip.resident_pause(); chip.resident_pause()
+        for l in ls:
+            assert bytes(chip.loop_tick(l, p)) == want[l]
+        assert resident_stats(chip) == (t0, n0)
+        chip.resident_resume()
+        assert bytes(chip.loop_tick(ls[0], p)) == want[ls[0]] and resident_stats(chip) == (t0, n0)
+        chip.resident_resume()
+        assert bytes(chip.loop_tick(ls[0], p)) == want[ls[0]]
+        assert resident_stats(chip) == (t0 + 1, n0 + 1)
+        # a tick thread hammering the ctx (faster than any lease) while the geometry thread's buffers grow three times (pnp_reserve and
+        # icp_reserve free and reallocate ~ten device / pinned buffers each): bounded, and every record still right
+        stop, bad, n_ticks = threading.Event(), [], [0]
+
+        def ticker():
+            i = 0
+            while not stop.is_set():
+                l = ls[i % len(ls)]
+                if bytes(chip.loop_tick(l, p)) != want[l]:
+                    bad.append(l)
+                i += 1
+            n_ticks[0] = i
+
+        th = threading.Thread(target=ticker)
+        th.start()
+        try:
+            t_start = time.perf_counter()
+            for N in (64, 700, 2600):
+                X, uv = synth.make_scene(N=N, outlier_frac=0.2, noise_px=0.5, seed=N)[:2]
+                rp = capi.default_ransac_params(); rp.n_hypotheses = 64; rp.seed = 3
+                assert chip.pnp_ransac(X, uv, rp)["summary"]["best_hypothesis"] >= 0
+                A, B = synth.make_icp_scene(N=N, outlier_frac=0.2, noise=0.01, seed=N)[:2]
+                ip = capi.default_icp_params(); ip.n_hypotheses = 64; ip.seed = 3
+                chip.icp_ransac(A, B, ip)
+            took = time.perf_counter() - t_start
+        finally:
+            stop.set()
+            th.join(60)
+        assert not th.is_alive() and not bad and n_ticks[0] > 50
+        assert took < 20.0, took                                   # (before: unbounded -- each free waited for an instance the ticks kept alive)
+        t1, n1 = resident_stats(chip)
+        assert t1 > t0 + 1                                         # the mode came back after every paused section
