@@ -934,6 +934,12 @@ int chip_create_multi(chip_ctx **out, int32_t D, int64_t capacity_hint, const in
     bool repeated = false;
     for (int a = 0; a < n_devices; a++)
         for (int b = a + 1; b < n_devices; b++) repeated = repeated || devices[a] == devices[b];
+#ifdef CHIP_TEST_HOOKS   // test build only: the RCCL transport for a group whose devices repeat -- real RCCL refuses that, the stand-in of tests/fakerccl does not
+    if (repeated && std::getenv("CHIP_TEST_RCCL_SAME_DEVICE")) {
+        std::fprintf(stderr, "[cerebro_hip] TEST HOOK ACTIVE: CHIP_TEST_RCCL_SAME_DEVICE -- ncclCommInitAll over repeated devices\n");
+        repeated = false;
+    }
+#endif
     chip_ctx *gc = new (std::nothrow) chip_ctx();
     if (!gc) return CHIP_ERR_OOM;
     Group *G = new (std::nothrow) Group();

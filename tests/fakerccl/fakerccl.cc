@@ -10,7 +10,13 @@
 //     -- so work enqueued on the stream afterwards sees the result, as with an in-stream collective;
 //   * every wait has a deadline (FAKERCCL_TIMEOUT_MS, default 60 s): a rank that never arrives makes its peers return
 //     ncclSystemError instead of hanging the test box;
-//   * payloads larger than a slot go through in slot-sized pieces, each its own operation.
+//   * payloads larger than a slot go through in slot-sized pieces, each its own operation;
+//   * FAKERCCL_ASYNC=1 (round 6): small collectives (<= 16 KiB per rank: the per-tick lists, the agreement word) are ENQUEUED like the
+//     real thing -- D2H copy, a host function on the caller's stream that does the exchange (and blocks that stream, like a collective
+//     kernel waiting for its peers, while the rank's other streams run on), H2D copy -- and the call returns at once: the overlap of
+//     all-gather(i) with scan(i+1) that the library's tick pipeline is built for is then really exercised.  Operations keep their issue
+//     order across streams by an event chain (as RCCL orders them); a peer timeout surfaces as ncclSystemError of the NEXT call;
+//   * ncclCommInitAll (round 6): n communicators of ONE process over one segment (the one-process / G-devices layout on one device).
 // Nothing under cerebro_amd/ references this file; the product path loads librccl.so.1.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -39,12 +45,34 @@ struct Shared {                                   // lives in the segment; zero-
     char data[2][kMaxRanks][kSlotBytes];          // double-buffered: operation n uses half n & 1
 };
 
+constexpr int kAsyncRing = 64;                    // operations in flight per communicator (the library rings 64 list buffers)
+constexpr size_t kAsyncSlot = 16u << 10;          // per rank: payloads up to this size are enqueued, larger ones take the synchronous path
+
+struct Comm;
+struct AsyncOp {                                  // one enqueued collective
+    Comm *c = nullptr;
+    uint64_t n = 0;
+    size_t bytes = 0;
+    int root = -1;                                // >= 0: broadcast from root
+    char *h = nullptr;                            // pinned: this rank's piece on the way out, every rank's pieces on the way in
+    hipEvent_t done = nullptr;                    // recorded behind the H2D copy of the slot's previous use
+    bool used = false;
+};
+
 struct Comm {
     Shared *sh = nullptr;
     int n = 0, rank = 0;
     uint64_t op = 0;                              // operations issued by this rank so far
     char name[64] = {0};
     void *host = nullptr;                         // pinned bounce buffer, kMaxRanks * kSlotBytes
+    bool async = false;
+    AsyncOp ring[kAsyncRing];
+    void *ring_host = nullptr;                    // pinned, kAsyncRing * kMaxRanks * kAsyncSlot
+    hipEvent_t last = nullptr;                    // behind the most recent enqueued operation (issue order across streams)
+    bool have_last = false;
+    std::atomic<int> async_error{0};
+    bool shared_mapping = false;                  // ncclCommInitAll: the process's n communicators share ONE mapping (the last one out unmaps it)
+    uint64_t n_async = 0;
 };
 
 int timeout_ms()
@@ -69,10 +97,9 @@ template <class F> bool wait_until(F &&cond)
 
 // one exchange step: every rank contributes `bytes` (<= kSlotBytes) from host memory; on return `all` (n * bytes) holds every
 // rank's contribution in rank order.  contribute == false: this rank sends nothing (broadcast from another root).
-ncclResult_t step(Comm *c, const void *mine, size_t bytes, bool contribute, char *all, int only_root)
+ncclResult_t step_n(Comm *c, uint64_t n, const void *mine, size_t bytes, bool contribute, char *all, int only_root)
 {
     Shared *sh = c->sh;
-    const uint64_t n = c->op++;
     const int half = (int)(n & 1);
     if (n >= 2) {   // the half is reused: every rank must have finished reading operation n - 2
         if (!wait_until([&] { for (int r = 0; r < c->n; r++) if (sh->depart[r].load(std::memory_order_acquire) < n - 1) return false; return true; })) {
@@ -90,6 +117,63 @@ ncclResult_t step(Comm *c, const void *mine, size_t bytes, bool contribute, char
     else for (int r = 0; r < c->n; r++) std::memcpy(all + (size_t)r * bytes, sh->data[half][r], bytes);
     sh->depart[c->rank].store(n + 1, std::memory_order_release);
     return ncclSuccess;
+}
+
+ncclResult_t step(Comm *c, const void *mine, size_t bytes, bool contribute, char *all, int only_root)
+{
+    return step_n(c, c->op++, mine, bytes, contribute, all, only_root);
+}
+
+void async_host_fn(void *p)                       // runs on the stream's callback thread: no HIP calls in here
+{
+    AsyncOp *o = static_cast<AsyncOp *>(p);
+    Comm *c = o->c;
+    const ncclResult_t r = step_n(c, o->n, o->h, o->bytes, o->root < 0 || c->rank == o->root, o->h, o->root);
+    if (r != ncclSuccess) c->async_error.store((int)r);
+}
+
+// enqueue one small collective on `stream`.  send == nullptr: this rank contributes nothing (broadcast from another root).
+ncclResult_t enqueue(Comm *c, const void *send, void *recv, size_t bytes, int root, hipStream_t stream)
+{
+    if (const int e = c->async_error.load()) return (ncclResult_t)e;
+    const uint64_t n = c->op++;
+    AsyncOp &o = c->ring[n % kAsyncRing];
+    if (o.used && hipEventSynchronize(o.done) != hipSuccess) return ncclUnhandledCudaError;   // the slot's previous use has landed
+    o.c = c; o.n = n; o.bytes = bytes; o.root = root; o.used = true;
+    if (c->have_last && hipStreamWaitEvent(stream, c->last, 0) != hipSuccess) return ncclUnhandledCudaError;   // issue order, whatever the stream
+    if (send && bytes && hipMemcpyAsync(o.h, send, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipLaunchHostFunc(stream, async_host_fn, &o) != hipSuccess) return ncclUnhandledCudaError;
+    if (bytes) {
+        if (root >= 0) {
+            if (hipMemcpyAsync(recv, o.h, bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
+        } else if (hipMemcpyAsync(recv, o.h, bytes * (size_t)c->n, hipMemcpyHostToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
+    }
+    if (hipEventRecord(o.done, stream) != hipSuccess || hipEventRecord(c->last, stream) != hipSuccess) return ncclUnhandledCudaError;
+    c->have_last = true;
+    c->n_async++;
+    return ncclSuccess;
+}
+
+// a synchronous operation behind enqueued ones: they come first (on whatever stream they sit)
+ncclResult_t drain(Comm *c)
+{
+    if (c->have_last && hipEventSynchronize(c->last) != hipSuccess) return ncclUnhandledCudaError;
+    if (const int e = c->async_error.load()) return (ncclResult_t)e;
+    return ncclSuccess;
+}
+
+bool setup_async(Comm *c)
+{
+    const char *a = std::getenv("FAKERCCL_ASYNC");
+    // (communicators of ONE process stay synchronous: their host functions would wait for each other on the runtime's callback thread)
+    c->async = a && a[0] == '1' && !c->shared_mapping;
+    if (!c->async) return true;
+    if (hipHostMalloc(&c->ring_host, (size_t)kAsyncRing * kMaxRanks * kAsyncSlot, hipHostMallocDefault) != hipSuccess) return false;
+    for (int i = 0; i < kAsyncRing; i++) {
+        c->ring[i].h = static_cast<char *>(c->ring_host) + (size_t)i * kMaxRanks * kAsyncSlot;
+        if (hipEventCreateWithFlags(&c->ring[i].done, hipEventDisableTiming) != hipSuccess) return false;
+    }
+    return hipEventCreateWithFlags(&c->last, hipEventDisableTiming) == hipSuccess;
 }
 
 size_t type_bytes(ncclDataType_t t)
@@ -133,23 +217,52 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
         (void)hipHostFree(c->host); munmap(p, sizeof(Shared)); delete c;
         return ncclSystemError;
     }
-    std::fprintf(stderr, "[fakerccl] TEST STUB: communicator of %d ranks over shared memory %s (rank %d)\n", nranks, c->name, rank);
+    if (!setup_async(c)) return ncclUnhandledCudaError;
+    std::fprintf(stderr, "[fakerccl] TEST STUB: communicator of %d ranks over shared memory %s (rank %d%s)\n", nranks, c->name, rank, c->async ? ", collectives enqueued" : "");
     *comm = reinterpret_cast<ncclComm_t>(c);
     return ncclSuccess;
 }
 
-ncclResult_t ncclCommInitAll(ncclComm_t *, int, const int *)
+// one process, n devices (here: n sub-contexts of one device): n communicators over one segment; each is driven by its own thread
+ncclResult_t ncclCommInitAll(ncclComm_t *comms, int ndev, const int *devlist)
 {
-    return ncclInvalidUsage;      // one process, many devices: not what this stub is for (groups fall back to the copy exchange)
+    if (!comms || ndev < 1 || ndev > kMaxRanks) return ncclInvalidArgument;
+    ncclUniqueId id;
+    ncclGetUniqueId(&id);
+    const int fd = shm_open(id.internal, O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)sizeof(Shared)) != 0) { if (fd >= 0) close(fd); return ncclSystemError; }
+    void *p = mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return ncclSystemError;
+    int dev0 = 0;
+    (void)hipGetDevice(&dev0);
+    for (int r = 0; r < ndev; r++) {
+        Comm *c = new Comm();
+        c->n = ndev; c->rank = r; c->shared_mapping = true;
+        std::memcpy(c->name, id.internal, sizeof c->name - 1);
+        c->sh = static_cast<Shared *>(p);
+        if (devlist) (void)hipSetDevice(devlist[r]);
+        if (hipHostMalloc(&c->host, (size_t)kMaxRanks * kSlotBytes, hipHostMallocDefault) != hipSuccess || !setup_async(c)) return ncclUnhandledCudaError;
+        c->sh->attached.fetch_add(1);
+        comms[r] = reinterpret_cast<ncclComm_t>(c);
+    }
+    (void)hipSetDevice(dev0);
+    std::fprintf(stderr, "[fakerccl] TEST STUB: %d communicators of one process over shared memory %s\n", ndev, id.internal);
+    return ncclSuccess;
 }
 
 ncclResult_t ncclCommDestroy(ncclComm_t comm)
 {
     Comm *c = reinterpret_cast<Comm *>(comm);
     if (!c) return ncclSuccess;
-    if (c->sh->detached.fetch_add(1) + 1 >= c->n) shm_unlink(c->name);     // the last rank out removes the name
-    munmap(c->sh, sizeof(Shared));
+    if (c->have_last) (void)hipEventSynchronize(c->last);
+    const bool last_out = c->sh->detached.fetch_add(1) + 1 >= c->n;
+    if (last_out) shm_unlink(c->name);                                      // the last rank out removes the name
+    if (!c->shared_mapping || last_out) munmap(c->sh, sizeof(Shared));
     (void)hipHostFree(c->host);
+    if (c->ring_host) (void)hipHostFree(c->ring_host);
+    for (AsyncOp &o : c->ring) if (o.done) (void)hipEventDestroy(o.done);
+    if (c->last) (void)hipEventDestroy(c->last);
     delete c;
     return ncclSuccess;
 }
@@ -165,6 +278,8 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataT
 {
     Comm *c = reinterpret_cast<Comm *>(comm);
     const size_t bytes = count * type_bytes(type);
+    if (c->async && bytes <= kAsyncSlot) return enqueue(c, send, recv, bytes, -1, stream);
+    if (c->async) { const ncclResult_t d = drain(c); if (d != ncclSuccess) return d; }
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;       // the send buffer's producers
     char *h = static_cast<char *>(c->host);       // this rank's piece on the way out, then every rank's pieces on the way in
     size_t off = 0;
@@ -186,6 +301,8 @@ ncclResult_t ncclBroadcast(const void *send, void *recv, size_t count, ncclDataT
     Comm *c = reinterpret_cast<Comm *>(comm);
     if (root < 0 || root >= c->n) return ncclInvalidArgument;
     const size_t bytes = count * type_bytes(type);
+    if (c->async && bytes <= kAsyncSlot) return enqueue(c, c->rank == root ? send : nullptr, recv, bytes, root, stream);
+    if (c->async) { const ncclResult_t d = drain(c); if (d != ncclSuccess) return d; }
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
     char *h = static_cast<char *>(c->host);
     size_t off = 0;
@@ -207,7 +324,7 @@ const char *ncclGetErrorString(ncclResult_t r)
     case ncclUnhandledCudaError: return "fakerccl: HIP call failed";
     case ncclSystemError: return "fakerccl: system error (shared memory / rendezvous / peer timeout)";
     case ncclInvalidArgument: return "fakerccl: invalid argument";
-    case ncclInvalidUsage: return "fakerccl: invalid usage (ncclCommInitAll is not provided)";
+    case ncclInvalidUsage: return "fakerccl: invalid usage";
     default: return "fakerccl: error";
     }
 }

@@ -69,7 +69,7 @@ def test_missing_library_is_an_error(tmp_path):
         capi.load_library(tmp_path / "libcerebro_hip.so")
 
 
-HOOK_NAMES = [b"CHIP_TEST_COMM_INIT", b"CHIP_TEST_FAIL_SHARD", b"CHIP_TEST_BATCH_OOM", b"CHIP_TEST_RESIDENT_SKIP_MASTER", b"CHIP_PNP_BACKSUB", b"CHIP_PNP_DEBUG_STOP"]
+HOOK_NAMES = [b"CHIP_TEST_COMM_INIT", b"CHIP_TEST_FAIL_SHARD", b"CHIP_TEST_BATCH_OOM", b"CHIP_TEST_RESIDENT_SKIP_MASTER", b"CHIP_TEST_RCCL_SAME_DEVICE", b"CHIP_PNP_BACKSUB", b"CHIP_PNP_DEBUG_STOP"]
 
 
 def test_product_library_contains_no_test_hook(chip_lib):

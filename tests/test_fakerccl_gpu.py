@@ -12,6 +12,7 @@ import json
 import os
 import socket
 import subprocess
+import time
 import sys
 from pathlib import Path
 
@@ -170,9 +171,11 @@ def _spawn(fn, world, tmp_path, args, env):
 BASE_ENV = {"CHIP_RCCL_LIBRARY": str(FAKE), "FAKERCCL_TIMEOUT_MS": "60000", "CHIP_COMM_INIT_TIMEOUT_MS": "90000"}
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_exchange_with_real_processes_on_one_device(world, tmp_path):
-    ret = _spawn(_worker, world, tmp_path, ("ok",), BASE_ENV)
+@pytest.mark.parametrize("world,enqueued", [(2, 0), (4, 0), (2, 1), (4, 1)])
+def test_exchange_with_real_processes_on_one_device(world, enqueued, tmp_path):
+    """enqueued = 1 (round 6): the stand-in ENQUEUES the small collectives on the caller's stream (host function between two async
+    copies) instead of executing them at call time -- the in-stream form the real collective has; same parity bar."""
+    ret = _spawn(_worker, world, tmp_path, ("ok",), dict(BASE_ENV, FAKERCCL_ASYNC=str(enqueued)))
     assert len(ret) == world and len(set(ret.values())) == 1 and next(iter(ret.values()))[0] > 0
 
 
@@ -188,24 +191,74 @@ def test_rank_out_of_memory_in_many_query_call(tmp_path):
     assert len(ret) == 2
 
 
-def test_bench_under_torchrun_reports_rccl_ranks():
-    """bench.py launched the way the driver launches N > 1, ranks sharing device 0, the library's exchange over the stub:
-    the JSON line says the in-library collective spanned N ranks (config.rccl_ranks == N, no fallback)."""
-    n = 4
+def _bench_torchrun(n, env_extra, rows="60000", steps="24"):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", **BASE_ENV)
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", **BASE_ENV, **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", str(n), "--steps", "24", "--warmup", "4", "--rows", "60000"]
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", str(n), "--steps", steps, "--warmup", "4", "--rows", rows]
+    t0 = time.time()
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    took = time.time() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0]), took
+
+
+@pytest.mark.parametrize("n", [4, 8])
+def test_bench_under_torchrun_reports_rccl_ranks(n):
+    """bench.py launched the way the driver launches N > 1 (N = 8: the driver's scaling run), ranks sharing device 0, the library's
+    exchange over the stub: the JSON line says the in-library collective spanned N ranks (config.rccl_ranks == N, no fallback), within
+    a bounded time."""
+    j, took = _bench_torchrun(n, {})
+    assert j["n_gpus"] == n and j["value"] > 0 and j["scaling"] == "strong"
+    assert j["config"]["rccl_ranks"] == n and not j["config"]["exchange_fallback"], j["config"]
+    assert "in-library RCCL" in j["config"]["exchange"]
+    assert took < 300, took
+
+
+def test_bench_one_process_eight_sub_contexts_over_the_stand_in():
+    """The OTHER layout of the driver's 8-GPU run (python bench.py --gpus 8 without torchrun = one process, chip_create_multi ->
+    ncclCommInitAll): eight sub-contexts of device 0, the stand-in's ncclCommInitAll (real RCCL refuses repeated devices; the TEST
+    build of the library lets the group ask for the RCCL transport anyway): rccl_ranks == 8, a JSON line, bounded time."""
+    env = dict(os.environ, **BASE_ENV, **HOOKS_ENV, CHIP_TEST_RCCL_SAME_DEVICE="1")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--same-device", "--steps", "24", "--warmup", "4", "--rows", "60000",
+                        "--cpu-budget", "0", "--no-pnp", "--no-batch"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    took = time.time() - t0
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == n and j["value"] > 0 and j["scaling"] == "strong"
-    assert j["config"]["rccl_ranks"] == n and not j["config"]["exchange_fallback"], j["config"]
-    assert "in-library RCCL" in j["config"]["exchange"]
+    assert j["n_gpus"] == 8 and j["value"] > 0 and j["config"]["process_layout"] == "one process"
+    assert j["config"]["rccl_ranks"] == 8 and "in-library RCCL (ncclCommInitAll" in j["config"]["exchange"], j["config"]
+    assert took < 300, took
+
+
+def test_enqueued_all_gather_overlaps_the_next_scan():
+    """with the collective ENQUEUED in-stream, all-gather(i) sits on the ctx stream while scan(i+1) runs on
+    the scan streams -- the overlap the >= 6x prediction rests on.  Timed on one GPU at 4 ranks x 125k rows of 4096-D (each rank's scan
+    ~0.3 ms when alone; here they share one device, so the absolute numbers say nothing about xGMI): the pipelined tick loop must not be
+    slower with enqueued collectives than with collectives executed at call time (which serialise host and stream per tick), and both
+    runs fire the planted revisits on every rank.  Numbers -> gpurun_out/r06/fakerccl_overlap.json."""
+    res = {}
+    for mode in ("0", "1", "0", "1"):
+        j, took = _bench_torchrun(4, {"FAKERCCL_ASYNC": mode}, rows="500000", steps="60")
+        assert j["config"]["rccl_ranks"] == 4 and not j["config"]["exchange_fallback"]
+        res.setdefault(mode, []).append(j["ms_per_step"])
+    sync_ms, async_ms = min(res["0"]), min(res["1"])
+    rep = {"ranks": 4, "rows": 500000, "ms_per_step_collective_at_call_time": res["0"], "ms_per_step_collective_enqueued": res["1"],
+           "note": "4 processes on ONE device over tests/fakerccl (shared memory): sequencing and overlap, not xGMI"}
+    out = ROOT / "gpurun_out" / "r06"
+    try:
+        out.mkdir(parents=True, exist_ok=True)
+        (out / "fakerccl_overlap.json").write_text(json.dumps(rep, indent=1))
+    except OSError:
+        pass
+    print(json.dumps(rep))
+    assert async_ms <= 1.10 * sync_ms, rep
 
 
 def _worker_1m(rank, world, uid_path, ret, want_path):
