@@ -529,7 +529,9 @@ def size_leg(chip, rows, plan, params, inflight, n_ticks=240, warm=20, dim=None,
                          "traffic_source": "profiles/scan_traffic_sizes.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this launch shape, synchronous ticks, separate run)"
                                            if sizes_traffic(rows, dim, "f64" if elem_bytes == 8 else "f32") is not None else None,
                          "kernel": "db_scan_topk_rows (row-batched form, R = 1, temporal loads: prefixes <= 768 MiB; the synchronous and the pipelined "
-                                   "tick run it fused: one launch per tick)" if rows_form else "db_scan_topk",
+                                   "tick run it fused: one launch per tick)" if rows_form else
+                                   ("db_scan_topk_rows (R = 2, non-temporal loads: rows of >= 32 KiB up to 2 GiB, fused)" if dim * elem_bytes >= 32768 and actual <= 2048 * 2**20 else
+                                    "db_scan_topk (pipelined ticks and this isolated launch)" + ("; synchronous ticks: db_scan_topk_rows fused, R = 1, non-temporal loads (<= 4 GiB)" if actual <= 4096 * 2**20 else "")),
                          "isolated_kernel_ms": iso_s * 1e3, "launches": cnt, "algorithmic_bytes_per_launch": alg, "cache_resident": cache_resident}}
 
 

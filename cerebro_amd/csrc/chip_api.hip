@@ -372,7 +372,7 @@ static int resident_tick_enqueue(Ctx *c, int64_t k, int64_t l, const chip_dot_pa
     cmd.seq_ptr = (uint64_t)(uintptr_t)s.seq_dev;
     cmd.seq_val = s.seq_want;
     // rows claimed within the workgroup: beyond cache-sized prefixes, as for launches (29k rows: 92.3 -> 91.7 us; neutral at 10k)
-    cmd.dyn_claim = (c->scan_claim == 1 || (c->scan_claim < 0 && (double)k * c->D * c->elem > c->scan_half_bytes)) ? 1u : 0u;
+    cmd.dyn_claim = (c->scan_claim == 1 || (c->scan_claim < 0 && (double)k * c->D * c->elem > c->scan_half_bytes)) ? (uint32_t)c->scan_depth : 0u;
     c->res_pending = cmd;
     resident_write_line(c, cmd);           // (before the launch: an instance must never find the previous one's leave mark in its lines)
     if (launch) {
@@ -561,11 +561,13 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     if (c->scan_blocks_per_cu < 1) c->scan_blocks_per_cu = 1;
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);
     c->scan_rows = env_int("CHIP_SCAN_ROWS", 0);
+    c->scan_depth = env_int("CHIP_SCAN_DEPTH", 1) >= 2 ? 2 : 1;
     c->scan_claim = env_int("CHIP_SCAN_CLAIM", -1);   // -1 = auto (full-occupancy launches of the row-batched kernel), 0 = never, 1 = always
     c->tick_same_stream = env_int("CHIP_TICK_SAME_STREAM", 1) != 0;
     c->scan_short_bpc = env_int("CHIP_SCAN_SHORT_BPC", 1);
     c->scan_plain_bytes = (double)env_int("CHIP_SCAN_PLAIN_MIB", 768) * 1024 * 1024;
     c->scan_half_bytes = (double)env_int("CHIP_SCAN_HALF_MIB", 192) * 1024 * 1024;
+    c->scan_sync_plain_bytes = (double)env_int("CHIP_SCAN_SYNC_PLAIN_MIB", 4096) * 1024 * 1024;
     c->scan_overlap_bytes = (double)env_int("CHIP_SCAN_OVERLAP_GIB", 8) * 1024 * 1024 * 1024;
     // a sharded ctx gets three small kernels per tick through its ctx stream underneath the scans: keep slots free for them
     c->scan_reserve = env_int("CHIP_SCAN_RESERVE", c->nranks > 1 ? 4 : 0);
@@ -699,12 +701,12 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
     a.partial = c->partial_dev[b];
     a.q64 = scan_q64(c, nq, !short_scan) ? 1 : 0;
     const int grid = scan_grid_for(c, a.n_rows, nq, a.q64 != 0);
-    a.rows_form = scan_rows_form(c, a.n_rows, nq, grid, a.q64 != 0);
+    a.rows_form = scan_rows_form(c, a.n_rows, nq, grid, a.q64 != 0, tick && c->tick_sync_now);
     a.plain_loads = (double)a.n_rows * c->D * c->elem <= c->scan_plain_bytes ? 1 : 0;
     a.stamps = c->stamps_dev;
     // rows claimed within the workgroup: measured -2 % on the synchronous 29k / 45k tick (two workgroups per CU), neutral at 10k (one
     // workgroup per CU: the launch is too short for the waves to drift apart) -- profiles/r05_short_scan.md
-    a.dyn_claim = (a.rows_form == 1 && (c->scan_claim == 1 || (c->scan_claim < 0 && grid > c->n_cus))) ? 1 : 0;
+    a.dyn_claim = (a.rows_form == 1 && (c->scan_claim == 1 || (c->scan_claim < 0 && grid > c->n_cus))) ? c->scan_depth : 0;
     // fused tick: one launch (kernels.hip fused_tick_finish) -- same-stream short ticks through the row-batched kernel, decision wanted,
     // no list output
     const bool fused = same_stream && a.rows_form > 0 && c->tick_fused && res != nullptr && out == nullptr && nq == 3 && p != nullptr;
@@ -1472,7 +1474,9 @@ int chip_loop_tick(chip_ctx *c, int64_t l, const chip_dot_params *p, chip_tick_r
     std::lock_guard<std::mutex> qlk(c->query_mu);
     CHIP_HIP(c, hipSetDevice(c->device));
     Slot &s = c->slots[CHIP_MAX_INFLIGHT - 1];
+    c->tick_sync_now = true;            // (query_mu held) the scan form of this tick is chosen for its latency: kernels.hip scan_rows_form
     int rc = tick_enqueue_slot(c, l, p, s);
+    c->tick_sync_now = false;
     if (rc != CHIP_OK) return rc;
     return tick_collect_slot(c, s, out);
 }

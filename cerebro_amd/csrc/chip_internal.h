@@ -93,7 +93,7 @@ int launch_scan(Ctx *c, hipStream_t s, const ScanArgs &a, int nq, int grid);
 int launch_merge(Ctx *c, hipStream_t s, const MergeArgs &a, int nq);
 int scan_grid_for(const Ctx *c, int64_t n_rows, int nq, bool q64);
 bool scan_q64(const Ctx *c, int nq, bool long_scan);
-int scan_rows_form(const Ctx *c, int64_t n_rows, int nq, int grid, bool q64);
+int scan_rows_form(const Ctx *c, int64_t n_rows, int nq, int grid, bool q64, bool sync_tick = false);
 int scan_forms_built();              // CHIP_SCAN_FORM_* bits of this build (-DCHIP_NO_ROWS_FORM leaves the row-batched kernel out)
 int launch_scores(Ctx *c, hipStream_t s, const ScanArgs &a, double *out_dev);   // K1s: all scores of one query, out[local row]
 int launch_store_rows(Ctx *c, hipStream_t s, const void *src, int src_elem, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring,
@@ -240,9 +240,12 @@ struct Ctx {
     int32_t scan_reserve = 0;
     int32_t scan_variant = 0;
     bool tick_same_stream = true;  // short ticks of a plain ctx: merge on the scan's stream (CHIP_TICK_SAME_STREAM=0 disables)
+    int32_t scan_depth = 1;       // CHIP_SCAN_DEPTH: batches of a wave's load stream in flight in the claimed row-batched kernel (1 or 2)
     int32_t scan_claim = -1;      // CHIP_SCAN_CLAIM: rows claimed within the workgroup (row-batched kernel, R = 1): -1 auto, 0 never (static row -> wave map), 1 always
     int32_t scan_rows = 0;        // CHIP_SCAN_ROWS: 0 = auto (prefixes up to scan_plain_bytes), 1..3 = row-batched kernel with that R for every scan, -1 = never
     double scan_plain_bytes = 768.0 * 1024 * 1024;   // prefixes up to this size: rows form, R = 1, temporal loads (CHIP_SCAN_PLAIN_MIB)
+    double scan_sync_plain_bytes = 4096.0 * 1024 * 1024;   // SYNCHRONOUS ticks: the row-batched (fused, one-launch) form up to this size (CHIP_SCAN_SYNC_PLAIN_MIB)
+    bool tick_sync_now = false;      // the tick being enqueued is a synchronous chip_loop_tick (query_mu held): form chosen for latency, not throughput
     double scan_half_bytes = 192.0 * 1024 * 1024;    // prefixes up to this size: launches take half of every CU's workgroup slots (CHIP_SCAN_HALF_MIB)
     int32_t scan_short_bpc = 1;       // workgroups per CU of a launch over a cache-sized prefix (CHIP_SCAN_SHORT_BPC; 0 = as any other)
     double scan_overlap_bytes = 8.0 * 1024 * 1024 * 1024;   // launches up to this size alternate between the two scan streams (CHIP_SCAN_OVERLAP_GIB)

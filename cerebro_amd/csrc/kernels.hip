@@ -846,6 +846,82 @@ __device__ __forceinline__ void scan_rows_body(const ScanArgs &a, const RowsPass
         auto unit_row = [&](int u) { return (int64_t)(u / wpb) * tw + wg0 + (u % wpb); };
         // (the counter was set to wpb by wave 0 before the staging barrier; unit `wave` is this wave's first, loaded above)
         int cur = wave;
+        if (t.dyn_claim >= 2 && (nb & 1) == 0) {
+            // ---- the same claimed rows with TWO batches (8 KiB) of every wave in flight (round 6) ----------------------------------
+            // With one batch in flight a wave moves 4 KiB per memory round trip, whatever the memory system could give it: in the
+            // steady state 4096 such waves saturate HBM, but the launch's tail -- the younger workgroup of every CU finishing its last
+            // row alone -- drains at half the bandwidth for ~20 us (profiles/r05_short_scan.md: 7.6 -> 5.4 -> 3.5 -> 1.3 TB/s).  R = 2
+            // doubles the bytes in flight but pads every wave's share to whole PAIRS of rows (29 000 rows over 4096 waves: 7.08 -> 8,
+            // 13 % more bytes).  Here the unit stays ONE claimed row and the load stream runs two batches ahead instead of one, across
+            // the row boundary into the next claimed row: slots 0..3 (v80..v95) hold the even batches of a row, slots 4..7 (v96..v111)
+            // the odd ones; consuming slot s re-issues it for the batch two ahead, so behind every slot exactly 7 younger loads are
+            // outstanding (the rest of its batch, the other set, the slots of its own set already re-issued).  One accumulator chain
+            // per query in ascending element order, as before: same bits.
+#define CHIP_ROWS2_FMA(slot, chunk, base, CNT)                                                                          \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        const int e_ = (base) + (chunk) * CH + lane * N;                                                                \
+        V w_[NQ];                                                                                                       \
+        _Pragma("unroll") for (int q = 0; q < NQ; q++) w_[q] = *reinterpret_cast<const V *>(qs + q * D + e_);           \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; h_++) {                                                              \
+            double vd_[2];                                                                                              \
+            if (h_ == 0) rows_take<rows_slot_reg<1>(slot, 0), CNT, 0>(vd_, T());                                        \
+            else rows_take<rows_slot_reg<1>(slot, 0), CNT, 1>(vd_, T());                                                \
+            _Pragma("unroll") for (int c = 0; c < N / 2; c++)                                                           \
+                _Pragma("unroll") for (int q = 0; q < NQ; q++)                                                          \
+                    acc[0][q] = __builtin_fma((double)w_[q][h_ * (N / 2) + c], vd_[c], acc[0][q]);                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+        }                                                                                                               \
+    } while (0)
+#define CHIP_ROWS2_ISSUE(slot, chunk, byte_off, rowp) rows_issue<NTL, rows_slot_reg<1>(slot, 0), (chunk) * 1024>((byte_off) + lane_off, rowp)
+            const T *rowp = row[0], *nrow = row[0];
+            if (cur < n_units) {   // batch 1 of the first row (batch 0 went out in front of the staging barrier)
+                CHIP_ROWS2_ISSUE(4, 0, 4096u, rowp); CHIP_ROWS2_ISSUE(5, 1, 4096u, rowp); CHIP_ROWS2_ISSUE(6, 2, 4096u, rowp); CHIP_ROWS2_ISSUE(7, 3, 4096u, rowp);
+            }
+            while (cur < n_units) {
+                uint32_t nxt_v = 0;
+                if (lane == 0) nxt_v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                int nxt = 0;
+                bool more = false;
+                for (b = 0; b < nb; b += 2) {
+                    const int base0 = b * (CH * U), base1 = base0 + CH * U;
+                    const T *ra = rowp;
+                    uint32_t oa = (uint32_t)(b + 2) * 4096u;
+                    bool ahead = true;
+                    if (b + 2 == nb) {                       // the two batches ahead are the next claimed row's first two
+                        nxt = __builtin_amdgcn_readfirstlane((int)nxt_v);
+                        more = nxt < n_units;
+                        ahead = more;
+                        oa = 0u;
+                        if (more) { nrow = uniform_ptr(row_base_uniform<T>(a, unit_row(nxt))); ra = nrow; }
+                    }
+                    if (ahead) {
+                        CHIP_ROWS2_FMA(0, 0, base0, 7); CHIP_ROWS2_ISSUE(0, 0, oa, ra);
+                        CHIP_ROWS2_FMA(1, 1, base0, 7); CHIP_ROWS2_ISSUE(1, 1, oa, ra);
+                        CHIP_ROWS2_FMA(2, 2, base0, 7); CHIP_ROWS2_ISSUE(2, 2, oa, ra);
+                        CHIP_ROWS2_FMA(3, 3, base0, 7); CHIP_ROWS2_ISSUE(3, 3, oa, ra);
+                        CHIP_ROWS2_FMA(4, 0, base1, 7); CHIP_ROWS2_ISSUE(4, 0, oa + 4096u, ra);
+                        CHIP_ROWS2_FMA(5, 1, base1, 7); CHIP_ROWS2_ISSUE(5, 1, oa + 4096u, ra);
+                        CHIP_ROWS2_FMA(6, 2, base1, 7); CHIP_ROWS2_ISSUE(6, 2, oa + 4096u, ra);
+                        CHIP_ROWS2_FMA(7, 3, base1, 7); CHIP_ROWS2_ISSUE(7, 3, oa + 4096u, ra);
+                    } else {                                 // the wave's last two batches: nothing is re-issued
+                        CHIP_ROWS2_FMA(0, 0, base0, 7); CHIP_ROWS2_FMA(1, 1, base0, 6); CHIP_ROWS2_FMA(2, 2, base0, 5); CHIP_ROWS2_FMA(3, 3, base0, 4);
+                        CHIP_ROWS2_FMA(4, 0, base1, 3); CHIP_ROWS2_FMA(5, 1, base1, 2); CHIP_ROWS2_FMA(6, 2, base1, 1); CHIP_ROWS2_FMA(7, 3, base1, 0);
+                    }
+                }
+                const int64_t r = unit_row(cur);
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const double s = butterfly_sum(acc[0][q]);
+                    acc[0][q] = 0.0;
+                    wave_topk_offer_lds(s, r * a.idx_mul + a.idx_add, K, lane, mylists + q * CHIP_MAX_TOPK, thr_s[q], thr_i[q]);
+                }
+                cur = more ? nxt : n_units;
+                rowp = nrow;
+            }
+#undef CHIP_ROWS2_FMA
+#undef CHIP_ROWS2_ISSUE
+        } else
         while (cur < n_units) {
             uint32_t nxt_v = 0;                                 // next unit, claimed by lane 0 alone: needed at this row's last batch
             if (lane == 0) nxt_v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1180,10 +1256,10 @@ int scan_forms_built()
 #endif
 }
 
-int scan_rows_form(const Ctx *c, int64_t n_rows, int nq, int grid, bool q64)
+int scan_rows_form(const Ctx *c, int64_t n_rows, int nq, int grid, bool q64, bool sync_tick)
 {
 #ifdef CHIP_NO_ROWS_FORM
-    (void)c; (void)n_rows; (void)nq; (void)grid; (void)q64;
+    (void)c; (void)n_rows; (void)nq; (void)grid; (void)q64; (void)sync_tick;
     return 0;
 #endif
     if (q64 || c->scan_rows < 0 || c->scan_variant == 1 || (int64_t)c->D * c->elem % 4096 != 0) return 0;
@@ -1202,7 +1278,21 @@ int scan_rows_form(const Ctx *c, int64_t n_rows, int nq, int grid, bool q64)
     //   100k / 1M rows: one-row kernel 232 / 2355 vs 245 / 2353.
     // => prefixes up to scan_plain_bytes (768 MiB: a good part of them survives in the 256 MiB Infinity Cache from tick to tick) take
     //    the rows form with R = 1 and temporal loads; longer ones the one-row kernel with non-temporal loads.
-    return (double)n_rows * c->D * c->elem <= c->scan_plain_bytes ? 1 : 0;
+    // Round 6, beyond 768 MiB (non-temporal loads either way; us: isolated kernel / pipelined step / SYNCHRONOUS tick, two boxes,
+    // profiles/r06_scan_rows_policy_ab.txt, r06_shape_ab_8192.txt):
+    //   4096-D x  60k (0.98 GB): one-row 167 / 155 / 188   rows R = 1 165 / 149 / 162   R = 2 169 / 149 / 171
+    //   4096-D x 100k (1.64 GB): one-row 257 / 245 / 282   rows R = 1 257 / 268 / 259   R = 2 264 / 256 / 274
+    //   8192-D x  29k (0.95 GB, the reference's default model at its own capacity, Cerebro.cpp:946,1021):
+    //                            one-row 180 / 166 / 207   rows R = 1 180 / 154 / 182   R = 2 168-172 / 153-157 / 170-178
+    // => a SYNCHRONOUS tick (chip_loop_tick: what the reference's 10 Hz thread issues) takes the rows form -- fused, ONE launch, no
+    //    merge kernel behind the scan -- up to scan_sync_plain_bytes (4 GiB; beyond that the 25 us are < 1 % of the tick); rows of
+    //    32 KiB and more (8192-D floats) with two rows per wave in flight there, pipelined ticks of such rows likewise up to 2 GiB.
+    const double bytes = (double)n_rows * c->D * c->elem;
+    if (bytes <= c->scan_plain_bytes) return 1;
+    const bool wide_rows = (int64_t)c->D * c->elem >= 32768 && nq < 4;
+    if (sync_tick && bytes <= c->scan_sync_plain_bytes) return wide_rows ? 2 : 1;
+    if (wide_rows && bytes <= 2048.0 * 1024 * 1024) return 2;
+    return 0;
 }
 
 int scan_grid_for(const Ctx *c, int64_t n_rows, int nq, bool q64)

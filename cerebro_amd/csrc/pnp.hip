@@ -2334,11 +2334,6 @@ struct PnpState {
     unsigned long long *stamps = nullptr;                // tuning only (CHIP_PNP_STAMPS): [H][8] of pnp_eig_score, then [H][16] of pnp_build_solve
     hipStream_t s2 = nullptr;                            // second launch-pair stream of a split batch (CHIP_PNP_GROUPS)
     hipEvent_t ev_in = nullptr, ev_g2 = nullptr;
-    // pipelined form of a large call (round 6): pnp_build_solve launches of consecutive slot groups back to back on s_build, the
-    // pnp_eig_score launch of group g on s_eig behind build(g)'s event -- eig(g) runs underneath build(g+1..)
-    static constexpr int kPipeMax = 32;
-    hipStream_t s_build = nullptr, s_eig = nullptr;
-    hipEvent_t ev_b[kPipeMax] = {}, ev_done = nullptr;
     int32_t stamps_n = 0;
 };
 
@@ -2372,10 +2367,6 @@ static void pnp_free_dev(PnpState *st)
     (void)hipHostFree(st->h_nsol); (void)hipHostFree(st->h_mask); (void)hipHostFree(st->h_sample_in);
     (void)hipFree(st->stamps);
     if (st->s2) (void)hipStreamDestroy(st->s2);
-    if (st->s_build) (void)hipStreamDestroy(st->s_build);
-    if (st->s_eig) (void)hipStreamDestroy(st->s_eig);
-    for (hipEvent_t e : st->ev_b) if (e) (void)hipEventDestroy(e);
-    if (st->ev_done) (void)hipEventDestroy(st->ev_done);
     if (st->ev_in) (void)hipEventDestroy(st->ev_in);
     if (st->ev_g2) (void)hipEventDestroy(st->ev_g2);
 }
@@ -2522,49 +2513,16 @@ static int pnp_run(Ctx *c, PnpState *st, int P, const double *const *X, const do
     ea.T_out = st->T_out; ea.cost = st->cost; ea.nin = st->nin; ea.valid = st->valid; ea.nsol = st->nsol; ea.mask = st->mask;
     if (want_stamps) ea.stamps = st->stamps;
     // A batch of several problems may go out as `groups` launch pairs on as many streams (CHIP_PNP_GROUPS, tuning): both kernels are
-    // latency chains that leave issue slots free, so build(group g+1) can run underneath eig(group g).
+    // latency chains that leave issue slots free, so build(group g+1) can run underneath eig(group g).  Measured NEGATIVE twice: two
+    // groups -3 % (round 5), and the fully pipelined form -- pnp_build_solve of consecutive slot groups back to back on one stream,
+    // pnp_eig_score(g) on a second, lower-priority stream behind build(g)'s event -- 1.7-2.1 M hyp/s against 2.52 M for one launch pair
+    // (round 6, profiles/r06_pnp.md): the two kernels do not share a CU's REGISTER FILE -- four resident eigen waves (4 x 128 rows)
+    // leave room for ONE pnp_build_solve workgroup (784 rows) instead of two, whatever the stream priorities say.
     static const int want_groups = [] { const char *e = std::getenv("CHIP_PNP_GROUPS"); return e ? std::atoi(e) : 1; }();
     static const int want_prio = [] { const char *e = std::getenv("CHIP_PNP_PRIO"); return e ? std::atoi(e) : 0; }();   // measured: no effect (profiles/r03_pnp_pmc.md)
     sa.factor_prio = want_prio;
     int groups = want_groups < 1 ? 1 : (want_groups > 2 ? 2 : want_groups);
     if (groups > P) groups = P;
-    // Pipelined form (round 6): a call of more slots than the chip holds pnp_build_solve workgroups at once (2 per CU) is cut into
-    // groups of `pipe_slots` slots; the pnp_build_solve launches of all groups go back to back onto a stream of HIGH priority, the
-    // pnp_eig_score launch of group g onto a stream of LOW priority behind build(g)'s event.  pnp_build_solve leaves a quarter of
-    // every CU's registers and 60 of its 160 KiB of LDS unused and keeps the vector pipe 31 % busy: the eigen waves of the finished
-    // groups run in what is left, and the dispatcher's priority order keeps them from taking the build workgroups' slots.
-    // CHIP_PNP_PIPE_SLOTS: slots per group (0 = off: one launch pair).
-    static const int pipe_slots = [] { const char *e = std::getenv("CHIP_PNP_PIPE_SLOTS"); return e ? std::atoi(e) : 0; }();
-    const int total_slots = P * H;
-    int pipe_groups = (pipe_slots > 0 && total_slots > pipe_slots && !want_stamps) ? (total_slots + pipe_slots - 1) / pipe_slots : 1;
-    if (pipe_groups > PnpState::kPipeMax) pipe_groups = PnpState::kPipeMax;
-    if (pipe_groups > 1) {
-        if (!st->s_build) {
-            int pr_lo = 0, pr_hi = 0;
-            CHIP_HIP(c, hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi));
-            static const int flat = [] { const char *e = std::getenv("CHIP_PNP_PIPE_FLAT"); return e ? std::atoi(e) : 0; }();   // A/B: no priorities
-            CHIP_HIP(c, hipStreamCreateWithPriority(&st->s_build, hipStreamNonBlocking, flat ? 0 : pr_hi));
-            CHIP_HIP(c, hipStreamCreateWithPriority(&st->s_eig, hipStreamNonBlocking, flat ? 0 : pr_lo));
-            for (hipEvent_t &e : st->ev_b) CHIP_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            CHIP_HIP(c, hipEventCreateWithFlags(&st->ev_done, hipEventDisableTiming));
-            if (!st->ev_in) CHIP_HIP(c, hipEventCreateWithFlags(&st->ev_in, hipEventDisableTiming));
-        }
-        CHIP_HIP(c, hipEventRecord(st->ev_in, s));              // whatever this call put on s_pnp before the kernels (H2D copy in A/B runs)
-        CHIP_HIP(c, hipStreamWaitEvent(st->s_build, st->ev_in, 0));
-        for (int g = 0; g < pipe_groups; g++) {
-            const int s0 = (int)((long long)total_slots * g / pipe_groups), s1 = (int)((long long)total_slots * (g + 1) / pipe_groups);
-            sa.slot0 = ea.slot0 = s0;
-            hipLaunchKernelGGL(pnp_build_solve<false>, dim3(s1 - s0), dim3(kSolveThreads), lds, st->s_build, sa);
-            CHIP_HIP(c, hipGetLastError());
-            CHIP_HIP(c, hipEventRecord(st->ev_b[g], st->s_build));
-            CHIP_HIP(c, hipStreamWaitEvent(st->s_eig, st->ev_b[g], 0));
-            hipLaunchKernelGGL(pnp_eig_score<false>, dim3(s1 - s0), dim3(64), 0, st->s_eig, ea);
-            CHIP_HIP(c, hipGetLastError());
-        }
-        CHIP_HIP(c, hipEventRecord(st->ev_done, st->s_eig));
-        CHIP_HIP(c, hipStreamWaitEvent(s, st->ev_done, 0));     // s_pnp stays the stream a caller (and chip_synchronize) waits on
-        groups = 0;
-    }
     if (groups > 1 && !st->s2) {
         CHIP_HIP(c, hipStreamCreateWithFlags(&st->s2, hipStreamNonBlocking));
         CHIP_HIP(c, hipEventCreateWithFlags(&st->ev_in, hipEventDisableTiming));

@@ -192,7 +192,8 @@ def test_resident_ticks_while_another_thread_appends_across_segments(monkeypatch
         assert not errors, errors
         assert bad == 0, (bad, n)
         ticks, launches = resident_stats(chip)
-        assert ticks == n + len(ls) and launches >= 2
+        # (round 6: ticks that arrive while the appender grows the DB by a segment -- the mode is PAUSED for that section -- are launched)
+        assert n + len(ls) - 200 <= ticks <= n + len(ls) and launches >= 2, (ticks, n, launches)
         # ... and a tick whose queries and prefix lie in the NEW segment (launched: 0.9 GB), then a resident one again
         r = chip.loop_tick(60_000, p)
         assert r.status == capi.CHIP_TICK_SCANNED
