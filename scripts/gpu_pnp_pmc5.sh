@@ -1,6 +1,6 @@
-# Counters + durations of the BATCHED PnP call (8 problems x 1000 hypotheses per launch pair, 5 calls) -> gpurun_out/r05/pnp_pmc.json
+# Counters + durations of the BATCHED PnP call (8 problems x 1000 hypotheses per launch pair, 5 calls) -> gpurun_out/r06/pnp_pmc.json
 # (copied to profiles/pnp_pmc.json: bench.py's pnp.roofline.valu_busy).  Separate passes: kernel trace, then --pmc (no other trace domain).
-O=gpurun_out/r05/pnp_pmc
+O=gpurun_out/r06/pnp_pmc
 mkdir -p $O; rm -rf $O/*
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o p -- python scripts/run_pnp_batch_once.py > $O/trace.log 2>&1
@@ -8,7 +8,7 @@ timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRB
 timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU --kernel-trace -d $O/pmc_lds -o p -- python scripts/run_pnp_batch_once.py > $O/pmc_lds.log 2>&1
 python - <<'PY'
 import sqlite3, glob, json
-O = "gpurun_out/r05/pnp_pmc"
+O = "gpurun_out/r06/pnp_pmc"
 dur, ctr = {}, {}
 def short(n):
     return "pnp_build_solve" if "pnp_build_solve" in n else "pnp_eig_score" if "pnp_eig_score" in n else n
@@ -27,6 +27,6 @@ out = {"workload": "chip_pnp_ransac_batch: 8 problems x 1000 hypotheses x 512 co
        "source": "profiles/pnp_pmc.json: rocprofv3 --pmc SQ_INSTS_VALU ... (separate pass) + --kernel-trace durations; valu_busy = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel duration x 2.4 GHz)",
        "valu_busy": busy, "kernels": dur, "counters_avg_per_launch": ctr,
        "valu_insts_per_hypothesis": {k: ctr[k]["SQ_INSTS_VALU"] / 8000.0 for k in ctr if "SQ_INSTS_VALU" in ctr[k]}}
-open("gpurun_out/r05/pnp_pmc.json", "w").write(json.dumps(out, indent=1) + "\n")
+open("gpurun_out/r06/pnp_pmc.json", "w").write(json.dumps(out, indent=1) + "\n")
 print(json.dumps({"valu_busy": busy, "kernels": dur}, indent=1))
 PY
