@@ -93,8 +93,8 @@ $(LIBDIR)/minimal_loop_detector: examples/minimal_loop_detector.cc include/cereb
 # so); a machine without pytest / llvm-objdump gets a loud warning and the library as built.  `make lib` never runs it.
 verify: $(LIBDIR)/.codeobj_verified
 $(LIBDIR)/.codeobj_verified: $(LIBDIR)/libcerebro_hip.so tests/test_codeobj_registers.py scripts/verify_codeobj.sh $(LIBDIR)/libcerebro_host.so $(LIBDIR)/cerebro_replay $(LIBDIR)/minimal_loop_detector
-	bash scripts/verify_codeobj.sh
-	@touch $@
+	@ROCM="$(ROCM)" MAKE="$(MAKE)" bash scripts/verify_codeobj.sh; rc=$$?; \
+	if [ $$rc -eq 0 ]; then touch $@; elif [ $$rc -eq 3 ]; then echo "make verify: NOT verified (no stamp written)"; else exit $$rc; fi
 
 $(LIBDIR)/sync_tick_latency: examples/sync_tick_latency.cc include/cerebro_hip.h $(LIBDIR)/libcerebro_hip.so
 	$(CXX) -O2 -std=c++17 -Wall -Wextra -Iinclude $< -o $@ -L$(LIBDIR) -lcerebro_hip -Wl,-rpath,'$$ORIGIN'

@@ -8,15 +8,20 @@
 #   * the check fails on the full build -> loud line, kernels.hip is rebuilt with -DCHIP_NO_ROWS_FORM (every scan takes the one-row
 #     kernel: same results, short prefixes slower), relinked, and the check is run again on THAT build -- only if that fails too
 #     does the build fail.  chip_get_info().scan_forms / chip_build_scan_forms() say which build a process has loaded.
+# ROCM and MAKE come from the Makefile: the tool path follows a ROCm installed elsewhere, the recursive build keeps -j and
+# command-line variables.  Exit 3 = the check could NOT run: the Makefile then does not stamp .codeobj_verified.
 set -u
 cd "$(dirname "$0")/.."
 LIBDIR=cerebro_amd/lib
-if ! python3 -c 'import pytest' 2>/dev/null || [ ! -x /opt/rocm/lib/llvm/bin/llvm-objdump ]; then
+ROCM=${ROCM:-/opt/rocm}
+MAKE=${MAKE:-make}
+export ROCM
+if ! python3 -c 'import pytest' 2>/dev/null || [ ! -x "$ROCM/lib/llvm/bin/llvm-objdump" ]; then
     echo "################################################################################################" >&2
     echo "## make verify: pytest or llvm-objdump is missing -- the code-object checks were NOT run.       ##" >&2
     echo "## libcerebro_hip.so stays as built; run tests/test_codeobj_registers.py before deploying it.  ##" >&2
     echo "################################################################################################" >&2
-    exit 0
+    exit 3
 fi
 # CHIP_VERIFY_FORCE_FAIL=1 (exercising this script): treat the first check as failed
 if [ "${CHIP_VERIFY_FORCE_FAIL:-0}" != "1" ] && python3 -m pytest tests/test_codeobj_registers.py -q -x -p no:cacheprovider -k "not cache_maintenance"; then
@@ -30,7 +35,7 @@ echo "## registers of db_scan_topk_rows differently?).  Rebuilding WITHOUT the r
 echo "## (-DCHIP_NO_ROWS_FORM): same results, short prefixes (<= 768 MiB) 10-25 % slower.             ##" >&2
 echo "################################################################################################" >&2
 rm -f $LIBDIR/kernels.o
-make EXTRA_HIPFLAGS=-DCHIP_NO_ROWS_FORM lib host || exit 1
+$MAKE ROCM="$ROCM" EXTRA_HIPFLAGS=-DCHIP_NO_ROWS_FORM lib host || exit 1
 python3 -m pytest tests/test_codeobj_registers.py -q -x -p no:cacheprovider -k "not cache_maintenance" || exit 1
 touch $LIBDIR/.rows_form_disabled
 exit 0
