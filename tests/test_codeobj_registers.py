@@ -19,7 +19,7 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 SO = ROOT / "cerebro_amd" / "lib" / "libcerebro_hip.so"
-LLVM = Path("/opt/rocm/lib/llvm/bin")
+LLVM = Path(__import__("os").environ.get("ROCM", "/opt/rocm")) / "lib" / "llvm" / "bin"   # ROCM: as the Makefile / scripts/verify_codeobj.sh
 pytestmark = pytest.mark.needs_hip_build
 
 LO, HI = 80, 127
