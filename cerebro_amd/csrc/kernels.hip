@@ -846,49 +846,78 @@ __device__ __forceinline__ void scan_rows_body(const ScanArgs &a, const RowsPass
         auto unit_row = [&](int u) { return (int64_t)(u / wpb) * tw + wg0 + (u % wpb); };
         // (the counter was set to wpb by wave 0 before the staging barrier; unit `wave` is this wave's first, loaded above)
         int cur = wave;
-        if (t.dyn_claim >= 2 && (nb & 1) == 0) {
-            // ---- the same claimed rows with TWO batches (8 KiB) of every wave in flight (round 6) ----------------------------------
-            // With one batch in flight a wave moves 4 KiB per memory round trip, whatever the memory system could give it: in the
-            // steady state 4096 such waves saturate HBM, but the launch's tail -- the younger workgroup of every CU finishing its last
-            // row alone -- drains at half the bandwidth for ~20 us (profiles/r05_short_scan.md: 7.6 -> 5.4 -> 3.5 -> 1.3 TB/s).  R = 2
-            // doubles the bytes in flight but pads every wave's share to whole PAIRS of rows (29 000 rows over 4096 waves: 7.08 -> 8,
-            // 13 % more bytes).  Here the unit stays ONE claimed row and the load stream runs two batches ahead instead of one, across
-            // the row boundary into the next claimed row: slots 0..3 (v80..v95) hold the even batches of a row, slots 4..7 (v96..v111)
-            // the odd ones; consuming slot s re-issues it for the batch two ahead, so behind every slot exactly 7 younger loads are
-            // outstanding (the rest of its batch, the other set, the slots of its own set already re-issued).  One accumulator chain
-            // per query in ascending element order, as before: same bits.
-#define CHIP_ROWS2_FMA(slot, chunk, base, CNT)                                                                          \
+        bool experimental = false;
+#ifdef CHIP_SCAN_TUNING_VARIANTS   // A/B builds only (make EXTRA_HIPFLAGS=-DCHIP_SCAN_TUNING_VARIANTS): the product kernel carries the product stream alone
+        // ---- experimental forms of the claimed stream, selected by t.dyn_claim (CHIP_SCAN_DEPTH; the default, 1, is the loop below);
+        //      all measured neutral or negative (profiles/r06_short_scan.md §2) ----
+        //   2: TWO batches (8 KiB) of every wave in flight, the unit still one claimed row (round 6; profiles/r06_short_scan.md §2):
+        //      slots 0..3 (v80..v95) hold the even batches of a row, slots 4..7 (v96..v111) the odd ones; consuming slot s re-issues it for
+        //      the batch two ahead, across the row boundary into the next claimed row, so behind every slot exactly 7 younger loads are
+        //      outstanding.  Steady state 7.6 -> 8.6 TB/s at 29k rows, but the OLDER workgroup of every CU takes all of the gain.
+        //   3 / 4: depth 1 / depth 2 with the slot's re-issue moved IN FRONT of its arithmetic and both at raised issue priority: what
+        //      starves the younger workgroup is not memory but the vector pipe's oldest-first arbitration -- a wave re-issues a slot only
+        //      after that slot's 12 fp64 fmas, and a young wave's fmas queue behind every older wave's burst, so its load pipeline runs
+        //      with gaps.  Here the wait + conversion of a slot (4 v_cvt) and the load that refills it run at s_setprio 3, the fmas at 0.
+        //   One accumulator chain per query in ascending element order in every form: same bits.
+#define CHIP_ROWSX_ISSUE(slot, chunk, byte_off, rowp) rows_issue<NTL, rows_slot_reg<1>(slot, 0), (chunk) * 1024>((byte_off) + lane_off, rowp)
+#define CHIP_ROWSX_STEP(slot, chunk, base, CNT, DO_ISSUE, byte_off, rowp)                                               \
     do {                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         const int e_ = (base) + (chunk) * CH + lane * N;                                                                \
         V w_[NQ];                                                                                                       \
         _Pragma("unroll") for (int q = 0; q < NQ; q++) w_[q] = *reinterpret_cast<const V *>(qs + q * D + e_);           \
-        _Pragma("unroll") for (int h_ = 0; h_ < 2; h_++) {                                                              \
-            double vd_[2];                                                                                              \
-            if (h_ == 0) rows_take<rows_slot_reg<1>(slot, 0), CNT, 0>(vd_, T());                                        \
-            else rows_take<rows_slot_reg<1>(slot, 0), CNT, 1>(vd_, T());                                                \
-            _Pragma("unroll") for (int c = 0; c < N / 2; c++)                                                           \
-                _Pragma("unroll") for (int q = 0; q < NQ; q++)                                                          \
-                    acc[0][q] = __builtin_fma((double)w_[q][h_ * (N / 2) + c], vd_[c], acc[0][q]);                      \
+        if constexpr (EARLY) {                                                                                          \
+            double va_[2], vb_[2];                                                                                      \
+            __builtin_amdgcn_s_setprio(3);                                                                              \
+            rows_take<rows_slot_reg<1>(slot, 0), CNT, 0>(va_, T());                                                     \
+            rows_take<rows_slot_reg<1>(slot, 0), CNT, 1>(vb_, T());                                                     \
+            if (DO_ISSUE) CHIP_ROWSX_ISSUE(slot, chunk, byte_off, rowp);                                                \
+            __builtin_amdgcn_s_setprio(0);                                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                                          \
+            _Pragma("unroll") for (int c = 0; c < N / 2; c++)                                                           \
+                _Pragma("unroll") for (int q = 0; q < NQ; q++) acc[0][q] = __builtin_fma((double)w_[q][c], va_[c], acc[0][q]); \
+            _Pragma("unroll") for (int c = 0; c < N / 2; c++)                                                           \
+                _Pragma("unroll") for (int q = 0; q < NQ; q++) acc[0][q] = __builtin_fma((double)w_[q][N / 2 + c], vb_[c], acc[0][q]); \
+            __builtin_amdgcn_sched_barrier(0);                                                                          \
+        } else {                                                                                                        \
+            _Pragma("unroll") for (int h_ = 0; h_ < 2; h_++) {                                                          \
+                double vd_[2];                                                                                          \
+                if (h_ == 0) rows_take<rows_slot_reg<1>(slot, 0), CNT, 0>(vd_, T());                                    \
+                else rows_take<rows_slot_reg<1>(slot, 0), CNT, 1>(vd_, T());                                            \
+                _Pragma("unroll") for (int c = 0; c < N / 2; c++)                                                       \
+                    _Pragma("unroll") for (int q = 0; q < NQ; q++)                                                      \
+                        acc[0][q] = __builtin_fma((double)w_[q][h_ * (N / 2) + c], vd_[c], acc[0][q]);                  \
+                __builtin_amdgcn_sched_barrier(0);                                                                      \
+            }                                                                                                           \
+            if (DO_ISSUE) CHIP_ROWSX_ISSUE(slot, chunk, byte_off, rowp);                                                \
         }                                                                                                               \
     } while (0)
-#define CHIP_ROWS2_ISSUE(slot, chunk, byte_off, rowp) rows_issue<NTL, rows_slot_reg<1>(slot, 0), (chunk) * 1024>((byte_off) + lane_off, rowp)
+        auto finish_row = [&](int unit) {
+            const int64_t r = unit_row(unit);
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const double s = butterfly_sum(acc[0][q]);
+                acc[0][q] = 0.0;
+                wave_topk_offer_lds(s, r * a.idx_mul + a.idx_add, K, lane, mylists + q * CHIP_MAX_TOPK, thr_s[q], thr_i[q]);
+            }
+        };
+        auto stream_depth2 = [&](auto early_tag) {
+            constexpr bool EARLY = decltype(early_tag)::value;
             const T *rowp = row[0], *nrow = row[0];
             if (cur < n_units) {   // batch 1 of the first row (batch 0 went out in front of the staging barrier)
-                CHIP_ROWS2_ISSUE(4, 0, 4096u, rowp); CHIP_ROWS2_ISSUE(5, 1, 4096u, rowp); CHIP_ROWS2_ISSUE(6, 2, 4096u, rowp); CHIP_ROWS2_ISSUE(7, 3, 4096u, rowp);
+                CHIP_ROWSX_ISSUE(4, 0, 4096u, rowp); CHIP_ROWSX_ISSUE(5, 1, 4096u, rowp); CHIP_ROWSX_ISSUE(6, 2, 4096u, rowp); CHIP_ROWSX_ISSUE(7, 3, 4096u, rowp);
             }
             while (cur < n_units) {
                 uint32_t nxt_v = 0;
                 if (lane == 0) nxt_v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 int nxt = 0;
                 bool more = false;
-                for (b = 0; b < nb; b += 2) {
-                    const int base0 = b * (CH * U), base1 = base0 + CH * U;
+                for (int bb = 0; bb < nb; bb += 2) {
+                    const int base0 = bb * (CH * U), base1 = base0 + CH * U;
                     const T *ra = rowp;
-                    uint32_t oa = (uint32_t)(b + 2) * 4096u;
+                    uint32_t oa = (uint32_t)(bb + 2) * 4096u;
                     bool ahead = true;
-                    if (b + 2 == nb) {                       // the two batches ahead are the next claimed row's first two
+                    if (bb + 2 == nb) {                      // the two batches ahead are the next claimed row's first two
                         nxt = __builtin_amdgcn_readfirstlane((int)nxt_v);
                         more = nxt < n_units;
                         ahead = more;
@@ -896,32 +925,64 @@ __device__ __forceinline__ void scan_rows_body(const ScanArgs &a, const RowsPass
                         if (more) { nrow = uniform_ptr(row_base_uniform<T>(a, unit_row(nxt))); ra = nrow; }
                     }
                     if (ahead) {
-                        CHIP_ROWS2_FMA(0, 0, base0, 7); CHIP_ROWS2_ISSUE(0, 0, oa, ra);
-                        CHIP_ROWS2_FMA(1, 1, base0, 7); CHIP_ROWS2_ISSUE(1, 1, oa, ra);
-                        CHIP_ROWS2_FMA(2, 2, base0, 7); CHIP_ROWS2_ISSUE(2, 2, oa, ra);
-                        CHIP_ROWS2_FMA(3, 3, base0, 7); CHIP_ROWS2_ISSUE(3, 3, oa, ra);
-                        CHIP_ROWS2_FMA(4, 0, base1, 7); CHIP_ROWS2_ISSUE(4, 0, oa + 4096u, ra);
-                        CHIP_ROWS2_FMA(5, 1, base1, 7); CHIP_ROWS2_ISSUE(5, 1, oa + 4096u, ra);
-                        CHIP_ROWS2_FMA(6, 2, base1, 7); CHIP_ROWS2_ISSUE(6, 2, oa + 4096u, ra);
-                        CHIP_ROWS2_FMA(7, 3, base1, 7); CHIP_ROWS2_ISSUE(7, 3, oa + 4096u, ra);
+                        CHIP_ROWSX_STEP(0, 0, base0, 7, 1, oa, ra); CHIP_ROWSX_STEP(1, 1, base0, 7, 1, oa, ra);
+                        CHIP_ROWSX_STEP(2, 2, base0, 7, 1, oa, ra); CHIP_ROWSX_STEP(3, 3, base0, 7, 1, oa, ra);
+                        CHIP_ROWSX_STEP(4, 0, base1, 7, 1, oa + 4096u, ra); CHIP_ROWSX_STEP(5, 1, base1, 7, 1, oa + 4096u, ra);
+                        CHIP_ROWSX_STEP(6, 2, base1, 7, 1, oa + 4096u, ra); CHIP_ROWSX_STEP(7, 3, base1, 7, 1, oa + 4096u, ra);
                     } else {                                 // the wave's last two batches: nothing is re-issued
-                        CHIP_ROWS2_FMA(0, 0, base0, 7); CHIP_ROWS2_FMA(1, 1, base0, 6); CHIP_ROWS2_FMA(2, 2, base0, 5); CHIP_ROWS2_FMA(3, 3, base0, 4);
-                        CHIP_ROWS2_FMA(4, 0, base1, 3); CHIP_ROWS2_FMA(5, 1, base1, 2); CHIP_ROWS2_FMA(6, 2, base1, 1); CHIP_ROWS2_FMA(7, 3, base1, 0);
+                        CHIP_ROWSX_STEP(0, 0, base0, 7, 0, 0u, ra); CHIP_ROWSX_STEP(1, 1, base0, 6, 0, 0u, ra);
+                        CHIP_ROWSX_STEP(2, 2, base0, 5, 0, 0u, ra); CHIP_ROWSX_STEP(3, 3, base0, 4, 0, 0u, ra);
+                        CHIP_ROWSX_STEP(4, 0, base1, 3, 0, 0u, ra); CHIP_ROWSX_STEP(5, 1, base1, 2, 0, 0u, ra);
+                        CHIP_ROWSX_STEP(6, 2, base1, 1, 0, 0u, ra); CHIP_ROWSX_STEP(7, 3, base1, 0, 0, 0u, ra);
                     }
                 }
-                const int64_t r = unit_row(cur);
-#pragma unroll
-                for (int q = 0; q < NQ; q++) {
-                    const double s = butterfly_sum(acc[0][q]);
-                    acc[0][q] = 0.0;
-                    wave_topk_offer_lds(s, r * a.idx_mul + a.idx_add, K, lane, mylists + q * CHIP_MAX_TOPK, thr_s[q], thr_i[q]);
-                }
+                finish_row(cur);
                 cur = more ? nxt : n_units;
                 rowp = nrow;
             }
-#undef CHIP_ROWS2_FMA
-#undef CHIP_ROWS2_ISSUE
-        } else
+        };
+        auto stream_depth1 = [&](auto early_tag) {
+            constexpr bool EARLY = decltype(early_tag)::value;
+            const T *rowp = row[0];
+            while (cur < n_units) {
+                uint32_t nxt_v = 0;
+                if (lane == 0) nxt_v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                int nxt = 0;
+                bool more = false;
+                for (int bb = 0; bb < nb; bb++) {
+                    const int base0 = bb * (CH * U);
+                    const T *ra = rowp;
+                    uint32_t oa = (uint32_t)(bb + 1) * 4096u;
+                    bool ahead = true;
+                    if (bb + 1 == nb) {
+                        nxt = __builtin_amdgcn_readfirstlane((int)nxt_v);
+                        more = nxt < n_units;
+                        ahead = more;
+                        oa = 0u;
+                        if (more) { rowp = uniform_ptr(row_base_uniform<T>(a, unit_row(nxt))); ra = rowp; }
+                    }
+                    if (ahead) {
+                        CHIP_ROWSX_STEP(0, 0, base0, 3, 1, oa, ra); CHIP_ROWSX_STEP(1, 1, base0, 3, 1, oa, ra);
+                        CHIP_ROWSX_STEP(2, 2, base0, 3, 1, oa, ra); CHIP_ROWSX_STEP(3, 3, base0, 3, 1, oa, ra);
+                    } else {
+                        CHIP_ROWSX_STEP(0, 0, base0, 3, 0, 0u, ra); CHIP_ROWSX_STEP(1, 1, base0, 2, 0, 0u, ra);
+                        CHIP_ROWSX_STEP(2, 2, base0, 1, 0, 0u, ra); CHIP_ROWSX_STEP(3, 3, base0, 0, 0, 0u, ra);
+                    }
+                }
+                finish_row(cur);
+                cur = more ? nxt : n_units;
+            }
+        };
+        // (the resident instance runs the product form only: its register budget is the tightest of the three kernels that inline this body)
+        if constexpr (!RESIDENT) {
+            experimental = t.dyn_claim >= 2;
+            if (t.dyn_claim == 2 && (nb & 1) == 0) stream_depth2(std::false_type{});
+            else if (t.dyn_claim == 4 && (nb & 1) == 0) stream_depth2(std::true_type{});
+            else if (t.dyn_claim >= 3) stream_depth1(std::true_type{});
+            else experimental = false;
+        }
+#endif
+        if (!experimental)
         while (cur < n_units) {
             uint32_t nxt_v = 0;                                 // next unit, claimed by lane 0 alone: needed at this row's last batch
             if (lane == 0) nxt_v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -960,6 +1021,10 @@ __device__ __forceinline__ void scan_rows_body(const ScanArgs &a, const RowsPass
             }
             cur = more ? nxt : n_units;
         }
+#ifdef CHIP_SCAN_TUNING_VARIANTS
+#undef CHIP_ROWSX_STEP
+#undef CHIP_ROWSX_ISSUE
+#endif
       }
     } else
     for (int t = 0; t < total; t++) {
