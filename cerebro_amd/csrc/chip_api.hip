@@ -372,7 +372,7 @@ static int resident_tick_enqueue(Ctx *c, int64_t k, int64_t l, const chip_dot_pa
     cmd.seq_ptr = (uint64_t)(uintptr_t)s.seq_dev;
     cmd.seq_val = s.seq_want;
     // rows claimed within the workgroup: beyond cache-sized prefixes, as for launches (29k rows: 92.3 -> 91.7 us; neutral at 10k)
-    cmd.dyn_claim = (c->scan_claim == 1 || (c->scan_claim < 0 && (double)k * c->D * c->elem > c->scan_half_bytes)) ? (uint32_t)c->scan_depth : 0u;
+    cmd.dyn_claim = (c->scan_claim == 1 || (c->scan_claim < 0 && (double)k * c->D * c->elem > c->scan_half_bytes)) ? 1u : 0u;   // (the instance runs the product stream only)
     c->res_pending = cmd;
     resident_write_line(c, cmd);           // (before the launch: an instance must never find the previous one's leave mark in its lines)
     if (launch) {
