@@ -978,7 +978,7 @@ __device__ __forceinline__ void scan_rows_body(const ScanArgs &a, const RowsPass
             experimental = t.dyn_claim >= 2;
             if (t.dyn_claim == 2 && (nb & 1) == 0) stream_depth2(std::false_type{});
             else if (t.dyn_claim == 4 && (nb & 1) == 0) stream_depth2(std::true_type{});
-            else if (t.dyn_claim >= 3) stream_depth1(std::true_type{});
+            else if (t.dyn_claim == 3 || t.dyn_claim == 4) stream_depth1(std::true_type{});
             else experimental = false;
         }
 #endif
