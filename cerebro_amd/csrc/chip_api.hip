@@ -563,6 +563,7 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     c->scan_rows = env_int("CHIP_SCAN_ROWS", 0);
     c->scan_depth = env_int("CHIP_SCAN_DEPTH", 1);      // 1 = the product's claimed stream; 2..4: experimental forms (kernels.hip scan_rows_body)
     if (c->scan_depth < 1 || c->scan_depth > 4) c->scan_depth = 1;
+    { const int st = env_int("CHIP_SCAN_STAGGER", 0); if (st > 0 && st < 4096) c->scan_depth |= st << 8; }   // tuning builds only (kernels.hip)
     c->scan_claim = env_int("CHIP_SCAN_CLAIM", -1);   // -1 = auto (full-occupancy launches of the row-batched kernel), 0 = never, 1 = always
     c->tick_same_stream = env_int("CHIP_TICK_SAME_STREAM", 1) != 0;
     c->scan_short_bpc = env_int("CHIP_SCAN_SHORT_BPC", 1);

@@ -778,6 +778,14 @@ __device__ __forceinline__ void scan_rows_body(const ScanArgs &a, const RowsPass
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
+#ifdef CHIP_SCAN_TUNING_VARIANTS
+    // CHIP_SCAN_STAGGER=n (tuning builds): wave w of a workgroup starts consuming n x 64 x w cycles late -- are the one-workgroup-per-CU
+    // shapes slow (6.6-6.9 TB/s) because their waves run in lockstep?
+    if constexpr (!RESIDENT) {
+        const int st = t.dyn_claim >> 8;
+        for (int i = 0; i < st * wave; i++) __builtin_amdgcn_s_sleep(1);
+    }
+#endif
     if (stamp && lane == 0) stamp[1] = wall_clock64();
     // running top-K lists: LDS behind the queries (this wave's NQ lists are touched by this wave only)
     chip_topk_entry *lists = reinterpret_cast<chip_topk_entry *>(smem + (size_t)NQ * D * sizeof(T));
@@ -975,10 +983,11 @@ __device__ __forceinline__ void scan_rows_body(const ScanArgs &a, const RowsPass
         };
         // (the resident instance runs the product form only: its register budget is the tightest of the three kernels that inline this body)
         if constexpr (!RESIDENT) {
-            experimental = t.dyn_claim >= 2;
-            if (t.dyn_claim == 2 && (nb & 1) == 0) stream_depth2(std::false_type{});
-            else if (t.dyn_claim == 4 && (nb & 1) == 0) stream_depth2(std::true_type{});
-            else if (t.dyn_claim == 3 || t.dyn_claim == 4) stream_depth1(std::true_type{});
+            const int form = t.dyn_claim & 255;
+            experimental = form >= 2;
+            if (form == 2 && (nb & 1) == 0) stream_depth2(std::false_type{});
+            else if (form == 4 && (nb & 1) == 0) stream_depth2(std::true_type{});
+            else if (form == 3 || form == 4) stream_depth1(std::true_type{});
             else experimental = false;
         }
 #endif
