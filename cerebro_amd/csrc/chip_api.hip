@@ -519,6 +519,7 @@ void ctx_destroy(chip_ctx *c)
     if (c->scores_dev) (void)hipFree(c->scores_dev);
     if (c->stamps_dev) (void)hipFree(c->stamps_dev);
     if (c->tickets_dev) (void)hipFree(c->tickets_dev);
+    if (c->pair_ctr_dev) (void)hipFree(c->pair_ctr_dev);
     if (c->seq_host_all) (void)hipHostFree(c->seq_host_all);
     for (Slot &s : c->slots) {
         if (s.done) (void)hipEventDestroy(s.done);
@@ -562,7 +563,7 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     c->scan_variant = env_int("CHIP_SCAN_VARIANT", 0);
     c->scan_rows = env_int("CHIP_SCAN_ROWS", 0);
     c->scan_depth = env_int("CHIP_SCAN_DEPTH", 1);      // 1 = the product's claimed stream; 2..4: experimental forms (kernels.hip scan_rows_body)
-    if (c->scan_depth < 1 || c->scan_depth > 4) c->scan_depth = 1;
+    if (c->scan_depth < 1 || c->scan_depth > 7) c->scan_depth = 1;
     { const int st = env_int("CHIP_SCAN_STAGGER", 0); if (st > 0 && st < 4096) c->scan_depth |= st << 8; }   // tuning builds only (kernels.hip)
     c->scan_claim = env_int("CHIP_SCAN_CLAIM", -1);   // -1 = auto (full-occupancy launches of the row-batched kernel), 0 = never, 1 = always
     c->tick_same_stream = env_int("CHIP_TICK_SAME_STREAM", 1) != 0;
@@ -600,6 +601,8 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     }
     CHIP_HIP(c, hipMalloc(&c->tickets_dev, Ctx::kRing * sizeof(int32_t)));
     CHIP_HIP(c, hipMemset(c->tickets_dev, 0, Ctx::kRing * sizeof(int32_t)));
+    CHIP_HIP(c, hipMalloc(&c->pair_ctr_dev, (size_t)Ctx::kRing * Ctx::kPairCtrs * Ctx::kPairStride * sizeof(uint32_t)));
+    CHIP_HIP(c, hipMemset(c->pair_ctr_dev, 0, (size_t)Ctx::kRing * Ctx::kPairCtrs * Ctx::kPairStride * sizeof(uint32_t)));
     c->tick_fused = env_int("CHIP_TICK_FUSED", 1) != 0;
     c->tick_poll = env_int("CHIP_TICK_POLL", 1) != 0;
     // opt-in: synchronous ticks over cache-sized prefixes go to a scan instance that stays on the chip (chip_internal.h ResidentCmd)
@@ -716,6 +719,8 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
         a.K = 1;
         a.fused_result = res;
         a.fused_ticket = c->tickets_dev + b;
+        // tuning builds, CHIP_SCAN_DEPTH=7 only: rows claimed by PAIRS of workgroups (b, b + grid / 2: the older and the younger workgroup of a CU) from one counter
+        if ((a.dyn_claim & 255) == 7 && (grid & 15) == 0 && grid / 2 <= Ctx::kPairCtrs) a.pair_ctr = c->pair_ctr_dev + (size_t)b * Ctx::kPairCtrs * Ctx::kPairStride;
         a.tick_l = l;
         a.locality = p->locality;
         a.thresh = p->thresh;

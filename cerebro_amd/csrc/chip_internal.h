@@ -34,6 +34,7 @@ struct ScanArgs {
     // decision record itself -- a tick is then ONE launch.  fused_result == nullptr: lists only, K2 follows as a launch of its own.
     chip_tick_result *fused_result = nullptr;
     int32_t *fused_ticket = nullptr;        // arrival counter of this launch's list buffer (0 at launch, reset by the last workgroup)
+    uint32_t *pair_ctr = nullptr;           // [gridDim / 2] row-claim counters shared by workgroups b and b + gridDim / 2 (0 at launch, reset by the last workgroup); nullptr: rows are claimed per workgroup
     unsigned long long *fused_seq = nullptr; // completion word of the tick's slot in pinned host memory: written (system-scope RELEASE) after the
     unsigned long long fused_seq_val = 0;    // record, so that a host that polls it sees the record complete (chip_api.hip tick_collect_slot)
     int64_t tick_l = 0;
@@ -178,6 +179,9 @@ struct Ctx {
     hipEvent_t ev_scan[kRing] = {};             // scan into buffer b finished
     hipEvent_t ev_merged[kRing] = {};           // merge out of buffer b finished
     int32_t *tickets_dev = nullptr;             // [kRing] arrival counters of the fused tick (one per list buffer)
+    uint32_t *pair_ctr_dev = nullptr;           // [kRing][kPairCtrs][kPairStride] row-claim counters of workgroup pairs (pair-claimed stream of the fused tick)
+    static constexpr int kPairCtrs = 256;
+    static constexpr int kPairStride = 32;      // uint32s: every counter has a 128-byte line to itself (the pairs of a launch sit on eight XCDs)
     unsigned long long *seq_host_all = nullptr; // [CHIP_MAX_INFLIGHT] completion words of the slots (pinned)
     unsigned long long tick_seq = 0;            // last value handed out
     bool tick_poll = true;                      // CHIP_TICK_POLL: fused ticks are collected by polling the completion word

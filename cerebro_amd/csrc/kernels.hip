@@ -637,6 +637,10 @@ __device__ __forceinline__ void fused_tick_finish(const ScanArgs &a, const RowsP
         }
     }
     if (xstamp && tid == 0) xstamp[6] = (unsigned long long)wall_clock64();
+    // the workgroup pairs' row-claim counters of this launch's list buffer: back to zero for the launch that reuses it (every workgroup
+    // has claimed its last row before it took the ticket, and this is the workgroup that took the last one)
+    if (a.pair_ctr != nullptr)
+        for (int i = tid; i < (int)(gridDim.x >> 1); i += (int)blockDim.x) __hip_atomic_store(a.pair_ctr + (size_t)i * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (wave != 0) return;
     if (xstamp && tid == 0) xstamp[7] = (unsigned long long)wall_clock64();
@@ -981,11 +985,97 @@ __device__ __forceinline__ void scan_rows_body(const ScanArgs &a, const RowsPass
                 cur = more ? nxt : n_units;
             }
         };
+        //   7: depth 2 with the rows claimed by PAIRS of workgroups -- b and b + gridDim / 2, i.e. (round-robin dispatch) the older and the
+        //      younger workgroup of a CU, on the same XCD -- from ONE counter in device memory: the older workgroup, which the memory path
+        //      prefers, simply takes more rows, so both run dry together.  The claim is a global atomic with return, issued from asm at the
+        //      START of a row into v112 (an asm-owned register depth 2 leaves free) and read two batches later: it sits in the in-order
+        //      vector-memory queue, so the waits of the row's first two batches allow ONE more outstanding operation (vmcnt 8 instead of 7)
+        //      and by the time the third batch is waited for it has returned -- no wait of its own.  Pair unit p -> row: ascending in p
+        //      (round, workgroup b's wpb rows, workgroup b + G/2's wpb rows), so "p names a row" is a prefix property.
+        auto stream_pair2 = [&]() {
+            constexpr bool EARLY = false;
+            const int G = (int)gridDim.x, Hh = G >> 1;
+            const int b1 = (int)blockIdx.x < Hh ? (int)blockIdx.x : (int)blockIdx.x - Hh, b2 = b1 + Hh;
+            const int second = (int)blockIdx.x >= Hh ? 1 : 0;
+            uint32_t *pctr = a.pair_ctr + (size_t)b1 * 32;   // a 128-byte line per pair (Ctx::kPairStride)
+            auto units_of = [&](int b) {
+                const int64_t w0 = (int64_t)b * wpb;
+                if (t.n_rows <= w0) return 0;
+                const int64_t span = t.n_rows - w0, pf = span / tw, rem = span - pf * tw;
+                return (int)(pf * wpb + (rem < wpb ? rem : wpb));
+            };
+            const int n_pair = units_of(b1) + units_of(b2);
+            auto prow = [&](int p) {
+                const int round = p / (2 * wpb), o = p - round * 2 * wpb;
+                return (int64_t)round * tw + (o < wpb ? (int64_t)b1 * wpb + o : (int64_t)b2 * wpb + (o - wpb));
+            };
+            auto finish_prow = [&](int p) {
+                const int64_t r = prow(p);
+#pragma unroll
+                for (int q = 0; q < NQ; q++) {
+                    const double s = butterfly_sum(acc[0][q]);
+                    acc[0][q] = 0.0;
+                    wave_topk_offer_lds(s, r * a.idx_mul + a.idx_add, K, lane, mylists + q * CHIP_MAX_TOPK, thr_s[q], thr_i[q]);
+                }
+            };
+            const uint64_t pc = (uint64_t)(uintptr_t)pctr;
+            const uint32_t one = 1u;
+            int pcur = second * wpb + wave;          // this wave's first pair unit = the row whose first batch is already in flight
+            const T *rowp = row[0], *nrow = row[0];
+            if (pcur < n_pair) {
+                CHIP_ROWSX_ISSUE(4, 0, 4096u, rowp); CHIP_ROWSX_ISSUE(5, 1, 4096u, rowp); CHIP_ROWSX_ISSUE(6, 2, 4096u, rowp); CHIP_ROWSX_ISSUE(7, 3, 4096u, rowp);
+            }
+            while (pcur < n_pair) {
+                // the claim of the NEXT row: lane 0 alone, result in v112 (pre-add value; units 0 .. 2 wpb - 1 are the waves' first rows).
+                // Agent scope (sc1): the counter is reset by the launch's LAST workgroup, which may sit on another XCD -- an atomic resolved
+                // in this XCD's L2 alone would leave a dirty line there for the end-of-kernel write-back to put on top of that reset
+                asm volatile("s_mov_b64 s[72:73], exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add v112, %0, %1, off sc0 sc1\n\ts_mov_b64 exec, s[72:73]"
+                             ::"v"(pc), "v"(one) : "memory", "s72", "s73");
+                int nxt = 0;
+                bool more = false;
+                for (int bb = 0; bb < nb; bb += 2) {
+                    const int base0 = bb * (CH * U), base1 = base0 + CH * U;
+                    const T *ra = rowp;
+                    uint32_t oa = (uint32_t)(bb + 2) * 4096u;
+                    bool ahead = true;
+                    if (bb + 2 == nb) {
+                        // (nb >= 4: the claim was issued two batches ago; the wait the next take would do anyway also covers it)
+                        int got;
+                        asm volatile("s_waitcnt vmcnt(7)\n\tv_readfirstlane_b32 %0, v112" : "=s"(got)::"memory");
+                        nxt = got + 2 * wpb;
+                        more = nxt < n_pair;
+                        ahead = more;
+                        oa = 0u;
+                        if (more) { nrow = uniform_ptr(row_base_uniform<T>(a, prow(nxt))); ra = nrow; }
+                    }
+                    if (bb == 0) {       // the claim is younger than these two batches' loads: one more operation may stay outstanding
+                        CHIP_ROWSX_STEP(0, 0, base0, 8, 1, oa, ra); CHIP_ROWSX_STEP(1, 1, base0, 8, 1, oa, ra);
+                        CHIP_ROWSX_STEP(2, 2, base0, 8, 1, oa, ra); CHIP_ROWSX_STEP(3, 3, base0, 8, 1, oa, ra);
+                        CHIP_ROWSX_STEP(4, 0, base1, 8, 1, oa + 4096u, ra); CHIP_ROWSX_STEP(5, 1, base1, 8, 1, oa + 4096u, ra);
+                        CHIP_ROWSX_STEP(6, 2, base1, 8, 1, oa + 4096u, ra); CHIP_ROWSX_STEP(7, 3, base1, 8, 1, oa + 4096u, ra);
+                    } else if (ahead) {
+                        CHIP_ROWSX_STEP(0, 0, base0, 7, 1, oa, ra); CHIP_ROWSX_STEP(1, 1, base0, 7, 1, oa, ra);
+                        CHIP_ROWSX_STEP(2, 2, base0, 7, 1, oa, ra); CHIP_ROWSX_STEP(3, 3, base0, 7, 1, oa, ra);
+                        CHIP_ROWSX_STEP(4, 0, base1, 7, 1, oa + 4096u, ra); CHIP_ROWSX_STEP(5, 1, base1, 7, 1, oa + 4096u, ra);
+                        CHIP_ROWSX_STEP(6, 2, base1, 7, 1, oa + 4096u, ra); CHIP_ROWSX_STEP(7, 3, base1, 7, 1, oa + 4096u, ra);
+                    } else {
+                        CHIP_ROWSX_STEP(0, 0, base0, 7, 0, 0u, ra); CHIP_ROWSX_STEP(1, 1, base0, 6, 0, 0u, ra);
+                        CHIP_ROWSX_STEP(2, 2, base0, 5, 0, 0u, ra); CHIP_ROWSX_STEP(3, 3, base0, 4, 0, 0u, ra);
+                        CHIP_ROWSX_STEP(4, 0, base1, 3, 0, 0u, ra); CHIP_ROWSX_STEP(5, 1, base1, 2, 0, 0u, ra);
+                        CHIP_ROWSX_STEP(6, 2, base1, 1, 0, 0u, ra); CHIP_ROWSX_STEP(7, 3, base1, 0, 0, 0u, ra);
+                    }
+                }
+                finish_prow(pcur);
+                pcur = more ? nxt : n_pair;
+                rowp = nrow;
+            }
+        };
         // (the resident instance runs the product form only: its register budget is the tightest of the three kernels that inline this body)
         if constexpr (!RESIDENT) {
             const int form = t.dyn_claim & 255;
             experimental = form >= 2;
-            if (form == 2 && (nb & 1) == 0) stream_depth2(std::false_type{});
+            if (form == 7 && (nb & 1) == 0 && nb >= 4 && a.pair_ctr != nullptr) stream_pair2();
+            else if (form == 2 && (nb & 1) == 0) stream_depth2(std::false_type{});
             else if (form == 4 && (nb & 1) == 0) stream_depth2(std::true_type{});
             else if (form == 3 || form == 4) stream_depth1(std::true_type{});
             else experimental = false;
