@@ -42,6 +42,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290
 READ_CEILING_GBS = 7090.0  # best PURE-READ kernel in the scan's own access shape and occupancy (scripts/probes/hbm_read_probe.hip,
 #                            profiles/r02_hbm_read_probe.txt; 7140 in any shape) -- context for roofline.frac, never its denominator
 SEED = 20190412
+UNIT_DATA = True     # rows of the synthetic DBs are unit-L2 vectors (chip_db_append_synthetic_unit); --data plain: round 1-5's generator
 
 
 TICK_WINDOW = 1000   # distinct tick positions; longer runs cycle through them (keeps sharded ticks inside the replicated ring)
@@ -77,7 +78,7 @@ def cpu_baseline(sample_cols: int, budget_s: float, kind: str = "eigen"):
     Returns columns/s, passes, seconds."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_lib  # checker/baseline only -- never on the product path
-    M = oracle_lib.synth_rows(SEED, range(sample_cols + 3), D).astype(np.float64)
+    M = oracle_lib.synth_rows(SEED, range(sample_cols + 3), D, unit=UNIT_DATA).astype(np.float64)
     v, vm, vmm = M[sample_cols + 2].copy(), M[sample_cols + 1].copy(), M[sample_cols].copy()
     scratch = (np.empty(sample_cols), np.empty(sample_cols), np.empty(sample_cols))
     if kind == "eigen":
@@ -155,7 +156,7 @@ def cpu_baseline_all_cores(sample_cols: int, budget_s: float):
     reference would get from Eigen's OpenMP GEMV, which it does not enable).  Reported next to `cpu_baseline`, never as it."""
     import oracle_lib  # baseline only
     nthreads = usable_cpus()
-    src = oracle_lib.synth_rows(SEED, range(2048), D).astype(np.float64)
+    src = oracle_lib.synth_rows(SEED, range(2048), D, unit=UNIT_DATA).astype(np.float64)
     M = oracle_lib.tile_columns_omp(sample_cols, src, nthreads)           # first touch by the scanning threads
     v, vm, vmm = src[5].copy(), src[6].copy(), src[7].copy()
     scratch = (np.empty(sample_cols), np.empty(sample_cols), np.empty(sample_cols))
@@ -544,7 +545,7 @@ def shape_leg(rows, dim, storage, inflight, n_ticks=240):
     ls, plants, expect = plan_ticks(rows, 20 + n_ticks)
     params = capi.default_dot_params()
     with capi.Chip(dim, capacity_hint=ls[-1], storage=(None if storage == "f32" else "f64")) as c:
-        c.append_synthetic(ls[-1], SEED, plants)
+        c.append_synthetic(ls[-1], SEED, plants, unit=UNIT_DATA)
         c.synchronize()
         leg = size_leg(c, rows, (ls, expect), params, inflight, n_ticks=n_ticks, dim=dim, elem_bytes=8 if storage == "f64" else 4)
     leg["D"] = dim
@@ -590,7 +591,7 @@ def resident_leg(rows, n_ticks=400, warm=40):
             os.environ["CHIP_TICK_RESIDENT"] = "1"
         try:
             with capi.Chip(D, capacity_hint=rows + 500) as c:
-                c.append_synthetic(rows + 400, 777, [])
+                c.append_synthetic(rows + 400, 777, [], unit=UNIT_DATA)
                 recs, lat = [], []
                 for l in ls:
                     t1 = time.perf_counter()
@@ -713,6 +714,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=16)
     ap.add_argument("--storage", choices=["f32", "f64"], default="f32",
                     help="row type of the DB: f32 (BASELINE: synthetic fp32 descriptors) or f64 (double rows, e.g. ReljaNetVLAD)")
+    ap.add_argument("--data", choices=["unit", "plain"], default="unit",
+                    help="synthetic rows: unit = exactly unit-L2 (SURVEY 8d, the default); plain = integers x one constant (rounds 1-5; norm spread 1.1 %% rms)")
     ap.add_argument("--no-pnp", action="store_true", help="skip the auxiliary PnP-RANSAC leg (config 3)")
     ap.add_argument("--no-batch", action="store_true", help="skip the auxiliary many-query MFMA leg (row N4)")
     ap.add_argument("--no-sizes", action="store_true", help="skip the 10k / 100k legs (BASELINE configs 2, 3)")
@@ -732,6 +735,8 @@ def main():
     ap.add_argument("--paced-ticks", type=int, default=40,
                     help="N = 1: synchronous ticks at the reference's 10 Hz cadence per mode and position (0 = skip; each costs 0.1 s)")
     args = ap.parse_args()
+    global UNIT_DATA
+    UNIT_DATA = args.data == "unit"
 
     # The paced (10 Hz) tick leg runs FIRST, in a process of its own, before this process has touched the GPU: round 5's record showed
     # 69.6 us for a launched tick at 10 Hz where the standalone tool on an otherwise idle box reads 52 us, and blamed the bench
@@ -923,7 +928,7 @@ def main():
 
     def fill(c):
         t = time.perf_counter()
-        c.append_synthetic(total_rows, SEED, plants)
+        c.append_synthetic(total_rows, SEED, plants, unit=UNIT_DATA)
         return time.perf_counter() - t
 
     t_fill = fill(chip)
@@ -1070,8 +1075,11 @@ def main():
             "scaling": "weak" if replicated else "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic (on-device integer-domain generator, seed 20190412, planted revisits; rows are unit-norm in expectation, "
-                    "norm spread ~1.1 % rms at D=4096: Irwin-Hall integers x one constant, so that CPU and GPU generate identical bits)",
+            "data": ("synthetic, SURVEY 8d: unit-L2 rows (on-device generator, seed 20190412: Irwin-Hall integers, sum of squares exact in "
+                     "integers, element = (float)(v / sqrt(S)) -- CPU oracle and GPU generate identical bits; | |row| - 1 | < 2e-7), planted "
+                     "revisits = unit(5 src + noise), cos 0.98" if UNIT_DATA else
+                     "synthetic (on-device integer-domain generator, seed 20190412, planted revisits; rows are unit-norm in expectation, "
+                     "norm spread ~1.1 % rms at D=4096: Irwin-Hall integers x one constant, so that CPU and GPU generate identical bits)"),
             # <= CONFIG_KEY_CAP keys once finalize_record has put the legs' headline scalars in front (N = 1: 8 keys here; N > 1: no legs)
             "config": ({"workload": f"{D}-D fp32 descriptors x {args.rows} keyframe DB, 3 queries/tick, top-{TOPK} + accept rule",
                         "db_rows": args.rows, "D": D, "queries_per_tick": 3, "topk": TOPK,

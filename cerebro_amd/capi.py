@@ -130,6 +130,7 @@ _SIGS = {
     "chip_db_read_rows_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
     "chip_db_read_rows_f64": (C.c_int, [_P, _P, C.c_int64, _P]),
     "chip_db_append_synthetic": (C.c_int, [_P, C.c_int64, C.c_uint64, _P, _P, _P, C.c_int64]),
+    "chip_db_append_synthetic_unit": (C.c_int, [_P, C.c_int64, C.c_uint64, _P, _P, _P, C.c_int64]),
     "chip_query_rows": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
     "chip_query_vectors_f32": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
     "chip_query_vectors_f64": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, _P, _P]),
@@ -344,16 +345,19 @@ class Chip:
         self._chk(self.lib.chip_db_append_f32(self.h, _ptr(desc), desc.shape[0], C.byref(first)), "chip_db_append_f32")
         return first.value
 
-    def append_synthetic(self, n: int, seed: int, plants=()):
+    def append_synthetic(self, n: int, seed: int, plants=(), unit: bool = False):
+        """unit=True: the rows normalised to unit L2 norm (chip_db_append_synthetic_unit, SURVEY.md 8d's data)."""
         plants = sorted(plants)
+        name = "chip_db_append_synthetic_unit" if unit else "chip_db_append_synthetic"
+        fn = getattr(self.lib, name)
         if plants:
             dst = np.array([p[0] for p in plants], dtype=np.int64)
             src = np.array([p[1] for p in plants], dtype=np.int64)
             kind = np.array([p[2] for p in plants], dtype=np.int32)
-            st = self.lib.chip_db_append_synthetic(self.h, n, seed, _ptr(dst), _ptr(src), _ptr(kind), len(plants))
+            st = fn(self.h, n, seed, _ptr(dst), _ptr(src), _ptr(kind), len(plants))
         else:
-            st = self.lib.chip_db_append_synthetic(self.h, n, seed, None, None, None, 0)
-        self._chk(st, "chip_db_append_synthetic")
+            st = fn(self.h, n, seed, None, None, None, 0)
+        self._chk(st, name)
 
     def size(self) -> int:
         return int(self.lib.chip_db_size(self.h))

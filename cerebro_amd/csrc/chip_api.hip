@@ -1113,7 +1113,7 @@ int ctx_append(Ctx *c, const void *desc, int src_elem, int64_t n, uint32_t flags
     return append_ring_publish(c, desc, src_elem, first, n, (bad & 1u) != 0);
 }
 
-int synth_generate(Ctx *c, int64_t first, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant)
+int synth_generate(Ctx *c, int64_t first, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant, int unit)
 {
     int64_t *pd = nullptr, *ps = nullptr;
     int32_t *pk = nullptr;
@@ -1126,7 +1126,7 @@ int synth_generate(Ctx *c, int64_t first, int64_t n, uint64_t seed, const int64_
         CHIP_HIP(c, hipMemcpyAsync(pk, plant_kind, n_plant * sizeof(int32_t), hipMemcpyHostToDevice, c->s_append));
     }
     int rc = ring_begin_append(c, first + n);   // same ordering against in-flight scans as ctx_append
-    if (rc == CHIP_OK) rc = launch_synth(c, c->s_append, first, n, seed, pd, ps, pk, n_plant);
+    if (rc == CHIP_OK) rc = launch_synth(c, c->s_append, first, n, seed, pd, ps, pk, n_plant, unit);
     hipError_t e = hipStreamSynchronize(c->s_append);
     if (pd) (void)hipFree(pd);
     if (ps) (void)hipFree(ps);
@@ -1146,7 +1146,7 @@ static int check_plants(int64_t first, int64_t n, const int64_t *plant_dst, cons
     return CHIP_OK;
 }
 
-int ctx_append_synthetic(Ctx *c, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant)
+int ctx_append_synthetic(Ctx *c, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant, int unit)
 {
     if (!c || n < 0 || n_plant < 0 || (n_plant > 0 && (!plant_dst || !plant_src || !plant_kind))) return CHIP_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> alk(c->append_mu);
@@ -1157,7 +1157,7 @@ int ctx_append_synthetic(Ctx *c, int64_t n, uint64_t seed, const int64_t *plant_
     if (n == 0) return CHIP_OK;
     rc = append_reserve(c, first, n);
     if (rc != CHIP_OK) return rc;
-    rc = synth_generate(c, first, n, seed, plant_dst, plant_src, plant_kind, n_plant);
+    rc = synth_generate(c, first, n, seed, plant_dst, plant_src, plant_kind, n_plant, unit);
     if (rc != CHIP_OK) return rc;
     append_publish(c, first + n, false, n);
     return CHIP_OK;
@@ -1382,8 +1382,16 @@ int chip_db_append_synthetic(chip_ctx *c, int64_t n, uint64_t seed,
                              const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant)
 {
     if (!c) return CHIP_ERR_INVALID_ARG;
-    return c->group ? group_append_synthetic(c, n, seed, plant_dst, plant_src, plant_kind, n_plant)
-                    : ctx_append_synthetic(c, n, seed, plant_dst, plant_src, plant_kind, n_plant);
+    return c->group ? group_append_synthetic(c, n, seed, plant_dst, plant_src, plant_kind, n_plant, 0)
+                    : ctx_append_synthetic(c, n, seed, plant_dst, plant_src, plant_kind, n_plant, 0);
+}
+
+int chip_db_append_synthetic_unit(chip_ctx *c, int64_t n, uint64_t seed,
+                                  const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant)
+{
+    if (!c) return CHIP_ERR_INVALID_ARG;
+    return c->group ? group_append_synthetic(c, n, seed, plant_dst, plant_src, plant_kind, n_plant, 1)
+                    : ctx_append_synthetic(c, n, seed, plant_dst, plant_src, plant_kind, n_plant, 1);
 }
 
 // ------------------------------------------------------------------------------------------------ queries

@@ -100,7 +100,7 @@ int launch_scores(Ctx *c, hipStream_t s, const ScanArgs &a, double *out_dev);   
 int launch_store_rows(Ctx *c, hipStream_t s, const void *src, int src_elem, int64_t n, int64_t first_global, uint32_t *flags_dev, bool write_ring,
                       int64_t row_stride = 1);
 int launch_synth(Ctx *c, hipStream_t s, int64_t first_global, int64_t n, uint64_t seed,
-                 const int64_t *plant_dst_dev, const int64_t *plant_src_dev, const int32_t *plant_kind_dev, int64_t n_plant);
+                 const int64_t *plant_dst_dev, const int64_t *plant_src_dev, const int32_t *plant_kind_dev, int64_t n_plant, int unit);
 
 struct Slot {
     hipEvent_t done = nullptr;
@@ -308,10 +308,10 @@ int append_store_db(Ctx *c, const void *desc, int src_elem, int64_t first, int64
 bool append_can_switch_to_double(const Ctx *c, int64_t first);
 int append_switch_to_double(Ctx *c, int64_t n);
 int append_ring_publish(Ctx *c, const void *desc, int src_elem, int64_t first, int64_t n, bool lossy);
-int synth_generate(Ctx *c, int64_t first, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant);
+int synth_generate(Ctx *c, int64_t first, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant, int unit);
 void append_publish(Ctx *c, int64_t new_total, bool lossy, int64_t n);
 int64_t published_rows(const Ctx *c);
-int ctx_append_synthetic(Ctx *c, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant);
+int ctx_append_synthetic(Ctx *c, int64_t n, uint64_t seed, const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant, int unit);
 int ctx_read_row(Ctx *c, int64_t g, int64_t total, void *out);          // one row, storage type, async on s_query
 int query_row_ptrs(Ctx *c, const int64_t *rows, int nq, int64_t n_global, const void **q);
 int upload_query_vectors(Ctx *c, const void *queries, int src_elem, int nq, const void **q);   // -> qvec_dev (on s_scan)
@@ -354,7 +354,7 @@ int xchg_query(Ctx *c, int64_t k, const void *const *q, int nq, int K, double *s
 int xchg_fetch_rows(Ctx *c, const int64_t *rows, int nq, int64_t n_local_published, const void **q, bool *fail_local);
 // group ctx (chip_create_multi): every entry point of the header that makes sense on a group
 int group_append(Ctx *gc, const void *desc, int src_elem, int64_t n, uint32_t flags, int64_t *first_index);
-int group_append_synthetic(Ctx *gc, int64_t n, uint64_t seed, const int64_t *pd, const int64_t *ps, const int32_t *pk, int64_t n_plant);
+int group_append_synthetic(Ctx *gc, int64_t n, uint64_t seed, const int64_t *pd, const int64_t *ps, const int32_t *pk, int64_t n_plant, int unit);
 int group_read_rows(Ctx *gc, const int64_t *rows, int64_t n, void *out, int out_elem);
 int group_tick_enqueue(Ctx *gc, int64_t l, const chip_dot_params *p, int32_t slot);
 int group_tick_collect(Ctx *gc, int32_t slot, chip_tick_result *out);

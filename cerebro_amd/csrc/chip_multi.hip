@@ -507,7 +507,7 @@ int group_append(Ctx *gc, const void *desc, int src_elem, int64_t n, uint32_t fl
     return CHIP_OK;
 }
 
-int group_append_synthetic(Ctx *gc, int64_t n, uint64_t seed, const int64_t *pd, const int64_t *ps, const int32_t *pk, int64_t n_plant)
+int group_append_synthetic(Ctx *gc, int64_t n, uint64_t seed, const int64_t *pd, const int64_t *ps, const int32_t *pk, int64_t n_plant, int unit)
 {
     Group *G = gc->group;
     std::lock_guard<std::mutex> alk(gc->append_mu);
@@ -529,7 +529,7 @@ int group_append_synthetic(Ctx *gc, int64_t n, uint64_t seed, const int64_t *pd,
     int rc = run_all(G, [&](int g) { return on_dev(g, [&](Ctx *c) { return append_reserve(c, first, n); }); });
     if (rc != CHIP_OK) return rc;
     // the generator writes the rings as it goes: from here on a failure on one device leaves the others ahead of it
-    rc = run_all(G, [&](int g) { return on_dev(g, [&](Ctx *c) { return synth_generate(c, first, n, seed, pd, ps, pk, n_plant); }); });
+    rc = run_all(G, [&](int g) { return on_dev(g, [&](Ctx *c) { return synth_generate(c, first, n, seed, pd, ps, pk, n_plant, unit); }); });
     if (rc != CHIP_OK) return group_break(G, rc);
     for (chip_ctx *c : G->subs) append_publish(c, first + n, false, n);
     mirror_state(gc);

@@ -1785,8 +1785,55 @@ __global__ __launch_bounds__(256) void synth_rows(SynthArgs a)
     }
 }
 
+// Unit-L2 form of the generator (spec: oracle/dot_scan.c orc_synth_row_unit_f32; SURVEY.md 8d "rows = unit-L2-norm"): the row's integers
+// v_e as above, S = sum v_e^2 EXACTLY (64-bit integers: any summation order gives the same S), inv = 1 / sqrt((double)S) (two correctly
+// rounded fp64 operations), element = (float)((double)v_e * inv) -- one correctly rounded multiply, one conversion.  So the rows are
+// unit vectors to fp32 rounding (| |row| - 1 | ~ 1e-8) AND bit-identical to the CPU generator.  One workgroup per row.
+template <typename T>
+__global__ __launch_bounds__(256) void synth_rows_unit(SynthArgs a)
+{
+    __shared__ unsigned long long part[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per_row = a.st.D / 4;
+    for (int64_t r = blockIdx.x; r < a.st.n; r += gridDim.x) {
+        const int64_t g = a.st.first_global + r;
+        int32_t kind = 0;
+        int64_t src = -1;
+        int64_t lo = 0, hi = a.n_plant;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (a.plant_dst[mid] < g) lo = mid + 1; else hi = mid;
+        }
+        if (lo < a.n_plant && a.plant_dst[lo] == g) { kind = a.plant_kind[lo]; src = a.plant_src[lo]; }
+        const uint64_t key = synth_rowkey(a.seed, g);
+        const uint64_t skey = kind ? synth_rowkey(a.seed, src) : 0;
+        auto value = [&](int e) -> int64_t {
+            if (kind == 0) return (int64_t)synth_from_key(key, e);
+            if (kind == 2) return (int64_t)synth_from_key(skey, e);
+            return 5 * (int64_t)synth_from_key(skey, e) + (int64_t)synth_from_key(key, e);
+        };
+        unsigned long long ss = 0;   // |v| <= 6 * 131070: v^2 < 2^40, a row of 8192 of them < 2^53
+        for (int ch = tid; ch < per_row; ch += 256)
+#pragma unroll
+            for (int c = 0; c < 4; c++) { const int64_t v = value(4 * ch + c); ss += (unsigned long long)(v * v); }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+        __syncthreads();   // (part[] of the previous row has been read by everybody)
+        if (lane == 0) part[wave] = ss;
+        __syncthreads();
+        const unsigned long long S = part[0] + part[1] + part[2] + part[3];
+        const double inv = S ? 1.0 / sqrt((double)S) : 0.0;
+        for (int ch = tid; ch < per_row; ch += 256) {
+            T v[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[c] = (T)(float)((double)value(4 * ch + c) * inv);
+            store_row4<T>(a.st, g, 4 * ch, v);
+        }
+    }
+}
+
 int launch_synth(Ctx *c, hipStream_t s, int64_t first_global, int64_t n, uint64_t seed,
-                 const int64_t *plant_dst_dev, const int64_t *plant_src_dev, const int32_t *plant_kind_dev, int64_t n_plant)
+                 const int64_t *plant_dst_dev, const int64_t *plant_src_dev, const int32_t *plant_kind_dev, int64_t n_plant, int unit)
 {
     SynthArgs a;
     a.st = make_store_args(c, first_global, n, nullptr);
@@ -1798,7 +1845,11 @@ int launch_synth(Ctx *c, hipStream_t s, int64_t first_global, int64_t n, uint64_
     a.plant_src = plant_src_dev;
     a.plant_kind = plant_kind_dev;
     a.n_plant = n_plant;
-    if (c->elem == 8) hipLaunchKernelGGL(synth_rows<double>, dim3(grid_for_elems(c, n * (c->D / 4))), dim3(256), 0, s, a);
+    if (unit) {
+        const int grid = (int)(n < (int64_t)c->n_cus * 32 ? n : (int64_t)c->n_cus * 32);
+        if (c->elem == 8) hipLaunchKernelGGL(synth_rows_unit<double>, dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(synth_rows_unit<float>, dim3(grid), dim3(256), 0, s, a);
+    } else if (c->elem == 8) hipLaunchKernelGGL(synth_rows<double>, dim3(grid_for_elems(c, n * (c->D / 4))), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(synth_rows<float>, dim3(grid_for_elems(c, n * (c->D / 4))), dim3(256), 0, s, a);
     CHIP_HIP(c, hipGetLastError());
     return CHIP_OK;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CHIP_ABI_VERSION 6
+#define CHIP_ABI_VERSION 7
 
 /* ------------------------------------------------------------------------------------------ status codes */
 enum {
@@ -166,6 +166,12 @@ int chip_db_read_rows_f64(chip_ctx *ctx, const int64_t *rows, int64_t n, double 
  * kind 1 = noisy copy of src (cos ~ 0.98), kind 2 = exact duplicate of src.                            */
 int chip_db_append_synthetic(chip_ctx *ctx, int64_t n, uint64_t seed,
                              const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant);
+/* Same rows normalised to UNIT L2 norm (ABI 7; SURVEY.md 8d: "rows = unit-L2-norm", what NetVLAD's last layer emits): the row's integers
+ * v_e, S = sum v_e^2 exactly in 64-bit integers, element = (float)((double)v_e * (1 / sqrt((double)S))) -- every floating-point step one
+ * correctly rounded operation, so the device rows equal oracle/dot_scan.c orc_synth_row_unit_f32 bit for bit.  Planted rows: kind 1 is the
+ * unit vector along 5 src + own (cos ~ 0.98 with src), kind 2 the unit vector of src.  bench.py's headline database is made by this call. */
+int chip_db_append_synthetic_unit(chip_ctx *ctx, int64_t n, uint64_t seed,
+                                  const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant);
 
 /* ------------------------------------------------------------------------------------------ scan + top-k
  * Replaces  u = v.transpose() * M.leftCols(k); maxCoeff(); last-index argmax  (src/Cerebro.cpp:1026-1043)

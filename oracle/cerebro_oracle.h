@@ -33,6 +33,8 @@ float    orc_synth_scale(int32_t D);                                 /* (float)(
 float    orc_synth_scale_planted(int32_t D);                         /* (float)(1/sqrt(D*var*26))               */
 /* kind: 0 = plain row, 1 = noisy copy of src (5*x_src + x_noise), 2 = exact duplicate of src */
 void     orc_synth_row_f32(uint64_t seed, int64_t row, int32_t D, int32_t kind, int64_t src, float *out);
+/* the same row normalised to unit L2 norm: S = sum v^2 in integers, element = (float)((double)v * (1 / sqrt((double)S))) */
+void     orc_synth_row_unit_f32(uint64_t seed, int64_t row, int32_t D, int32_t kind, int64_t src, float *out);
 
 /* ------------------------------------------------------------------ dot products */
 /* Fixed summation tree of SURVEY.md Appendix B (the device kernel uses the same tree):
@@ -65,6 +67,10 @@ void     orc_scan_topk_synth(uint64_t seed, int64_t k, int32_t D,
                              const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant,
                              const float *queries, int32_t nq, int32_t K,
                              double *out_scores, int64_t *out_idx, int32_t nthreads);
+void     orc_scan_topk_synth_unit(uint64_t seed, int64_t k, int32_t D,   /* ... over orc_synth_row_unit_f32 rows */
+                                  const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant,
+                                  const float *queries, int32_t nq, int32_t K,
+                                  double *out_scores, int64_t *out_idx, int32_t nthreads);
 
 /* ------------------------------------------------------------------ the tick (Cerebro.cpp:956-1100) */
 typedef struct {

@@ -56,6 +56,26 @@ void orc_synth_row_f32(uint64_t seed, int64_t row, int32_t D, int32_t kind, int6
     }
 }
 
+/* Unit-L2 form ("rows = unit-L2-norm", the NetVLAD layer's own normalisation -- scripts/predict_utils.py:59-61 of the
+ * reference): the same integers v_e, S = sum v_e^2 exactly (|v| <= 6 * 131070, D <= 8192: S < 2^53), inv = 1 / sqrt((double)S) -- two
+ * correctly rounded operations -- and element = (float)((double)v_e * inv).  Any IEEE machine produces the same bits; the device
+ * generator (kernels.hip synth_rows_unit) sums the squares in another order, which integers do not notice. */
+void orc_synth_row_unit_f32(uint64_t seed, int64_t row, int32_t D, int32_t kind, int64_t src, float *out)
+{
+    const uint64_t key = synth_rowkey(seed, row);
+    const uint64_t skey = kind ? synth_rowkey(seed, src) : 0;
+    uint64_t S = 0;
+    for (int32_t e = 0; e < D; e++) {
+        const int64_t v = kind == 0 ? synth_from_key(key, e) : kind == 2 ? synth_from_key(skey, e) : 5 * (int64_t)synth_from_key(skey, e) + synth_from_key(key, e);
+        S += (uint64_t)(v * v);
+    }
+    const double inv = S ? 1.0 / sqrt((double)S) : 0.0;
+    for (int32_t e = 0; e < D; e++) {
+        const int64_t v = kind == 0 ? synth_from_key(key, e) : kind == 2 ? synth_from_key(skey, e) : 5 * (int64_t)synth_from_key(skey, e) + synth_from_key(key, e);
+        out[e] = (float)((double)v * inv);
+    }
+}
+
 /* ---------------------------------------------------------------- dot products */
 double orc_dot_tree_f32(const float *q, const float *row, int32_t D)
 {
@@ -153,10 +173,31 @@ void orc_scan_topk_fmaf_f32(const float *db, int64_t k, int32_t D, const float *
     }
 }
 
+static void scan_topk_synth_impl(uint64_t seed, int64_t k, int32_t D,
+                                 const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant,
+                                 const float *queries, int32_t nq, int32_t K,
+                                 double *out_scores, int64_t *out_idx, int32_t nthreads, int unit);
+
 void orc_scan_topk_synth(uint64_t seed, int64_t k, int32_t D,
                          const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant,
                          const float *queries, int32_t nq, int32_t K,
                          double *out_scores, int64_t *out_idx, int32_t nthreads)
+{
+    scan_topk_synth_impl(seed, k, D, plant_dst, plant_src, plant_kind, n_plant, queries, nq, K, out_scores, out_idx, nthreads, 0);
+}
+
+void orc_scan_topk_synth_unit(uint64_t seed, int64_t k, int32_t D,
+                              const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant,
+                              const float *queries, int32_t nq, int32_t K,
+                              double *out_scores, int64_t *out_idx, int32_t nthreads)
+{
+    scan_topk_synth_impl(seed, k, D, plant_dst, plant_src, plant_kind, n_plant, queries, nq, K, out_scores, out_idx, nthreads, 1);
+}
+
+static void scan_topk_synth_impl(uint64_t seed, int64_t k, int32_t D,
+                                 const int64_t *plant_dst, const int64_t *plant_src, const int32_t *plant_kind, int64_t n_plant,
+                                 const float *queries, int32_t nq, int32_t K,
+                                 double *out_scores, int64_t *out_idx, int32_t nthreads, int unit)
 {
     if (nthreads <= 0) nthreads = 1;
     double *tsc = (double *)malloc(sizeof(double) * (size_t)nthreads * nq * K);
@@ -179,7 +220,8 @@ void orc_scan_topk_synth(uint64_t seed, int64_t k, int32_t D,
         for (int64_t i = lo; i < hi; i++) {
             int32_t kind = 0; int64_t src = -1;
             if (pp < n_plant && plant_dst[pp] == i) { kind = plant_kind[pp]; src = plant_src[pp]; pp++; }
-            orc_synth_row_f32(seed, i, D, kind, src, row);
+            if (unit) orc_synth_row_unit_f32(seed, i, D, kind, src, row);
+            else orc_synth_row_f32(seed, i, D, kind, src, row);
             for (int32_t q = 0; q < nq; q++)
                 topk_push(sc + (size_t)q * K, ix + (size_t)q * K, K, orc_dot_tree_f32(queries + (size_t)q * D, row, D), i);
         }

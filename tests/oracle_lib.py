@@ -56,6 +56,8 @@ def load():
     lib.orc_synth_scale_planted.argtypes = [C.c_int32]
     lib.orc_synth_row_f32.restype = None
     lib.orc_synth_row_f32.argtypes = [C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, V]
+    lib.orc_synth_row_unit_f32.restype = None
+    lib.orc_synth_row_unit_f32.argtypes = [C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, V]
     lib.orc_dot_tree_f32.restype = C.c_double
     lib.orc_dot_tree_f32.argtypes = [V, V, C.c_int32]
     lib.orc_dot_tree_f64.restype = C.c_double
@@ -78,6 +80,8 @@ def load():
     lib.orc_scan_topk_synth.restype = None
     lib.orc_scan_topk_synth.argtypes = [C.c_uint64, C.c_int64, C.c_int32, V, V, V, C.c_int64, V, C.c_int32, C.c_int32,
                                         V, V, C.c_int32]
+    lib.orc_scan_topk_synth_unit.restype = None
+    lib.orc_scan_topk_synth_unit.argtypes = lib.orc_scan_topk_synth.argtypes
     lib.orc_dot_params_default.restype = None
     lib.orc_dot_params_default.argtypes = [C.POINTER(OrcDotParams)]
     lib.orc_loop_tick_f32.restype = None
@@ -90,15 +94,16 @@ def load():
 
 
 # ---------------------------------------------------------------- convenience wrappers
-def synth_rows(seed: int, rows, D: int, plants=()) -> np.ndarray:
-    """rows: iterable of global row ids; plants: iterable of (dst, src, kind)."""
+def synth_rows(seed: int, rows, D: int, plants=(), unit: bool = False) -> np.ndarray:
+    """rows: iterable of global row ids; plants: iterable of (dst, src, kind); unit: the unit-L2 form of the generator."""
     lib = load()
     pm = {int(d): (int(s), int(k)) for d, s, k in plants}
     rows = list(rows)
     out = np.empty((len(rows), D), dtype=np.float32)
+    gen = lib.orc_synth_row_unit_f32 if unit else lib.orc_synth_row_f32
     for i, r in enumerate(rows):
         src, kind = pm.get(int(r), (-1, 0))
-        lib.orc_synth_row_f32(seed, int(r), D, kind, src, _p(out[i]))
+        gen(seed, int(r), D, kind, src, _p(out[i]))
     return out
 
 
@@ -129,7 +134,7 @@ def scan_topk_fmaf(db: np.ndarray, k: int, queries: np.ndarray, K: int):
     return sc, ix
 
 
-def scan_topk_synth(seed: int, k: int, D: int, queries: np.ndarray, K: int, plants=(), nthreads: int = 1):
+def scan_topk_synth(seed: int, k: int, D: int, queries: np.ndarray, K: int, plants=(), nthreads: int = 1, unit: bool = False):
     queries = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, D)
     nq = queries.shape[0]
     plants = sorted(plants)
@@ -138,8 +143,8 @@ def scan_topk_synth(seed: int, k: int, D: int, queries: np.ndarray, K: int, plan
     kind = np.array([p[2] for p in plants], dtype=np.int32)
     sc = np.empty((nq, K), dtype=np.float64)
     ix = np.empty((nq, K), dtype=np.int64)
-    load().orc_scan_topk_synth(seed, k, D, _p(dst), _p(src), _p(kind), len(plants), _p(queries), nq, K, _p(sc), _p(ix),
-                               nthreads)
+    fn = load().orc_scan_topk_synth_unit if unit else load().orc_scan_topk_synth
+    fn(seed, k, D, _p(dst), _p(src), _p(kind), len(plants), _p(queries), nq, K, _p(sc), _p(ix), nthreads)
     return sc, ix
 
 

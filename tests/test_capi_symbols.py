@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(chip_lib):
 
 
 def test_abi_version_and_defaults(chip_lib):
-    assert chip_lib.chip_abi_version() == 6
+    assert chip_lib.chip_abi_version() == 7
     p = capi.default_dot_params()
     assert (p.locality, p.lag, p.min_new, p.min_k) == (12, 50, 3, 5)        # Cerebro.cpp:912-914,962,1022
     assert p.thresh == 0.85000002384185791015625                           # (double)(float)0.85

@@ -83,6 +83,51 @@ def test_topk_order_and_padding():
     assert list(ix[0]) == [-1, -1]
 
 
+def test_unit_generator_is_unit_l2_and_matches_its_definition(oracle):
+    """SURVEY.md 8d's data: unit-L2 rows.  The definition restated in numpy (exact integer sum of squares, two correctly rounded fp64
+    operations, one multiply, one conversion) gives the oracle's bits; norms are 1 to fp32 rounding; planted rows keep their angles."""
+    D, seed = 4096, 20190412
+    plants = [(100, 3, 1), (101, 3, 2)]
+    rows = [0, 3, 17, 100, 101, 999_999]
+    got = oracle_lib.synth_rows(seed, rows, D, plants, unit=True)
+    pm = {d: (s, k) for d, s, k in plants}
+    for out, r in zip(got, rows):
+        src, kind = pm.get(r, (-1, 0))
+        own = np.array([oracle.orc_synth_i32(seed, r, e) for e in range(D)], dtype=np.int64)
+        if kind:
+            sv = np.array([oracle.orc_synth_i32(seed, src, e) for e in range(D)], dtype=np.int64)
+            v = sv if kind == 2 else 5 * sv + own
+        else:
+            v = own
+        S = int((v * v).sum())
+        assert S < 2**53
+        inv = 1.0 / math.sqrt(float(S))
+        want = (v.astype(np.float64) * inv).astype(np.float32)
+        assert out.tobytes() == want.tobytes()
+    norms = np.linalg.norm(got.astype(np.float64), axis=1)
+    assert np.all(np.abs(norms - 1.0) < 2e-7)            # unit vectors to fp32 rounding (the plain generator: ~1 % rms spread)
+    g = got.astype(np.float64) @ got.astype(np.float64).T
+    assert 0.975 < g[3, 1] < 0.985                       # row 100 = unit(5 x3 + x100): cos = 5 / sqrt(26) = 0.9806
+    assert got[4].tobytes() == got[1].tobytes()          # kind 2: the unit vector of src, bit for bit
+    assert abs(g[0, 2]) < 0.1                            # unrelated rows: N(0, 1/64)
+    # the direction is the plain generator's: same integers, another scale
+    plain = oracle_lib.synth_rows(seed, [17], D)[0].astype(np.float64)
+    assert abs(plain @ got[2].astype(np.float64) / np.linalg.norm(plain) - 1.0) < 1e-6
+
+
+def test_scan_synth_unit_matches_materialised_and_threads():
+    D, N = 128, 700
+    plants = [(300, 20, 1), (301, 21, 2), (650, 20, 2)]
+    db = oracle_lib.synth_rows(21, range(N), D, plants, unit=True)
+    q = db[[N - 1, N - 2, 300]]
+    a = oracle_lib.scan_topk(db, N - 50, q, 8)
+    for nt in (1, 3, 8):
+        b = oracle_lib.scan_topk_synth(21, N - 50, D, q, 8, plants, nthreads=nt, unit=True)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[1][2][0] == 300 and abs(a[0][2][0] - 1.0) < 1e-6      # row 300 against itself: a unit vector
+    assert a[1][2][1] == 20 and 0.95 < a[0][2][1] < 0.995          # ... then row 20, which it is a noisy copy of (row 650 is outside the prefix)
+
+
 def test_scan_synth_matches_materialised_and_threads():
     D, N = 128, 700
     plants = [(300, 20, 1), (301, 21, 2), (650, 20, 2)]
