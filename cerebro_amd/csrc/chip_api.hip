@@ -601,8 +601,10 @@ static int create_impl(chip_ctx *c, int64_t capacity_hint, int elem)
     }
     CHIP_HIP(c, hipMalloc(&c->tickets_dev, Ctx::kRing * sizeof(int32_t)));
     CHIP_HIP(c, hipMemset(c->tickets_dev, 0, Ctx::kRing * sizeof(int32_t)));
-    CHIP_HIP(c, hipMalloc(&c->pair_ctr_dev, (size_t)Ctx::kRing * Ctx::kPairCtrs * Ctx::kPairStride * sizeof(uint32_t)));
-    CHIP_HIP(c, hipMemset(c->pair_ctr_dev, 0, (size_t)Ctx::kRing * Ctx::kPairCtrs * Ctx::kPairStride * sizeof(uint32_t)));
+    if ((c->scan_depth & 255) == 7) {   // tuning builds only (pair-claimed stream, profiles/r06_short_scan.md): the product allocates nothing for it
+        CHIP_HIP(c, hipMalloc(&c->pair_ctr_dev, (size_t)Ctx::kRing * Ctx::kPairCtrs * Ctx::kPairStride * sizeof(uint32_t)));
+        CHIP_HIP(c, hipMemset(c->pair_ctr_dev, 0, (size_t)Ctx::kRing * Ctx::kPairCtrs * Ctx::kPairStride * sizeof(uint32_t)));
+    }
     c->tick_fused = env_int("CHIP_TICK_FUSED", 1) != 0;
     c->tick_poll = env_int("CHIP_TICK_POLL", 1) != 0;
     // opt-in: synchronous ticks over cache-sized prefixes go to a scan instance that stays on the chip (chip_internal.h ResidentCmd)
@@ -720,7 +722,7 @@ int enqueue_scan_merge(Ctx *c, int64_t k, const void *const *q, int nq, int K, i
         a.fused_result = res;
         a.fused_ticket = c->tickets_dev + b;
         // tuning builds, CHIP_SCAN_DEPTH=7 only: rows claimed by PAIRS of workgroups (b, b + grid / 2: the older and the younger workgroup of a CU) from one counter
-        if ((a.dyn_claim & 255) == 7 && (grid & 15) == 0 && grid / 2 <= Ctx::kPairCtrs) a.pair_ctr = c->pair_ctr_dev + (size_t)b * Ctx::kPairCtrs * Ctx::kPairStride;
+        if ((a.dyn_claim & 255) == 7 && c->pair_ctr_dev && (grid & 15) == 0 && grid / 2 <= Ctx::kPairCtrs) a.pair_ctr = c->pair_ctr_dev + (size_t)b * Ctx::kPairCtrs * Ctx::kPairStride;
         a.tick_l = l;
         a.locality = p->locality;
         a.thresh = p->thresh;
