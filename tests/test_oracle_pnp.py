@@ -187,6 +187,32 @@ def test_ransac_reference_mode_adaptive_termination():
     assert r["confidence"] == pytest.approx(np.float32(conf))
 
 
+@pytest.mark.parametrize("thresh,ratio,cite", [(0.02, 0.90, "unittest_theia.cpp:489-494"), (0.02, 0.7, "unittest_theia.cpp:1283-1287, Cerebro.cpp:1976-1980")])
+def test_ransac_with_the_reference_s_other_parameter_sets(thresh, ratio, cite):
+    """Besides the production set (0.03 / 0.7, DlsPnpWithRansac.cpp:207-212) the reference runs DlsPnpWithRansac with two more:
+    its own manual test uses error_thresh 0.02 with min_inlier_ratio 0.90 -- which caps the run at ComputeMaxIterations(15, .9) = 20
+    iterations before the first hypothesis -- and a second (dead) copy uses 0.02 / 0.7.  The sequential rule replayed in Python."""
+    X, uv, T, inl = M.make_scene(N=300, outlier_frac=0.04, noise_px=0.3, seed=21)
+    prm = O.ransac_params(seed=5, error_thresh=thresh, min_inlier_ratio=ratio)
+    r = O.pnp_ransac(X, uv, prm)
+    s = r["summary"]
+    lib = O._bind_pnp()
+    max_it = min(50, lib.orc_ransac_max_iterations(15, ratio, math.log(0.01), 5, 50))
+    assert max_it == (20 if ratio == 0.90 else 50), cite
+    best, it, best_h = np.inf, 0, -1
+    while it < max_it:
+        ok, Th, _ = O.pnp_hypothesis(X, uv, 5, it)
+        if ok:
+            cost, nin, _ = O.score_model(Th, X, uv, thresh=thresh)
+            if cost < best:
+                best, best_h = cost, it
+                if nin / 300 >= 15 / 300:
+                    max_it = min(max_it, lib.orc_ransac_max_iterations(15, nin / 300, math.log(0.01), 5, 50))
+        it += 1
+    assert (it, best_h) == (s["n_iterations"], s["best_hypothesis"]) and 5 <= it <= (20 if ratio == 0.90 else 50)
+    assert rel_frob(r["T"][:3, :3], T[:3, :3]) < 0.02
+
+
 def test_ransac_edge_cases():
     X, uv, T, inl = M.make_scene(N=64, outlier_frac=0.0, noise_px=0.0, seed=1)
     assert O.pnp_ransac(X[:19], uv[:19])["status"] == -9            # DlsPnpWithRansac.cpp:136-139 (<20 points -> -1)

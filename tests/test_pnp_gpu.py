@@ -71,6 +71,27 @@ def test_random_scenes_both_modes(N, outl, noise, seed):
         check_against_oracle(chip, X, uv, seed=seed, use_mle=0, n_hypotheses=64)  # inlier-count quality measure
 
 
+@pytest.mark.parametrize("thresh,ratio", [(0.02, 0.90), (0.02, 0.7)])
+def test_the_reference_s_other_parameter_sets(thresh, ratio):
+    """The parameter sets the reference runs DlsPnpWithRansac with besides production's 0.03 / 0.7 (DlsPnpWithRansac.cpp:207-212):
+    its manual test's 0.02 / 0.90 (unittest_theia.cpp:489-494: at most ComputeMaxIterations(15, .9) = 20 iterations) and 0.02 / 0.7
+    (unittest_theia.cpp:1283-1287, Cerebro.cpp:1976-1980).  Adaptive mode, both samplers, clean and cluttered scenes; also batched."""
+    with capi.Chip(256) as chip:
+        for N, outl, noise, seed in [(300, 0.04, 0.3, 21), (512, 0.3, 0.5, 4242), (64, 0.0, 0.0, 3), (2000, 0.08, 0.4, 8)]:
+            X, uv, T, inl = M.make_scene(N=N, outlier_frac=outl, noise_px=noise, seed=seed)
+            for sampler in (capi.CHIP_SAMPLER_FRESH, capi.CHIP_SAMPLER_THEIA_PERSISTENT):
+                g, o = check_against_oracle(chip, X, uv, seed=seed, error_thresh=thresh, min_inlier_ratio=ratio, sampler=sampler)
+                assert 5 <= g["summary"]["n_iterations"] <= (20 if ratio == 0.90 else 50)
+        Xa, uva, _, _ = M.make_scene(N=300, outlier_frac=0.04, noise_px=0.3, seed=21)
+        Xb, uvb, _, _ = M.make_scene(N=150, outlier_frac=0.1, noise_px=0.3, seed=22)
+        p = gparams(error_thresh=thresh, min_inlier_ratio=ratio)
+        rs = chip.pnp_ransac_batch([(Xa, uva), (Xb, uvb)], p, seeds=[21, 22])
+        for (X, uv), sd, r in zip([(Xa, uva), (Xb, uvb)], [21, 22], rs):
+            o = O.pnp_ransac(X, uv, O.ransac_params(seed=sd, error_thresh=thresh, min_inlier_ratio=ratio))
+            assert r["summary"]["n_iterations"] == o["summary"]["n_iterations"] and r["summary"]["best_hypothesis"] == o["summary"]["best_hypothesis"]
+            assert np.array_equal(r["mask"], o["mask"]) and np.array_equal(r["T"].view(np.uint64), o["T"].view(np.uint64))
+
+
 def test_config3_512_correspondences_1000_hypotheses():
     """BASELINE config 3: 512-correspondence DlsPnpWithRansac, 1k hypotheses."""
     X, uv, T, inl = M.make_scene(N=512, outlier_frac=0.3, noise_px=0.5, seed=4242)
