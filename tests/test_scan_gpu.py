@@ -68,7 +68,13 @@ def test_topk_parity_shapes(D, N):
         assert_topk_equal(chip.query_vectors(N, q, 8), oracle_lib.scan_topk(db, N, q, 8))
 
 
-def test_tick_sequence_parity_and_tie_rule():
+@pytest.mark.parametrize("env", [{}, {"CHIP_TICK_FUSED": "0"}, {"CHIP_TICK_POLL": "0"}, {"CHIP_TICK_FUSED": "0", "CHIP_TICK_SAME_STREAM": "0"}],
+                         ids=["default", "two-launch tick", "event-collected tick", "two-launch tick on the scan streams"])
+def test_tick_sequence_parity_and_tie_rule(env, monkeypatch):
+    """... in the product's form of the short tick (one fused launch, completion word polled) and in its documented fall-backs: the
+    two-launch tick (K1 lists -> K2 merge: kernel-boundary visibility only, README `CHIP_TICK_FUSED=0`) and the event-collected one."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     D, N = 1024, 1500
     plants, loops, ties = scenarios.loop_plants(N, 6, seed=42)
     db = scenarios.build_db(31337, N, D, plants)
