@@ -553,22 +553,24 @@ def shape_leg(rows, dim, storage, inflight, n_ticks=240):
     return leg
 
 
-def paced_tick_leg(rows, n=60, pause_ms=100):
+def paced_tick_leg(rows, n=60, pause_ms=100, spin=False):
     """Synchronous ticks at the reference's own cadence -- dot_product_th ticks at 10 Hz (Cerebro.cpp:1100), so the GPU has idled for
     100 ms when a tick arrives -- launched and through the resident instance, measured by the C caller examples/sync_tick_latency.cc
     (built by `make` into cerebro_amd/lib/): through the ctypes binding the first call after a sleep carries tens of microseconds of
-    cold-interpreter jitter on about every third tick (scripts/gpu_paced_ticks.py), which is not the library's.  None without the tool."""
+    cold-interpreter jitter on about every third tick (scripts/gpu_paced_ticks.py), which is not the library's.  None without the tool.
+    spin: the caller BUSY-WAITS through the pause instead of sleeping -- the GPU idles exactly as long, the host core stays awake: what
+    is left of the idle penalty then is the GPU's (the cold hardware queue), not the waking host's (profiles/r06_paced.md)."""
     import subprocess
     tool = ROOT / "cerebro_amd" / "lib" / "sync_tick_latency"
     if not tool.exists():
         return None
-    out = {"rows": rows, "ticks": n, "pause_ms": pause_ms, "caller": "examples/sync_tick_latency.cc"}
+    out = {"rows": rows, "ticks": n, "pause_ms": pause_ms, "pause": "spin" if spin else "sleep", "caller": "examples/sync_tick_latency.cc"}
     for mode in ("launched", "resident"):
         env = {k: v for k, v in os.environ.items() if k != "CHIP_TICK_RESIDENT"}
         if mode == "resident":
             env["CHIP_TICK_RESIDENT"] = "1"
         try:
-            r = subprocess.run([str(tool), str(rows), str(n), "0", str(pause_ms)], env=env, capture_output=True, text=True, timeout=120)
+            r = subprocess.run([str(tool), str(rows), str(n), "0", str(pause_ms), "spin" if spin else "sleep"], env=env, capture_output=True, text=True, timeout=120)
             line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
             out[mode] = json.loads(line)["sync_tick"]
         except Exception as e:      # noqa: BLE001 -- a reported figure, not a gate
@@ -637,6 +639,8 @@ ROOFLINE_EXTRA_SCALARS = [
     ("size_f64_1M_ms_per_step", "shapes.f64_1M.ms_per_step"),
     ("size_10k_sync_tick_10hz_launched_after_contexts_us", "paced_10hz.after_contexts.launched.p50_us"),
     ("size_10k_sync_tick_10hz_resident_after_contexts_us", "paced_10hz.after_contexts.resident.p50_us"),
+    ("size_10k_sync_tick_10hz_spin_launched_us", "paced_10hz.spin.launched.p50_us"),
+    ("size_10k_sync_tick_10hz_spin_resident_us", "paced_10hz.spin.resident.p50_us"),
     ("size_10k_sync_tick_launched_us", "resident_tick.10k.launched.p50_us"),
     ("size_10k_sync_tick_resident_us", "resident_tick.10k.resident.p50_us"),
     ("size_29k_sync_tick_launched_us", "resident_tick.29k.launched.p50_us"),
@@ -1125,9 +1129,12 @@ def main():
             # the paced leg ran BEFORE this process created any HIP context (first) and runs again now, with the
             # bench's contexts, streams and 16+ GB of device memory alive (after_contexts) -- the pair says what the held queues cost
             out["paced_10hz"] = {"first": paced_first, "after_contexts": paced_tick_leg(10_000, n=args.paced_ticks),
+                                 "spin": paced_tick_leg(10_000, n=max(10, args.paced_ticks // 2), spin=True),
                                  "what": "synchronous chip_loop_tick at the reference's 10 Hz cadence (100 ms idle before every tick), C caller "
                                          "examples/sync_tick_latency.cc in a process of its own; `first` = nothing else on the GPU, `after_contexts` = "
-                                         "while this bench process holds its contexts (DB, tick streams, PnP / ICP / batch buffers)"}
+                                         "while this bench process holds its contexts (DB, tick streams, PnP / ICP / batch buffers); `spin` = the caller "
+                                         "busy-waits through the 100 ms instead of sleeping (same GPU idle time, host core awake): the difference to the "
+                                         "slept figures is the waking host, what remains above the back-to-back tick is the idle hardware queue"}
         if size_plans and single and args.storage == "f32" and (capi.load_library().chip_build_scan_forms() & 2):
             # the opt-in resident scan instance at the two sizes of the reference's operating range (ctxs of their own, a few hundred ms)
             out["resident_tick"] = {fmt_rows(r): resident_leg(r) for r in (10_000, 29_000)}

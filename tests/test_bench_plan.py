@@ -90,7 +90,8 @@ def _synthetic_record(n_gpus=1):
                      "pure_read_ceiling": {"value": 7090.0}},
         "sizes": {"10k": leg(1), "29k": leg(2), "100k": leg(3), "1M": {"value": 422.0}},
         "shapes": {"8192x29k": leg(4), "f64_1M": leg(5)},
-        "paced_10hz": {"first": {"launched": stat(52), "resident": stat(36)}, "after_contexts": {"launched": stat(70), "resident": stat(37)}},
+        "paced_10hz": {"first": {"launched": stat(52), "resident": stat(36)}, "after_contexts": {"launched": stat(70), "resident": stat(37)},
+                       "spin": {"launched": stat(47), "resident": stat(35.4)}},
         "resident_tick": {"10k": {"launched": stat(40), "resident": stat(35)}, "29k": {"launched": stat(95), "resident": stat(90)}},
         "pnp": {"value": 1.4e6, "ms_per_call_1000_hyp": 0.71, "batch8_hypotheses_per_s": 2.5e6, "reference_mode_ms_per_call": 0.46,
                 "reference_mode_pair_ms_per_call": 0.47, "cpu_baseline": {"value": 7000.0},
@@ -126,6 +127,7 @@ def test_record_layout_keeps_both_halves_of_the_metric_inside_what_the_driver_ke
     assert cfg["pnp_hyp_per_s"] == 1.4e6 and cfg["pnp_roofline_frac_batch8"] == 0.028 and roof["pnp_reference_mode_pair_ms_per_call"] == 0.47
     assert abs(cfg["size_29k_roofline_frac_kernel"] - 0.52) < 1e-12 and abs(cfg["size_f64_1M_roofline_frac_actual_bytes"] - 0.85) < 1e-12
     assert cfg["size_10k_sync_tick_10hz_launched_us"] == 52.0 and roof["size_10k_sync_tick_10hz_launched_after_contexts_us"] == 70.0
+    assert roof["size_10k_sync_tick_10hz_spin_launched_us"] == 47.0 and roof["size_10k_sync_tick_10hz_spin_resident_us"] == 35.4   # (round 6: the pause spun through)
     # the contract's own numbers are untouched
     assert roof["frac"] == 0.8625 and roof["achieved"] == 6900.0 and roof["kernel"] == "db_scan_topk" and json_rt["value"] == 422.0
 
